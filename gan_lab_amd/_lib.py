@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI kernel library (include/ganlab_hip.h -> csrc/libganlab_hip.so).
+
+There is NO fallback: if the shared library is missing or a kernel returns an error code the call
+raises.  PyTorch is used only for device memory, streams and autograd bookkeeping.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SO_PATH = os.path.join(CSRC, 'libganlab_hip.so')
+
+_c_int, _c_ll, _c_f, _c_p, _c_sz, _c_u64 = (ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_uint64)
+
+ACT_NONE, ACT_LRELU = 0, 1
+PACK_FWD, PACK_DGRAD = 0, 1
+
+
+class ConvGeom(ctypes.Structure):
+    """Mirror of `ganlab_conv_geom` (include/ganlab_hip.h)."""
+    _fields_ = [('N', _c_int), ('Cin', _c_int), ('Hin', _c_int), ('Win', _c_int),
+                ('Cout', _c_int), ('ks', _c_int), ('pad', _c_int), ('up', _c_int)]
+
+
+_GP = ctypes.POINTER(ConvGeom)
+
+# name -> (restype, argtypes): must list every function declared in include/ganlab_hip.h
+SIGNATURES = {
+    'ganlab_abi_version': (_c_int, []),
+    'ganlab_conv_out_hw': (_c_int, [_GP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    'ganlab_conv_pack_f32': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_conv_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_dgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_wgrad_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_blur3x3_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_p]),
+    'ganlab_up2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_pool2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_bias_act_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_act_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_f, _c_p]),
+    'ganlab_channel_sum_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_channel_sum_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
+    'ganlab_instnorm_stats_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_f, _c_p]),
+    'ganlab_instnorm_style_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'ganlab_instnorm_style_bwd_reduce_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_p]),
+    'ganlab_instnorm_style_bwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int,
+                                                     _c_ll, _c_p]),
+    'ganlab_pixelnorm_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_pixelnorm_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_mbstd_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_mbstd_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_mbstd_bwdbwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_axpby_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_f, _c_f, _c_p]),
+    'ganlab_scale_dev_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_f, _c_p]),
+    'ganlab_lerp_rows_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_p]),
+    'ganlab_sum_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_f, _c_int, _c_p, _c_sz, _c_p]),
+    'ganlab_sum_workspace': (_c_sz, [_c_ll]),
+    'ganlab_bce_logits_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_f, _c_p]),
+    'ganlab_bce_logits_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_f, _c_p]),
+    'ganlab_chnorm_penalty_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_chnorm_penalty_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_f, _c_p]),
+    'ganlab_adam_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
+    'ganlab_ewma_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_f, _c_p]),
+    'ganlab_randn_f32': (_c_int, [_c_p, _c_ll, _c_u64, _c_u64, _c_p]),
+}
+
+_LIB = None
+
+
+class GanlabLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise GanlabLibraryError('building libganlab_hip.so failed:\n' + res.stderr[-4000:])
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise GanlabLibraryError(
+                f'{SO_PATH} not found: the HIP kernel library is required (there is no CPU/PyTorch '
+                f'fallback). Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+                f'`make -C {CSRC}`.')
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+_ERR = {-1: 'GANLAB_EINVAL (bad argument)', -2: 'GANLAB_EWORKSPACE (workspace too small)',
+        -3: 'GANLAB_ELAUNCH (kernel launch failed)'}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GanlabLibraryError(f'{what} failed: {_ERR.get(rc, rc)}')

@@ -1,0 +1,38 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ganlab_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GL_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? GANLAB_OK : GANLAB_ELAUNCH)
+
+static inline hipStream_t gl_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch"):
+// hand each XCD a contiguous chunk of the logical tile space so tiles that share operand panels hit
+// the same per-XCD L2.  Bijective for any grid size (cdna_hip_programming.md T1).  Speed only.
+__device__ __forceinline__ int gl_xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, xcd = b & 7, i = b >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + i;
+}
+
+__device__ __forceinline__ float gl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float gl_block_sum_256(float v, float* red) {
+  v = gl_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

@@ -1,0 +1,854 @@
+// HBM-bound elementwise / resampling / reduction kernels of the G+D step (fp32, NCHW).
+// Every kernel is a single pass over its tensors with 16-byte accesses where the row length allows
+// (cdna_hip_programming.md G13) and a grid capped at ~8 blocks/CU with a grid-stride loop (G11).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 8;
+
+inline unsigned ew_blocks(long long n_items) {
+  long long b = (n_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (unsigned)b;
+}
+
+#define GRID_STRIDE(i, n) \
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------------------------- //
+// blur: depthwise [1 2 1]x[1 2 1]/16, zero padding (custom_layers.py:41-51)
+// ---------------------------------------------------------------------------------------------- //
+__global__ void blur3x3_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W) {
+  const long long total = planes * H * W;
+  GRID_STRIDE(i, total) {
+    const int w = (int)(i % W);
+    const long long t = i / W;
+    const int h = (int)(t % H);
+    const float* px = x + (t - h) * W;  // plane base
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = h + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const float* row = px + (long long)yy * W;
+      const float l = (w > 0) ? row[w - 1] : 0.f;
+      const float c = row[w];
+      const float r = (w + 1 < W) ? row[w + 1] : 0.f;
+      const float rs = l + 2.f * c + r;
+      acc += (dy == 0) ? 2.f * rs : rs;
+    }
+    y[i] = acc * (1.f / 16.f);
+  }
+}
+
+__global__ void up2_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W,
+                           float scale) {
+  const int Wo = 2 * W, Ho = 2 * H;
+  const long long total = planes * Ho * Wo;
+  GRID_STRIDE(i, total) {
+    const int w = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int h = (int)(t % Ho);
+    const long long pl = t / Ho;
+    y[i] = scale * x[(pl * H + (h >> 1)) * W + (w >> 1)];
+  }
+}
+
+__global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int Ho, int Wo,
+                             float scale) {
+  const int W = 2 * Wo;
+  const long long total = planes * Ho * Wo;
+  GRID_STRIDE(i, total) {
+    const int w = (int)(i % Wo);
+    const long long t = i / Wo;  // = pl*Ho + h
+    const float2 a = *reinterpret_cast<const float2*>(x + (2 * t) * W + 2 * w);
+    const float2 b = *reinterpret_cast<const float2*>(x + (2 * t + 1) * W + 2 * w);
+    y[i] = scale * ((a.x + a.y) + (b.x + b.y));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// y = act(x + noise_w[c]*noise[n,hw] + bias[c]*bias_scale)
+// ---------------------------------------------------------------------------------------------- //
+template <int VEC>
+__global__ void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                float* __restrict__ y, int N, int C, long long HW, float bias_scale, int act,
+                                float slope) {
+  const long long hwv = HW / VEC, total = (long long)N * C * hwv;
+  GRID_STRIDE(i, total) {
+    const long long pl = i / hwv, hv = i - pl * hwv;
+    const int c = (int)(pl % C);
+    const long long n = pl / C;
+    const float b = bias ? bias[c] * bias_scale : 0.f;
+    const float nw = noise ? noise_w[c] : 0.f;
+    float v[VEC], nz[VEC];
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(x + i * 4);
+      if (noise) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + (n * hwv + hv) * 4);
+    } else {
+      v[0] = x[i];
+      if (noise) nz[0] = noise[n * HW + hv];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float t = v[k] + b;
+      if (noise) t += nw * nz[k];
+      if (act == GANLAB_ACT_LRELU) t = gl_lrelu(t, slope);
+      v[k] = t;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(y + i * 4) = *reinterpret_cast<float4*>(v);
+    else y[i] = v[0];
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gz,
+                               long long n, float slope) {
+  const long long n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    const float4 g = reinterpret_cast<const float4*>(gy)[i];
+    const float4 o = reinterpret_cast<const float4*>(y)[i];
+    float4 r;
+    r.x = o.x > 0.f ? g.x : g.x * slope;
+    r.y = o.y > 0.f ? g.y : g.y * slope;
+    r.z = o.z > 0.f ? g.z : g.z * slope;
+    r.w = o.w > 0.f ? g.w : g.w * slope;
+    reinterpret_cast<float4*>(gz)[i] = r;
+  }
+  // tail
+  const long long base = n4 << 2;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (tid < n - base) {
+    const long long j = base + tid;
+    gz[j] = y[j] > 0.f ? gy[j] : gy[j] * slope;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// per-channel sums: out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)
+// stage 1: grid (chunks, C); stage 2: one wave per channel
+// ---------------------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ part, int N, int C, long long HW,
+                                                          int chunks) {
+  __shared__ float red[4];
+  const int c = blockIdx.y, chunk = blockIdx.x;
+  const long long total = (long long)N * HW;
+  float s = 0.f;
+  for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
+    const long long n = i / HW, hw = i - n * HW;
+    const float v = a[(n * C + c) * HW + hw];
+    s += b ? v * b[i] : v;
+  }
+  s = gl_block_sum_256(s, red);
+  if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s;
+}
+
+__global__ void channel_sum_stage2(const float* __restrict__ part, float* __restrict__ out, int C, int chunks,
+                                   float scale) {
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < chunks; i += 64) s += part[(long long)c * chunks + i];
+  s = gl_wave_sum(s);
+  if (threadIdx.x == 0) out[c] = s * scale;
+}
+
+inline int channel_chunks(int N, long long HW) {
+  long long c = ((long long)N * HW + 256 * 32 - 1) / (256 * 32);
+  if (c < 1) c = 1;
+  if (c > 128) c = 128;
+  return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// InstanceNorm (biased var, eps) + AdaIN affine
+// ---------------------------------------------------------------------------------------------- //
+template <int T>  // threads cooperating on one plane: 64 or 256
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, long long planes,
+                                                             long long HW, float eps) {
+  __shared__ double red[2][4];
+  const int sub = (T == 64) ? (threadIdx.x >> 6) : 0;
+  const int t = (T == 64) ? (threadIdx.x & 63) : threadIdx.x;
+  const long long pl = (T == 64) ? (blockIdx.x * 4LL + sub) : blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  if (pl < planes) {
+    const float* p = x + pl * HW;
+    if ((HW & 3) == 0) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      for (long long i = t; i < (HW >> 2); i += T) {
+        const float4 v = p4[i];
+        const float a = (v.x + v.y) + (v.z + v.w);
+        const float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        s += a;
+        ss += q;
+      }
+    } else {
+      for (long long i = t; i < HW; i += T) {
+        const float v = p[i];
+        s += v;
+        ss += (double)v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  if (T == 256) {
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = s;
+      red[1][threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+  if (t == 0 && pl < planes) {
+    const double m = s / (double)HW;
+    double var = ss / (double)HW - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[pl] = (float)m;
+    rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <int VEC>
+__global__ void instnorm_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, const float* __restrict__ style,
+                                          float* __restrict__ y, int N, int C, long long HW) {
+  const long long hwv = HW / VEC, total = (long long)N * C * hwv;
+  GRID_STRIDE(i, total) {
+    const long long pl = i / hwv;
+    const int c = (int)(pl % C);
+    const long long n = pl / C;
+    const float m = mean[pl], r = rstd[pl];
+    const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
+    const float yb = style ? style[(n * 2 + 1) * C + c] : 0.f;
+    const float a = r * ys, b = yb - m * r * ys;
+    if (VEC == 4) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+      reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+      y[i] = x[i] * a + b;
+    }
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ gy,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  float* __restrict__ s1, float* __restrict__ s2,
+                                                                  long long planes, long long HW) {
+  __shared__ double red[2][4];
+  const int sub = (T == 64) ? (threadIdx.x >> 6) : 0;
+  const int t = (T == 64) ? (threadIdx.x & 63) : threadIdx.x;
+  const long long pl = (T == 64) ? (blockIdx.x * 4LL + sub) : blockIdx.x;
+  double a = 0.0, b = 0.0;
+  if (pl < planes) {
+    const float m = mean[pl], r = rstd[pl];
+    const float* pg = gy + pl * HW;
+    const float* px = x + pl * HW;
+    if ((HW & 3) == 0) {
+      for (long long i = t; i < (HW >> 2); i += T) {
+        const float4 g = reinterpret_cast<const float4*>(pg)[i];
+        const float4 v = reinterpret_cast<const float4*>(px)[i];
+        a += (g.x + g.y) + (g.z + g.w);
+        b += (g.x * ((v.x - m) * r) + g.y * ((v.y - m) * r)) + (g.z * ((v.z - m) * r) + g.w * ((v.w - m) * r));
+      }
+    } else {
+      for (long long i = t; i < HW; i += T) {
+        a += pg[i];
+        b += pg[i] * ((px[i] - m) * r);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (T == 256) {
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = a;
+      red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+  if (t == 0 && pl < planes) {
+    s1[pl] = (float)a;
+    s2[pl] = (float)b;
+  }
+}
+
+template <int VEC>
+__global__ void instnorm_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const float* __restrict__ style, const float* __restrict__ s1,
+                                          const float* __restrict__ s2, float* __restrict__ gx, int N, int C,
+                                          long long HW) {
+  const long long hwv = HW / VEC, total = (long long)N * C * hwv;
+  const float inv = 1.f / (float)HW;
+  GRID_STRIDE(i, total) {
+    const long long pl = i / hwv;
+    const int c = (int)(pl % C);
+    const long long n = pl / C;
+    const float m = mean[pl], r = rstd[pl];
+    const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
+    const float k = r * ys, a1 = s1[pl] * inv, a2 = s2[pl] * inv;
+    if (VEC == 4) {
+      const float4 g = reinterpret_cast<const float4*>(gy)[i];
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 o;
+      o.x = k * (g.x - a1 - (v.x - m) * r * a2);
+      o.y = k * (g.y - a1 - (v.y - m) * r * a2);
+      o.z = k * (g.z - a1 - (v.z - m) * r * a2);
+      o.w = k * (g.w - a1 - (v.w - m) * r * a2);
+      reinterpret_cast<float4*>(gx)[i] = o;
+    } else {
+      gx[i] = k * (gy[i] - a1 - (x[i] - m) * r * a2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// PixelNorm over channels (custom_layers.py:85-86); one thread per pixel, coalesced across pixels
+// ---------------------------------------------------------------------------------------------- //
+__global__ void pixelnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, long long HW,
+                                     float eps) {
+  const long long total = (long long)N * HW;
+  GRID_STRIDE(i, total) {
+    const long long n = i / HW, hw = i - n * HW;
+    const float* p = x + n * C * HW + hw;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = p[c * HW];
+      s += v * v;
+    }
+    const float r = rsqrtf(s / (float)C + eps);
+    float* q = y + n * C * HW + hw;
+    for (int c = 0; c < C; ++c) q[c * HW] = p[c * HW] * r;
+  }
+}
+
+__global__ void pixelnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                     float* __restrict__ gx, int N, int C, long long HW, float eps) {
+  const long long total = (long long)N * HW;
+  GRID_STRIDE(i, total) {
+    const long long n = i / HW, hw = i - n * HW;
+    const float* p = x + n * C * HW + hw;
+    const float* g = gy + n * C * HW + hw;
+    float s = 0.f, d = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = p[c * HW];
+      s += v * v;
+      d += v * g[c * HW];
+    }
+    const float r = rsqrtf(s / (float)C + eps);
+    const float k = r * r * r * d / (float)C;
+    float* q = gx + n * C * HW + hw;
+    for (int c = 0; c < C; ++c) q[c * HW] = g[c * HW] * r - p[c * HW] * k;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// minibatch-stddev statistic (custom_layers.py:117-140): one workgroup per group, wave-shuffle reduce
+// ---------------------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ stat,
+                                                        int gs, long long F, float eps) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  const float* base = x + (long long)g * gs * F;
+  float acc = 0.f;
+  for (long long f = threadIdx.x; f < F; f += 256) {
+    float mu = 0.f;
+    for (int i = 0; i < gs; ++i) mu += base[i * F + f];
+    mu /= (float)gs;
+    float v = 0.f;
+    for (int i = 0; i < gs; ++i) {
+      const float d = base[i * F + f] - mu;
+      v += d * d;
+    }
+    acc += sqrtf(v / (float)(gs - 1) + eps);
+  }
+  acc = gl_block_sum_256(acc, red);
+  if (threadIdx.x == 0) stat[g] = acc / (float)F;
+}
+
+__global__ void mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gstat,
+                                 float* __restrict__ gx, int G, int gs, long long F, float eps) {
+  const long long total = (long long)G * F;
+  GRID_STRIDE(t, total) {
+    const long long g = t / F, f = t - g * F;
+    const float* base = x + g * gs * F + f;
+    float mu = 0.f;
+    for (int i = 0; i < gs; ++i) mu += base[i * F];
+    mu /= (float)gs;
+    float v = 0.f;
+    for (int i = 0; i < gs; ++i) {
+      const float d = base[i * F] - mu;
+      v += d * d;
+    }
+    const float s = sqrtf(v / (float)(gs - 1) + eps);
+    const float k = gstat[g] / ((float)F * (float)(gs - 1) * s);
+    float* o = gx + g * gs * F + f;
+    for (int i = 0; i < gs; ++i) o[i * F] = k * (base[i * F] - mu);
+  }
+}
+
+// backward of mbstd_bwd w.r.t. (gstat, x) given the cotangent ggx of gx.
+__global__ __launch_bounds__(256) void mbstd_bwdbwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ gstat,
+                                                           const float* __restrict__ ggx,
+                                                           float* __restrict__ g_gstat, float* __restrict__ g_x,
+                                                           int gs, long long F, float eps) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  const float* bx = x + (long long)g * gs * F;
+  const float* bg = ggx + (long long)g * gs * F;
+  float* bo = g_x + (long long)g * gs * F;
+  const float c = 1.f / ((float)F * (float)(gs - 1));
+  const float G_ = gstat[g];
+  float acc = 0.f;
+  for (long long f = threadIdx.x; f < F; f += 256) {
+    float mu = 0.f, mg = 0.f;
+    for (int i = 0; i < gs; ++i) {
+      mu += bx[i * F + f];
+      mg += bg[i * F + f];
+    }
+    mu /= (float)gs;
+    mg /= (float)gs;
+    float v = 0.f, dot = 0.f;
+    for (int i = 0; i < gs; ++i) {
+      const float d = bx[i * F + f] - mu;
+      v += d * d;
+      dot += bg[i * F + f] * d;
+    }
+    const float s = sqrtf(v / (float)(gs - 1) + eps);
+    const float is = 1.f / s;
+    acc += dot * is;
+    const float k2 = dot * is * is * is / (float)(gs - 1);
+    for (int i = 0; i < gs; ++i) {
+      const float d = bx[i * F + f] - mu;
+      bo[i * F + f] = c * G_ * ((bg[i * F + f] - mg) * is - d * k2);
+    }
+  }
+  acc = gl_block_sum_256(acc, red);
+  if (threadIdx.x == 0) g_gstat[g] = c * acc;
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// elementwise axpby, reductions, losses
+// ---------------------------------------------------------------------------------------------- //
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                             long long n, float a, float b) {
+  const long long n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    if (y) {
+      const float4 w = reinterpret_cast<const float4*>(y)[i];
+      v.x += b * w.x; v.y += b * w.y; v.z += b * w.z; v.w += b * w.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  const long long base = n4 << 2;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (tid < n - base) {
+    const long long j = base + tid;
+    out[j] = a * x[j] + (y ? b * y[j] : 0.f);
+  }
+}
+
+// out = a * gout[0] * (x ? x[i] : 1): backward of the scalar reductions without a host sync
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                 float* __restrict__ out, long long n, float a) {
+  const float k = a * gout[0];
+  GRID_STRIDE(i, n) out[i] = x ? k * x[i] : k;
+}
+
+// out[n,m] = t[n]*a[n,m] + (1-t[n])*b[n,m]   (WGAN-GP interpolates, resnetgan/learner.py:793-796)
+__global__ void lerp_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                 const float* __restrict__ t, float* __restrict__ out, long long N, long long M) {
+  const long long total = N * M;
+  GRID_STRIDE(i, total) {
+    const float w = t[i / M];
+    out[i] = w * a[i] + (1.f - w) * b[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ x, float* __restrict__ part, long long n,
+                                                  int squared) {
+  __shared__ float red[4];
+  float s = 0.f;
+  GRID_STRIDE(i, n) {
+    const float v = x[i];
+    s += squared ? v * v : v;
+  }
+  s = gl_block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ part, float* __restrict__ out, int nb,
+                                                  float scale) {
+  __shared__ float red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  float f = gl_block_sum_256((float)s, red);
+  if (threadIdx.x == 0) out[0] = f * scale;
+}
+
+inline int sum_blocks(long long n) {
+  long long b = (n + 256 * 16 - 1) / (256 * 16);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
+                                                      float t) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = x[i];
+    s += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+  }
+  s = gl_block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout, float* __restrict__ gx,
+                               int n, float t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = x[i];
+    const float sg = 1.f / (1.f + expf(-v));
+    gx[i] = gout[0] * (sg - t) / (float)n;
+  }
+}
+
+__global__ __launch_bounds__(256) void chnorm_pen_stage1(const float* __restrict__ g, float* __restrict__ part,
+                                                         int N, int C, long long HW, float gamma) {
+  __shared__ float red[4];
+  const long long total = (long long)N * HW;
+  float s = 0.f;
+  GRID_STRIDE(i, total) {
+    const long long n = i / HW, hw = i - n * HW;
+    const float* p = g + n * C * HW + hw;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) q += p[c * HW] * p[c * HW];
+    const float d = sqrtf(q) - gamma;
+    s += d * d;
+  }
+  s = gl_block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void chnorm_pen_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gout,
+                                      float* __restrict__ gg, int N, int C, long long HW, float gamma, float scale) {
+  const long long total = (long long)N * HW;
+  const float go = gout[0] * scale * 2.f;
+  GRID_STRIDE(i, total) {
+    const long long n = i / HW, hw = i - n * HW;
+    const float* p = g + n * C * HW + hw;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) q += p[c * HW] * p[c * HW];
+    const float s = sqrtf(q);
+    const float k = s > 0.f ? go * (s - gamma) / s : 0.f;
+    float* o = gg + n * C * HW + hw;
+    for (int c = 0; c < C; ++c) o[c * HW] = k * p[c * HW];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// optimiser + EWMA + RNG
+// ---------------------------------------------------------------------------------------------- //
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2) {
+  const float step = lr / bc1, isq = rsqrtf(bc2);
+  GRID_STRIDE(i, n) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) * isq + eps);
+  }
+}
+
+__global__ void ewma_kernel(float* __restrict__ lag, const float* __restrict__ p, long long n, float beta) {
+  GRID_STRIDE(i, n) lag[i] = p[i] * (1.f - beta) + lag[i] * beta;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
+  const long long n4 = (n + 3) >> 2;
+  GRID_STRIDE(i, n4) {
+    const uint64_t ctr = offset + (uint64_t)i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u1 = ((float)c[2 * k] + 1.0f) * (1.0f / 4294967296.0f);  // (0,1]
+      const float u2 = (float)c[2 * k + 1] * (1.0f / 4294967296.0f);
+      const float rad = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.28318530717958647692f * u2, &sn, &cs);
+      r[2 * k] = rad * cs;
+      r[2 * k + 1] = rad * sn;
+    }
+    for (int k = 0; k < 4; ++k)
+      if (i * 4 + k < n) out[i * 4 + k] = r[k];
+  }
+}
+
+}  // namespace
+
+#define ST gl_stream(stream)
+
+extern "C" {
+
+int ganlab_abi_version(void) { return 1; }
+
+int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream) {
+  if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(blur3x3_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, ST, x, y, planes, H, W);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_up2_f32(const float* x, float* y, long long planes, int H, int W, float scale, void* stream) {
+  if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(up2_kernel, dim3(ew_blocks(planes * H * W * 4)), dim3(256), 0, ST, x, y, planes, H, W, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_pool2_f32(const float* x, float* y, long long planes, int Hout, int Wout, float scale, void* stream) {
+  if (!x || !y || planes <= 0 || Hout <= 0 || Wout <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(pool2_kernel, dim3(ew_blocks(planes * Hout * Wout)), dim3(256), 0, ST, x, y, planes, Hout,
+                     Wout, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                        int N, int C, long long HW, float bias_scale, int act, float slope, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
+  if ((HW & 3) == 0)
+    hipLaunchKernelGGL(bias_act_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST, x, bias,
+                       noise, noise_w, y, N, C, HW, bias_scale, act, slope);
+  else
+    hipLaunchKernelGGL(bias_act_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x, bias,
+                       noise, noise_w, y, N, C, HW, bias_scale, act, slope);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, float slope, void* stream) {
+  if (!gy || !y || !gz || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, gy, y, gz, n, slope);
+  return GL_CHECK_LAUNCH();
+}
+
+size_t ganlab_channel_sum_workspace(int N, int C, long long HW) {
+  return (size_t)C * channel_chunks(N, HW) * sizeof(float);
+}
+
+int ganlab_channel_sum_f32(const float* a, const float* b, float* out, int N, int C, long long HW, float scale,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a || !out || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  const int chunks = channel_chunks(N, HW);
+  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipLaunchKernelGGL(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (float*)workspace, N, C, HW,
+                     chunks);
+  hipLaunchKernelGGL(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, out, C, chunks, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long long planes, long long HW, float eps,
+                              void* stream) {
+  if (!x || !mean || !rstd || planes <= 0 || HW <= 0) return GANLAB_EINVAL;
+  if (HW >= 1024)
+    hipLaunchKernelGGL(instnorm_stats_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, x, mean, rstd, planes,
+                       HW, eps);
+  else
+    hipLaunchKernelGGL(instnorm_stats_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, x, mean,
+                       rstd, planes, HW, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float* rstd, const float* style,
+                                  float* y, int N, int C, long long HW, void* stream) {
+  if (!x || !mean || !rstd || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  if ((HW & 3) == 0)
+    hipLaunchKernelGGL(instnorm_style_fwd_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
+                       x, mean, rstd, style, y, N, C, HW);
+  else
+    hipLaunchKernelGGL(instnorm_style_fwd_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x,
+                       mean, rstd, style, y, N, C, HW);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_instnorm_style_bwd_reduce_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                         float* s1, float* s2, long long planes, long long HW, void* stream) {
+  if (!gy || !x || !mean || !rstd || !s1 || !s2 || planes <= 0 || HW <= 0) return GANLAB_EINVAL;
+  if (HW >= 1024)
+    hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, gy, x, mean,
+                       rstd, s1, s2, planes, HW);
+  else
+    hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, gy, x,
+                       mean, rstd, s1, s2, planes, HW);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_instnorm_style_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                        const float* style, const float* s1, const float* s2, float* gx, int N,
+                                        int C, long long HW, void* stream) {
+  if (!gy || !x || !mean || !rstd || !s1 || !s2 || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  if ((HW & 3) == 0)
+    hipLaunchKernelGGL(instnorm_bwd_apply_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
+                       gy, x, mean, rstd, style, s1, s2, gx, N, C, HW);
+  else
+    hipLaunchKernelGGL(instnorm_bwd_apply_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, gy,
+                       x, mean, rstd, style, s1, s2, gx, N, C, HW);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long HW, float eps, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, x, y, N, C, HW,
+                     eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, int C, long long HW, float eps,
+                             void* stream) {
+  if (!gy || !x || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, gy, x, gx, N, C,
+                     HW, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_mbstd_fwd_f32(const float* x, float* stat, int G, int gs, long long F, float eps, void* stream) {
+  if (!x || !stat || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(G), dim3(256), 0, ST, x, stat, gs, F, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_mbstd_bwd_f32(const float* x, const float* gstat, float* gx, int G, int gs, long long F, float eps,
+                         void* stream) {
+  if (!x || !gstat || !gx || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(ew_blocks((long long)G * F)), dim3(256), 0, ST, x, gstat, gx, G, gs, F,
+                     eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_mbstd_bwdbwd_f32(const float* x, const float* gstat, const float* ggx, float* g_gstat, float* g_x,
+                            int G, int gs, long long F, float eps, void* stream) {
+  if (!x || !gstat || !ggx || !g_gstat || !g_x || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(mbstd_bwdbwd_kernel, dim3(G), dim3(256), 0, ST, x, gstat, ggx, g_gstat, g_x, gs, F, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_axpby_f32(const float* x, const float* y, float* out, long long n, float a, float b, void* stream) {
+  if (!x || !out || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, x, y, out, n, a, b);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_scale_dev_f32(const float* x, const float* gout, float* out, long long n, float a, void* stream) {
+  if (!gout || !out || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, x, gout, out, n, a);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_lerp_rows_f32(const float* a, const float* b, const float* t, float* out, long long N, long long M,
+                         void* stream) {
+  if (!a || !b || !t || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(lerp_rows_kernel, dim3(ew_blocks(N * M)), dim3(256), 0, ST, a, b, t, out, N, M);
+  return GL_CHECK_LAUNCH();
+}
+
+size_t ganlab_sum_workspace(long long n) { return (size_t)sum_blocks(n) * sizeof(float); }
+
+int ganlab_sum_f32(const float* x, float* out, long long n, float scale, int squared, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  if (!x || !out || n <= 0) return GANLAB_EINVAL;
+  const int nb = sum_blocks(n);
+  if (!workspace || workspace_bytes < (size_t)nb * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipLaunchKernelGGL(sum_stage1, dim3(nb), dim3(256), 0, ST, x, (float*)workspace, n, squared);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_bce_logits_fwd_f32(const float* x, float* out, int n, float target, void* stream) {
+  if (!x || !out || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, ST, x, out, n, target);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_bce_logits_bwd_f32(const float* x, const float* gout, float* gx, int n, float target, void* stream) {
+  if (!x || !gout || !gx || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, x, gout, gx, n, target);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_chnorm_penalty_fwd_f32(const float* g, float* out, int N, int C, long long HW, float gamma, float scale,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !out || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  const int nb = sum_blocks((long long)N * HW);
+  if (!workspace || workspace_bytes < (size_t)nb * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipLaunchKernelGGL(chnorm_pen_stage1, dim3(nb), dim3(256), 0, ST, g, (float*)workspace, N, C, HW, gamma);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_chnorm_penalty_bwd_f32(const float* g, const float* gout, float* gg, int N, int C, long long HW,
+                                  float gamma, float scale, void* stream) {
+  if (!g || !gout || !gg || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(chnorm_pen_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, g, gout, gg, N,
+                     C, HW, gamma, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_adam_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, float wd, float bc1, float bc2, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, wd,
+                     bc1, bc2);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void* stream) {
+  if (!lagged || !p || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(ewma_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, lagged, p, n, beta);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream) {
+  if (!out || n <= 0) return GANLAB_EINVAL;
+  hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, offset);
+  return GL_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,718 @@
+"""Autograd ops over the HIP C-ABI (include/ganlab_hip.h).
+
+Layering:
+  k_*        thin launchers: torch tensors in (device memory + current stream), kernel call, tensor out.
+  _Fn        torch.autograd.Function subclasses.  Every backward is itself written with other
+             Functions of this module, so `torch.autograd.grad(..., create_graph=True)` (the R1 /
+             WGAN-GP penalty, reference resnetgan/learner.py:811-815) differentiates straight
+             through the hand-written kernels:
+                conv is bilinear -> {fwd, dgrad, wgrad} is closed under differentiation;
+                LeakyReLU'' = 0 -> act_bwd is linear in the cotangent, None towards the activation;
+                blur is self-adjoint; pool2/up2 are an adjoint pair; mbstd has an explicit bwd-of-bwd.
+  functional wrappers (conv2d, linear, bias_act, ...) used by custom_layers.py / the architectures.
+
+All ops require contiguous fp32 CUDA(HIP) tensors and raise otherwise - there is no CPU path.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, PACK_DGRAD, PACK_FWD, ConvGeom, check
+
+
+# ---------------------------------------------------------------------------------------------- #
+# plumbing
+# ---------------------------------------------------------------------------------------------- #
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t, what='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError(f'gan_lab_amd.ops: {what} must be a float32 tensor on the GPU (got '
+                        f'{type(t).__name__}, {getattr(t, "device", None)}, {getattr(t, "dtype", None)}); '
+                        f'the HIP path has no CPU fallback')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+class Geom:
+    """Static description of one convolution (mirrors ganlab_conv_geom) + derived output size."""
+    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'Ho', 'Wo', '_c')
+
+    def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0):
+        if ks not in (1, 3):
+            raise ValueError('conv kernels support ks in {1, 3}; a 4x4 valid conv runs as a linear')
+        self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up = \
+            int(N), int(Cin), int(Hin), int(Win), int(Cout), int(ks), int(pad), int(bool(up))
+        hv, wv = (2 * Hin, 2 * Win) if up else (Hin, Win)
+        self.Ho, self.Wo = hv + 2 * pad - ks + 1, wv + 2 * pad - ks + 1
+        self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up)
+
+    def ref(self):
+        return ctypes.byref(self._c)
+
+    @property
+    def in_shape(self):
+        return (self.N, self.Cin, self.Hin, self.Win)
+
+    @property
+    def out_shape(self):
+        return (self.N, self.Cout, self.Ho, self.Wo)
+
+
+# ---- packed-weight cache ------------------------------------------------------------------------
+# Packing (OIHW -> [tap][ci][co], eq-LR scale folded in) costs one tiny kernel; D weights are used
+# by 3 forward + several dgrad passes per step, so the result is cached until the weights change.
+# The entry keeps an alias of the weight alive so its address cannot be recycled under the key.
+_PACK_CACHE = {}
+_PACK_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by the fused optimiser after it rewrites parameters through raw pointers."""
+    _PACK_EPOCH[0] += 1
+    _PACK_CACHE.clear()
+
+
+def _packed(w, mode, scale):
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0])
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    if len(_PACK_CACHE) > 512:
+        _PACK_CACHE.clear()
+    cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    L = _lib.lib()
+    n = L.ganlab_conv_pack_f32(None, None, cout, cin, ks, mode, scale, None)
+    if n <= 0:
+        raise _lib.GanlabLibraryError(f'conv_pack size query failed ({n}) for weight {tuple(w.shape)}')
+    out = _new((n,), w)
+    rc = L.ganlab_conv_pack_f32(_p(w), _p(out), cout, cin, ks, mode, scale, _st())
+    if rc != n:
+        raise _lib.GanlabLibraryError(f'conv_pack failed ({rc})')
+    _PACK_CACHE[key] = (w.detach(), out)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- #
+# kernel launchers
+# ---------------------------------------------------------------------------------------------- #
+def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
+    x, w = _c(x, 'conv input'), _c(w, 'conv weight')
+    assert tuple(x.shape) == g.in_shape, (tuple(x.shape), g.in_shape)
+    assert tuple(w.shape) == (g.Cout, g.Cin, g.ks, g.ks), (tuple(w.shape), g.Cout, g.Cin, g.ks)
+    wp = _packed(w, PACK_FWD, scale)
+    if bias is not None:
+        bias = _c(bias, 'bias')
+        assert bias.numel() == g.Cout
+    y = _new(g.out_shape, x)
+    check(_lib.lib().ganlab_conv_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _st()),
+          'conv_fwd')
+    return y
+
+
+def k_conv_dgrad(gy, w, g, scale):
+    gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
+    assert tuple(gy.shape) == g.out_shape, (tuple(gy.shape), g.out_shape)
+    wp = _packed(w, PACK_DGRAD, scale)
+    hv, wv = (2 * g.Hin, 2 * g.Win) if g.up else (g.Hin, g.Win)
+    gxv = _new((g.N, g.Cin, hv, wv), gy)
+    check(_lib.lib().ganlab_conv_dgrad_f32(_p(gy), _p(wp), _p(gxv), g.ref(), _st()), 'conv_dgrad')
+    if g.up:
+        return k_pool2(gxv, 1.0)   # adjoint of the nearest upsample
+    return gxv
+
+
+def k_conv_wgrad(gy, x, g, scale):
+    gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
+    assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    L = _lib.lib()
+    nbytes = L.ganlab_conv_wgrad_workspace(g.ref())
+    ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
+    check(L.ganlab_conv_wgrad_f32(_p(gy), _p(x), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
+          'conv_wgrad')
+    return gw
+
+
+def k_blur(x):
+    x = _c(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().ganlab_blur3x3_f32(_p(x), _p(y), n * c, h, w, _st()), 'blur3x3')
+    return y
+
+
+def k_up2(x, scale=1.0):
+    x = _c(x)
+    n, c, h, w = x.shape
+    y = _new((n, c, 2 * h, 2 * w), x)
+    check(_lib.lib().ganlab_up2_f32(_p(x), _p(y), n * c, h, w, scale, _st()), 'up2')
+    return y
+
+
+def k_pool2(x, scale=0.25):
+    x = _c(x)
+    n, c, h, w = x.shape
+    assert h % 2 == 0 and w % 2 == 0
+    y = _new((n, c, h // 2, w // 2), x)
+    check(_lib.lib().ganlab_pool2_f32(_p(x), _p(y), n * c, h // 2, w // 2, scale, _st()), 'pool2')
+    return y
+
+
+def _nchw(x):
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1], 1
+    n, c = x.shape[0], x.shape[1]
+    hw = 1
+    for s in x.shape[2:]:
+        hw *= s
+    return n, c, hw
+
+
+def k_bias_act(x, bias, noise, noise_w, bias_scale, act, slope):
+    x = _c(x)
+    n, c, hw = _nchw(x)
+    y = torch.empty_like(x)
+    bias = _c(bias) if bias is not None else None
+    noise = _c(noise) if noise is not None else None
+    noise_w = _c(noise_w) if noise_w is not None else None
+    if noise is not None:
+        assert noise.numel() == n * hw and noise_w.numel() == c
+    check(_lib.lib().ganlab_bias_act_f32(_p(x), _p(bias), _p(noise), _p(noise_w), _p(y), n, c, hw, bias_scale, act,
+                                         slope, _st()), 'bias_act')
+    return y
+
+
+def k_act_bwd(gy, y, slope):
+    gy, y = _c(gy), _c(y)
+    assert gy.shape == y.shape
+    gz = torch.empty_like(gy)
+    check(_lib.lib().ganlab_act_bwd_f32(_p(gy), _p(y), _p(gz), gy.numel(), slope, _st()), 'act_bwd')
+    return gz
+
+
+def k_channel_sum(a, b=None, scale=1.0):
+    a = _c(a)
+    n, c, hw = _nchw(a)
+    L = _lib.lib()
+    nbytes = L.ganlab_channel_sum_workspace(n, c, hw)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
+    out = _new((c,), a)
+    b = _c(b) if b is not None else None
+    check(L.ganlab_channel_sum_f32(_p(a), _p(b), _p(out), n, c, hw, scale, _p(ws), ws.numel() * 4, _st()),
+          'channel_sum')
+    return out
+
+
+def k_axpby(x, y, a, b):
+    x = _c(x)
+    y = _c(y) if y is not None else None
+    if y is not None:
+        assert x.shape == y.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().ganlab_axpby_f32(_p(x), _p(y), _p(out), x.numel(), a, b, _st()), 'axpby')
+    return out
+
+
+def k_scale_dev(x, gout, a, shape=None):
+    gout = _c(gout)
+    x = _c(x) if x is not None else None
+    out = torch.empty_like(x) if x is not None else _new(shape, gout)
+    check(_lib.lib().ganlab_scale_dev_f32(_p(x), _p(gout), _p(out), out.numel(), a, _st()), 'scale_dev')
+    return out
+
+
+def k_sum(x, scale=1.0, squared=False):
+    x = _c(x)
+    L = _lib.lib()
+    ws = torch.empty((L.ganlab_sum_workspace(x.numel()) + 3) // 4, dtype=torch.float32, device=x.device)
+    out = _new((), x)
+    check(L.ganlab_sum_f32(_p(x), _p(out), x.numel(), scale, int(squared), _p(ws), ws.numel() * 4, _st()), 'sum')
+    return out
+
+
+def randn(shape, seed, offset, device):
+    """Counter-based N(0,1) (Philox4x32-10 + Box-Muller) - replaces torch.randn for latents
+    (utils/latent_utils.py:15) and per-layer noise (stylegan/architectures.py:115-116)."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().ganlab_randn_f32(_p(out), out.numel(), int(seed) & (2 ** 64 - 1), int(offset), _st()), 'randn')
+    return out
+
+
+def lerp_rows(a, b, t):
+    a, b, t = _c(a), _c(b), _c(t)
+    out = torch.empty_like(a)
+    n = a.shape[0]
+    check(_lib.lib().ganlab_lerp_rows_f32(_p(a), _p(b), _p(t), _p(out), n, a.numel() // n, _st()), 'lerp_rows')
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, bc1, bc2):
+    check(_lib.lib().ganlab_adam_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
+                                     _st()), 'adam')
+
+
+def ewma_step(lagged, p, beta):
+    check(_lib.lib().ganlab_ewma_f32(_p(lagged), _p(p), p.numel(), beta, _st()), 'ewma')
+
+
+# ---------------------------------------------------------------------------------------------- #
+# convolution: three mutually-recursive Functions (bilinear form  C(x, w) = s * conv(up?(x), w))
+# ---------------------------------------------------------------------------------------------- #
+class _ConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, g, s):
+        ctx.save_for_backward(x, w)
+        ctx.g, ctx.s = g, s
+        return k_conv_fwd(x, w, None, g, s)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+class _ConvDgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w, g, s):
+        ctx.save_for_backward(gy, w)
+        ctx.g, ctx.s = g, s
+        return k_conv_dgrad(gy, w, g, s)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        d_gy = _ConvFwd.apply(ggx, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        return d_gy, d_w, None, None
+
+
+class _ConvWgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, x, g, s):
+        ctx.save_for_backward(gy, x)
+        ctx.g, ctx.s = g, s
+        return k_conv_wgrad(gy, x, g, s)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        d_gy = _ConvFwd.apply(x, ggw, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        d_x = _ConvDgrad.apply(gy, ggw, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        return d_gy, d_x, None, None
+
+
+class _ActBwd(Function):
+    """gz = gy * lrelu'(y) from the saved OUTPUT y (sign(y) == sign(pre-activation))."""
+
+    @staticmethod
+    def forward(ctx, gy, y, slope):
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return k_act_bwd(gy, y, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        y, = ctx.saved_tensors
+        return _ActBwd.apply(gg, y, ctx.slope), None, None
+
+
+class _ChanSum(Function):
+    """(N,C,...) -> (C,) sum, optionally weighted by a (N,1,...) map (noise-weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        ctx.shape, ctx.scale = a.shape, scale
+        ctx.has_b = b is not None
+        return k_channel_sum(a, b, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.has_b:
+            raise NotImplementedError('double backward through the noise-weighted channel sum')
+        shape = ctx.shape
+        view = [1, shape[1]] + [1] * (len(shape) - 2)
+        return _Scale.apply(g.view(view).expand(shape), ctx.scale), None, None
+
+
+class _ConvBiasAct(Function):
+    """y = act(s*conv(up?(x), w) + bias*bias_scale) in ONE kernel (bias/LeakyReLU in the MFMA
+    epilogue).  Reference: Conv2dEx.forward (+ nn.LeakyReLU) custom_layers.py:202-211."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope):
+        y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope = g, s, bias_scale, act, slope
+        ctx.bias_shape = bias.shape if bias is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+        gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
+            gb = _ChanSum.apply(gz, None, ctx.bias_scale).view(ctx.bias_shape)
+        return gx, gw, gb, None, None, None, None, None
+
+
+class _BiasAct(Function):
+    """y = act(x + noise_w*noise + bias*bias_scale)  (Conv2dBias + StyleAddNoise + LeakyReLU:
+    custom_layers.py:213-226, stylegan/architectures.py:105-119)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope):
+        y = k_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+        ctx.save_for_backward(y if act != ACT_NONE else None, noise)
+        ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, noise = ctx.saved_tensors
+        gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+        gb = gnw = None
+        if ctx.bias_shape is not None and ctx.needs_input_grad[1]:
+            gb = _ChanSum.apply(gz, None, ctx.bias_scale).view(ctx.bias_shape)
+        if ctx.nw_shape is not None and ctx.needs_input_grad[3]:
+            gnw = _ChanSum.apply(gz, noise, 1.0).view(ctx.nw_shape)
+        return (gz if ctx.needs_input_grad[0] else None), gb, None, gnw, None, None, None
+
+
+class _Blur(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return k_blur(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Blur.apply(g)  # symmetric taps + zero padding -> self-adjoint
+
+
+class _Pool2(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return k_pool2(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Up2.apply(g, ctx.scale), None
+
+
+class _Up2(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return k_up2(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Pool2.apply(g, ctx.scale), None
+
+
+class _Scale(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.a = a
+        return k_axpby(x, None, a, 0.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Scale.apply(g, ctx.a), None
+
+
+class _Axpby(Function):
+    """out = a*x + b*y (fade-in blends, progan/architectures.py:163-167, :311-315)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        ctx.a, ctx.b = a, b
+        return k_axpby(x, y, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = _Scale.apply(g, ctx.a) if ctx.needs_input_grad[0] else None
+        gy = _Scale.apply(g, ctx.b) if ctx.needs_input_grad[1] else None
+        return gx, gy, None, None
+
+
+# ---------------------------------------------------------------------------------------------- #
+# normalisation (generator side: first-order only)
+# ---------------------------------------------------------------------------------------------- #
+class _InstNormStyle(Function):
+    """y = InstanceNorm(x; eps, biased var) * (ys + 1) + yb  with style (N, 2C) = [ys | yb]
+    (custom_layers.py:98-99 + stylegan/architectures.py:524-526); style=None -> plain IN."""
+
+    @staticmethod
+    def forward(ctx, x, style, eps):
+        x = _c(x)
+        n, c, hw = _nchw(x)
+        L = _lib.lib()
+        mean, rstd = _new((n * c,), x), _new((n * c,), x)
+        check(L.ganlab_instnorm_stats_f32(_p(x), _p(mean), _p(rstd), n * c, hw, eps, _st()), 'instnorm_stats')
+        style_c = _c(style) if style is not None else None
+        if style_c is not None:
+            assert style_c.numel() == n * 2 * c
+        y = torch.empty_like(x)
+        check(L.ganlab_instnorm_style_fwd_f32(_p(x), _p(mean), _p(rstd), _p(style_c), _p(y), n, c, hw, _st()),
+              'instnorm_style_fwd')
+        ctx.save_for_backward(x, mean, rstd, style_c)
+        ctx.style_shape = style.shape if style is not None else None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, mean, rstd, style = ctx.saved_tensors
+        gy = _c(gy)
+        n, c, hw = _nchw(x)
+        L = _lib.lib()
+        s1, s2 = _new((n, c), x), _new((n, c), x)
+        check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
+                                                     _st()), 'instnorm_bwd_reduce')
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(L.ganlab_instnorm_style_bwd_apply_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
+                                                        _p(gx), n, c, hw, _st()), 'instnorm_bwd_apply')
+        gstyle = None
+        if style is not None and ctx.needs_input_grad[1]:
+            gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)  # d/dys = sum gy*xhat ; d/dyb = sum gy
+        return gx, gstyle, None
+
+
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _c(x)
+        n, c, hw = _nchw(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().ganlab_pixelnorm_fwd_f32(_p(x), _p(y), n, c, hw, eps, _st()), 'pixelnorm_fwd')
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        gy = _c(gy)
+        n, c, hw = _nchw(x)
+        gx = torch.empty_like(x)
+        check(_lib.lib().ganlab_pixelnorm_bwd_f32(_p(gy), _p(x), _p(gx), n, c, hw, ctx.eps, _st()), 'pixelnorm_bwd')
+        return gx, None
+
+
+# ---------------------------------------------------------------------------------------------- #
+# minibatch stddev statistic with explicit second order (discriminator, R1 path)
+# ---------------------------------------------------------------------------------------------- #
+class _MbstdStat(Function):
+    @staticmethod
+    def forward(ctx, x, gs, eps):
+        x = _c(x)
+        b = x.shape[0]
+        G, F = b // gs, x.numel() // b
+        stat = _new((G,), x)
+        check(_lib.lib().ganlab_mbstd_fwd_f32(_p(x), _p(stat), G, gs, F, eps, _st()), 'mbstd_fwd')
+        ctx.save_for_backward(x)
+        ctx.gs, ctx.eps = gs, eps
+        return stat
+
+    @staticmethod
+    def backward(ctx, gstat):
+        x, = ctx.saved_tensors
+        return _MbstdBwd.apply(x, gstat, ctx.gs, ctx.eps), None, None
+
+
+class _MbstdBwd(Function):
+    @staticmethod
+    def forward(ctx, x, gstat, gs, eps):
+        x, gstat = _c(x), _c(gstat)
+        b = x.shape[0]
+        G, F = b // gs, x.numel() // b
+        gx = torch.empty_like(x)
+        check(_lib.lib().ganlab_mbstd_bwd_f32(_p(x), _p(gstat), _p(gx), G, gs, F, eps, _st()), 'mbstd_bwd')
+        ctx.save_for_backward(x, gstat)
+        ctx.gs, ctx.eps = gs, eps
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx):
+        x, gstat = ctx.saved_tensors
+        ggx = _c(ggx)
+        b = x.shape[0]
+        G, F = b // ctx.gs, x.numel() // b
+        g_gstat, g_x = _new((G,), x), torch.empty_like(x)
+        check(_lib.lib().ganlab_mbstd_bwdbwd_f32(_p(x), _p(gstat), _p(ggx), _p(g_gstat), _p(g_x), G, ctx.gs, F,
+                                                 ctx.eps, _st()), 'mbstd_bwdbwd')
+        return g_x, g_gstat, None, None
+
+
+# ---------------------------------------------------------------------------------------------- #
+# scalar reductions / losses (first-order)
+# ---------------------------------------------------------------------------------------------- #
+class _Sum(Function):
+    """scale * sum(x) or scale * sum(x^2) -> 0-dim tensor; the cotangent never leaves the device."""
+
+    @staticmethod
+    def forward(ctx, x, scale, squared):
+        ctx.save_for_backward(x if squared else None)
+        ctx.scale, ctx.squared, ctx.shape = scale, squared, x.shape
+        return k_sum(x, scale, squared)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, = ctx.saved_tensors
+        if ctx.squared:
+            return k_scale_dev(x, gout.reshape(1), 2.0 * ctx.scale), None, None
+        return k_scale_dev(None, gout.reshape(1), ctx.scale, ctx.shape), None, None
+
+
+class _BceMean(Function):
+    @staticmethod
+    def forward(ctx, x, target):
+        x = _c(x)
+        out = _new((), x)
+        check(_lib.lib().ganlab_bce_logits_fwd_f32(_p(x), _p(out), x.numel(), target, _st()), 'bce_fwd')
+        ctx.save_for_backward(x)
+        ctx.target = target
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        g1 = _c(gout).reshape(1)
+        check(_lib.lib().ganlab_bce_logits_bwd_f32(_p(x), _p(g1), _p(gx), x.numel(), ctx.target, _st()), 'bce_bwd')
+        return gx, None
+
+
+class _ChNormPenalty(Function):
+    """scale * sum_{n,hw} (||g[n,:,hw]||_2 - gamma)^2  (WGAN-GP, resnetgan/learner.py:817-823)."""
+
+    @staticmethod
+    def forward(ctx, g, gamma, scale):
+        g = _c(g)
+        n, c, hw = _nchw(g)
+        L = _lib.lib()
+        ws = torch.empty((L.ganlab_sum_workspace(n * hw) + 3) // 4, dtype=torch.float32, device=g.device)
+        out = _new((), g)
+        check(L.ganlab_chnorm_penalty_fwd_f32(_p(g), _p(out), n, c, hw, gamma, scale, _p(ws), ws.numel() * 4, _st()),
+              'chnorm_penalty_fwd')
+        ctx.save_for_backward(g)
+        ctx.gamma, ctx.scale = gamma, scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        g, = ctx.saved_tensors
+        n, c, hw = _nchw(g)
+        gg = torch.empty_like(g)
+        g1 = _c(gout).reshape(1)
+        check(_lib.lib().ganlab_chnorm_penalty_bwd_f32(_p(g), _p(g1), _p(gg), n, c, hw, ctx.gamma, ctx.scale, _st()),
+              'chnorm_penalty_bwd')
+        return gg, None, None
+
+
+# ---------------------------------------------------------------------------------------------- #
+# functional API
+# ---------------------------------------------------------------------------------------------- #
+def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2):
+    """act(scale*conv2d(up2?(x), weight, padding) + bias*bias_scale) on the matrix cores."""
+    n, cin, h, w = x.shape
+    cout, cin_w, ks, _ = weight.shape
+    if ks == 4 and padding == 0 and h == 4 and w == 4 and not up:
+        # 4x4 valid conv on a 4x4 map == linear over (ci, ky, kx)  (progan/architectures.py:227-229)
+        y = linear(x.reshape(n, cin * 16), weight.reshape(cout, cin * 16), bias, scale, bias_scale, act, slope)
+        return y.view(n, cout, 1, 1)
+    g = Geom(n, cin, h, w, cout, ks, padding, up)
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    if bias is None and a == ACT_NONE:
+        return _ConvFwd.apply(x, weight, g, float(scale))
+    return _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), a, float(slope))
+
+
+def linear(x, weight, bias=None, scale=1.0, bias_scale=1.0, act=None, slope=0.2):
+    """act(scale * x @ weight.T + bias*bias_scale): a 1x1 conv over B 'pixels' of a 1x1 image."""
+    n, cin = x.shape
+    cout = weight.shape[0]
+    y = conv2d(x.view(n, cin, 1, 1), weight.view(cout, cin, 1, 1), bias, scale, 0, False, bias_scale, act, slope)
+    return y.view(n, cout)
+
+
+def bias_act(x, bias=None, noise=None, noise_w=None, bias_scale=1.0, act=None, slope=0.2):
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    return _BiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope))
+
+
+def blur(x):
+    return _Blur.apply(x)
+
+
+def avg_pool2(x):
+    return _Pool2.apply(x, 0.25)
+
+
+def upsample2(x):
+    return _Up2.apply(x, 1.0)
+
+
+def lerp(a, b, alpha):
+    """a*(1-alpha) + b*alpha."""
+    return _Axpby.apply(a, b, float(1.0 - alpha), float(alpha))
+
+
+def scale(x, a):
+    return _Scale.apply(x, float(a))
+
+
+def instnorm_style(x, style=None, eps=1e-8):
+    return _InstNormStyle.apply(x, style, float(eps))
+
+
+def pixelnorm(x, eps=1e-8):
+    return _PixelNorm.apply(x, float(eps))
+
+
+def mbstd_stat(x, group_size, eps=1e-8):
+    return _MbstdStat.apply(x, int(group_size), float(eps))
+
+
+def sum_all(x, scale=1.0):
+    return _Sum.apply(x, float(scale), False)
+
+
+def sumsq_all(x, scale=1.0):
+    return _Sum.apply(x, float(scale), True)
+
+
+def bce_logits_mean(x, target):
+    return _BceMean.apply(x, float(target))
+
+
+def chnorm_penalty(g, gamma, scale):
+    return _ChNormPenalty.apply(g, float(gamma), float(scale))

@@ -1,0 +1,1 @@
+"""Mirror of the reference sub-package gan_lab/progan."""

@@ -1,0 +1,288 @@
+"""Layer ops of the G/D conv stack on the HIP kernels (drop-in for gan_lab/utils/custom_layers.py).
+
+Same class names, constructor arguments and ``state_dict`` keys as the reference
+(custom_layers.py:18-306), but every ``forward`` lands in ``gan_lab_amd.ops`` (hand-written gfx950
+kernels): nothing here computes with ATen.  ``fused_sequential`` is the peephole executor the
+architectures use so that e.g. ``Sequential(Upsample, Conv2dEx, blur)`` or
+``Sequential(Conv2dEx(bias), LeakyReLU)`` run as ONE kernel while the module tree (and therefore
+the checkpoint layout) stays that of the reference.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .initializer import Initializer
+
+
+class Lambda(nn.Module):
+    """Converts any function into a Module (custom_layers.py:18-29)."""
+
+    def __init__(self, func, **kwargs):
+        super().__init__()
+        self.func = func
+        self.kwargs = kwargs if kwargs else {}
+
+    def forward(self, x):
+        return self.func(x, **self.kwargs)
+
+
+# -- activations / resampling as parameter-free modules ------------------------------------------- #
+class LeakyReLU(nn.Module):
+    """nn.LeakyReLU stand-in (negative_slope=0 gives ReLU)."""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = float(negative_slope)
+
+    def forward(self, x):
+        return ops.bias_act(x, act='lrelu', slope=self.negative_slope)
+
+    def extra_repr(self):
+        return f'negative_slope={self.negative_slope}'
+
+
+class Upsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='nearest') stand-in (fused into the following conv)."""
+
+    def forward(self, x):
+        return ops.upsample2(x)
+
+
+class AvgPool2x(nn.Module):
+    """nn.AvgPool2d(kernel_size=2, stride=2) stand-in."""
+
+    def forward(self, x):
+        return ops.avg_pool2(x)
+
+
+class Blur2d(nn.Module):
+    """Depthwise 3x3 binomial blur, zero padding (custom_layers.py:41-51)."""
+
+    def forward(self, x):
+        return ops.blur(x)
+
+
+def get_blur_op(blur_type, num_channels):
+    """Low-pass filter op (custom_layers.py:36-53).  Only 'binomial' is on the hot path."""
+    if blur_type.casefold() == 'binomial':
+        return Blur2d()
+    if blur_type.casefold() == 'gaussian':
+        raise NotImplementedError('Gaussian blur not yet implemented.')
+    raise NotImplementedError(f"blur_type '{blur_type}' has no HIP kernel (only 'binomial').")
+
+
+# -- normalisation --------------------------------------------------------------------------------- #
+class PixelNorm2d(nn.Module):
+    def forward(self, x, eps=1.e-8):
+        return ops.pixelnorm(x, eps)
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(None, eps=1e-8): biased var, no affine, no running stats."""
+
+    def __init__(self, eps=1.e-8):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.instnorm_style(x, None, self.eps)
+
+
+class NormalizeLayer(nn.Module):
+    """All normalisation methods in one place (custom_layers.py:88-111)."""
+
+    def __init__(self, norm_type, ni=None, res=None):
+        super().__init__()
+        norm_type = norm_type.lower()
+        if norm_type in ('pixelnorm', 'pixel norm',):
+            self.norm = PixelNorm2d()
+        elif norm_type in ('instancenorm', 'instance norm',):
+            self.norm = InstanceNorm2d(eps=1.e-8)
+        elif norm_type in ('batchnorm', 'batch norm', 'layernorm', 'layer norm',):
+            raise NotImplementedError(f'`norm_type` == "{norm_type}" is only used by the ResNet GAN path '
+                                      f'(out of the StyleGAN/ProGAN hot path) and has no HIP kernel yet.')
+        else:
+            raise Exception(f'`norm_type` == "{norm_type}" not supported.')
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+# -- minibatch stddev ------------------------------------------------------------------------------ #
+def concat_mbstd_layer(x, group_size=4):
+    """Minibatch Standard Deviation layer (custom_layers.py:117-140).  The statistic (unbiased var
+    over contiguous groups, sqrt(.+1e-8), mean over C*H*W) is a HIP kernel with explicit first and
+    second derivatives; expand/cat are pure data movement."""
+    b, c, h, w = x.shape
+    group_size = min(b, group_size)
+    if b % group_size != 0:
+        group_size = b
+    G = b // group_size
+    if group_size > 1:
+        stat = ops.mbstd_stat(x, group_size)                       # (G,)
+        m = stat.view(G, 1, 1, 1, 1).expand(G, group_size, 1, h, w).reshape(b, 1, h, w)
+    else:
+        m = torch.zeros(b, 1, h, w, device=x.device, dtype=x.dtype)
+    return torch.cat((x, m), dim=1)
+
+
+# -- eq-LR conv / linear --------------------------------------------------------------------------- #
+def _init_weight(mod_weight, initializer, init, init_type, equalized_lr, lrmul, use_lrmul, stride=1):
+    """Weight init + runtime scale, following custom_layers.py:171-195 (including the
+    ``init_type == ('default','resnet',)`` str-vs-tuple comparison of Conv2dEx that never matches,
+    handled by the callers)."""
+    wscale = None
+    if init_type in ('progan', 'stylegan',) and init is not None:
+        bound = initializer.get_init_bound_layer(tensor=mod_weight, distribution_type='Normal', stride=stride)
+        if equalized_lr:
+            wscale = bound
+            mod_weight.data.normal_(0., 1. / lrmul)
+        else:
+            mod_weight.data.normal_(0., bound / lrmul)
+    elif init_type == 'standard normal' and init is None and not equalized_lr and not use_lrmul:
+        mod_weight.data.normal_(0., 1.)
+    return wscale
+
+
+class Conv2dEx(nn.Module):
+    def __init__(self, ni, nf, ks, stride=1, padding=0, groups=1, init='he', init_type='default',
+                 gain_sq_base=2., equalized_lr=False, lrmul=1., include_bias=True):
+        super().__init__()
+        if stride != 1 or groups != 1:
+            raise NotImplementedError('the HIP conv kernels implement stride 1, groups 1')
+        self.ni, self.nf, self.ks, self.padding = ni, nf, ks, padding
+        init = init.casefold() if init is not None else None
+        init_type = init_type.casefold()
+        self.equalized_lr = equalized_lr
+        self.use_lrmul = True if lrmul != 1. else False
+        self.lrmul = lrmul
+        self.initializer = None
+        if init_type != 'standard normal':
+            self.initializer = Initializer(init=init, init_type=init_type, gain_sq_base=gain_sq_base,
+                                           equalized_lr=equalized_lr)
+        # parameter container only (keys `conv2d.weight` / `conv2d.bias`); never called
+        self.conv2d = nn.Conv2d(ni, nf, kernel_size=ks, stride=stride, padding=padding, groups=groups,
+                                bias=include_bias)
+        # NB: for init_type 'default'/'resnet' the reference's tuple comparison never matches
+        # (custom_layers.py:173), so PyTorch's default init and wscale=None are what it ends up with.
+        self.wscale = _init_weight(self.conv2d.weight, self.initializer, init, init_type, equalized_lr, lrmul,
+                                   self.use_lrmul, stride)
+        self.bias = None
+        if include_bias:
+            self.conv2d.bias.data.fill_(0)
+
+    @property
+    def scale(self):
+        s = self.wscale if (self.equalized_lr and self.wscale is not None) else 1.0
+        return s * (self.lrmul if self.use_lrmul else 1.0)
+
+    def forward(self, x, up=False, act=None, slope=0.2):
+        # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
+        return ops.conv2d(x, self.conv2d.weight, self.conv2d.bias, scale=self.scale, padding=self.padding,
+                          up=up, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+
+
+class Conv2dBias(nn.Module):
+    def __init__(self, nf, lrmul=1., device='cpu'):
+        super().__init__()
+        self.use_lrmul = True if lrmul != 1. else False
+        self.lrmul = lrmul
+        self.bias = nn.Parameter(torch.zeros(1, nf, 1, 1, device=device))
+
+    def forward(self, x, act=None, slope=0.2):
+        return ops.bias_act(x, self.bias, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+
+
+class LinearEx(nn.Module):
+    def __init__(self, nin_feat, nout_feat, init='xavier', init_type='default', gain_sq_base=2.,
+                 equalized_lr=False, lrmul=1., include_bias=True):
+        super().__init__()
+        self.nin_feat, self.nout_feat = int(nin_feat), int(nout_feat)
+        init = init.casefold() if init is not None else None
+        init_type = init_type.casefold()
+        self.equalized_lr = equalized_lr
+        self.use_lrmul = True if lrmul != 1. else False
+        self.lrmul = lrmul
+        self.initializer = None
+        if init_type != 'standard normal':
+            self.initializer = Initializer(init=init, init_type=init_type, gain_sq_base=gain_sq_base,
+                                           equalized_lr=equalized_lr)
+        self.linear = nn.Linear(self.nin_feat, self.nout_feat, bias=include_bias)
+        self.wscale = None
+        if init_type in ('default', 'resnet',) and init is not None:
+            bound = self.initializer.get_init_bound_layer(tensor=self.linear.weight, distribution_type='Uniform')
+            if equalized_lr:
+                self.wscale = bound
+                self.linear.weight.data.uniform_(-1. / lrmul, 1. / lrmul)
+            else:
+                self.linear.weight.data.uniform_(-bound / lrmul, bound / lrmul)
+        else:
+            self.wscale = _init_weight(self.linear.weight, self.initializer, init, init_type, equalized_lr, lrmul,
+                                       self.use_lrmul)
+        self.bias = None
+        if include_bias:
+            self.linear.bias.data.fill_(0)
+
+    @property
+    def scale(self):
+        s = self.wscale if (self.equalized_lr and self.wscale is not None) else 1.0
+        return s * (self.lrmul if self.use_lrmul else 1.0)
+
+    def forward(self, x, act=None, slope=0.2):
+        return ops.linear(x, self.linear.weight, self.linear.bias, scale=self.scale,
+                          bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+
+
+class LinearBias(nn.Module):
+    def __init__(self, nout_feat, lrmul=1., device='cpu'):
+        super().__init__()
+        self.use_lrmul = True if lrmul != 1. else False
+        self.lrmul = lrmul
+        self.bias = nn.Parameter(torch.zeros(1, nout_feat, device=device))
+
+    def forward(self, x, act=None, slope=0.2):
+        return ops.bias_act(x, self.bias, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+
+
+# -- peephole executor ------------------------------------------------------------------------------ #
+def fused_sequential(mods, x):
+    """Run a list of modules with kernel fusion where the pattern allows:
+         Upsample2x, Conv2dEx                      -> conv with the upsample folded into the tile load
+         Conv2dEx / LinearEx [, LeakyReLU]         -> bias + LeakyReLU in the MFMA epilogue
+         Conv2dBias / LinearBias [, LeakyReLU]     -> one bias+act pass
+       Everything else falls through to the module's own (HIP) forward.  nn.Sequential children are
+       flattened first."""
+    flat = []
+
+    def add(m):
+        if m is None:
+            return
+        if isinstance(m, nn.Sequential):
+            for c in m:
+                add(c)
+        else:
+            flat.append(m)
+
+    for m in mods:
+        add(m)
+    i, n = 0, len(flat)
+    while i < n:
+        m = flat[i]
+        up = False
+        if isinstance(m, Upsample2x) and i + 1 < n and isinstance(flat[i + 1], Conv2dEx):
+            up = True
+            i += 1
+            m = flat[i]
+        nxt = flat[i + 1] if i + 1 < n else None
+        if isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
+            kw = {}
+            if isinstance(nxt, LeakyReLU):
+                kw = dict(act='lrelu', slope=nxt.negative_slope)
+                i += 1
+            if up:
+                kw['up'] = True
+            x = m(x, **kw)
+        else:
+            x = m(x)
+        i += 1
+    return x

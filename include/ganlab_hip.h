@@ -1,0 +1,167 @@
+/*
+ * ganlab_hip.h - C ABI of the MI355X (gfx950) kernel library for the gan-lab G+D training step.
+ *
+ * The reference (sidward14/gan-lab v0.4.2) is pure Python/PyTorch: it has no FFI, plugin or
+ * operator interface of its own.  The boundary this library replaces is therefore
+ * the set of ATen call sites inside the reference's layer ops; each entry point below cites the
+ * reference file:line (relative to /root/reference/gan_lab) whose math it implements.  A
+ * maintainer binds these with ctypes from `torch.autograd.Function`s - see INTEGRATION.md and
+ * gan_lab_amd/_lib.py.
+ *
+ * Conventions
+ *  - all tensors are fp32, contiguous NCHW (weights OIHW), device pointers owned by the caller;
+ *  - nothing is allocated inside: scratch is a caller-provided workspace;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return value: 0 on success, negative GANLAB_E* on error (never throws across the ABI);
+ *  - re-entrant: no global mutable state.
+ */
+#ifndef GANLAB_HIP_H
+#define GANLAB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANLAB_OK 0
+#define GANLAB_EINVAL (-1)   /* bad argument (null pointer, non-positive dim, unsupported ks) */
+#define GANLAB_EWORKSPACE (-2) /* workspace too small */
+#define GANLAB_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch */
+
+#define GANLAB_ACT_NONE 0
+#define GANLAB_ACT_LRELU 1
+
+#define GANLAB_PACK_FWD 0    /* out[tap][ci][co] = scale * w[co][ci][tap]                */
+#define GANLAB_PACK_DGRAD 1  /* out[tap][co][ci] = scale * w[co][ci][KK-1-tap] (flipped) */
+
+int ganlab_abi_version(void);
+
+/* Geometry of one convolution C(x, w) = scale * conv2d(up2?(x), w, stride 1, padding pad).
+ * Replaces Conv2dEx.forward / LinearEx.forward (utils/custom_layers.py:202-211, :282-291) with the
+ * eq-LR runtime scale folded into `scale` (the reference multiplies the input, :204), and the
+ * nearest-neighbour 2x upsample in front of a generator conv
+ * (stylegan/architectures.py:292-334, progan/architectures.py:119-148) folded in as `up`. */
+typedef struct {
+  int N, Cin, Hin, Win; /* physical input (before the optional 2x nearest upsample)     */
+  int Cout, ks, pad;    /* square kernel ks in {1,3}; a 4x4 valid conv is run as a linear */
+  int up;               /* 1: input is nearest-upsampled 2x on the fly                   */
+} ganlab_conv_geom;
+
+/* Output spatial size of a geometry: Hout = (up ? 2*Hin : Hin) + 2*pad - ks + 1. */
+int ganlab_conv_out_hw(const ganlab_conv_geom* g, int* Hout, int* Wout);
+
+/* Re-layout OIHW weights for the implicit-GEMM kernels; `mode` is GANLAB_PACK_*.
+ * Returns the number of floats the packed buffer needs when `out` is NULL. */
+long long ganlab_conv_pack_f32(const float* w, float* out, int Cout, int Cin, int ks, int mode,
+                               float scale, void* stream);
+
+/* y = act( conv(x, wp) + bias * bias_scale ), fp32 MFMA implicit GEMM.
+ * wp: GANLAB_PACK_FWD-packed weights (scale already folded in).  bias may be NULL.
+ * custom_layers.py:202-211 (+ Conv2dBias :222-226, LeakyReLU) */
+int ganlab_conv_fwd_f32(const float* x, const float* wp, const float* bias, float* y,
+                        const ganlab_conv_geom* g, float bias_scale, int act, float slope,
+                        void* stream);
+
+/* gx = conv_transpose(gy, w) wrt the conv input (the autograd rule of custom_layers.py:204-206).
+ * wp: GANLAB_PACK_DGRAD-packed weights.  When g->up == 1 the result is the gradient w.r.t. the
+ * *virtual* (upsampled) input, shape (N, Cin, 2*Hin, 2*Win); fold it with ganlab_pool2_f32. */
+int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual,
+                          const ganlab_conv_geom* g, void* stream);
+
+/* gw[co][ci][ky][kx] = scale * sum_{n,y,x} gy[n,co,y,x] * up2?(x)[n,ci,y+ky-pad,x+kx-pad].
+ * Deterministic two-stage reduction through `workspace`; query the size with
+ * ganlab_conv_wgrad_workspace (bytes). */
+size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g,
+                          float scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- depthwise / resampling (custom_layers.py:36-53; nn.Upsample / nn.AvgPool2d call sites) ---- */
+/* y = depthwise [1 2 1]x[1 2 1]/16 blur, zero padding (self-adjoint: also its own backward). */
+int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream);
+/* y[2h+i,2w+j] = scale * x[h,w]  (nearest upsample; backward of pool2) */
+int ganlab_up2_f32(const float* x, float* y, long long planes, int H, int W, float scale, void* stream);
+/* y[h,w] = scale * sum_{i,j<2} x[2h+i,2w+j]  (avg-pool with scale .25; backward of up2) */
+int ganlab_pool2_f32(const float* x, float* y, long long planes, int Hout, int Wout, float scale,
+                     void* stream);
+
+/* ---- bias / activation / noise (custom_layers.py:213-226, stylegan/architectures.py:105-119) ---- */
+/* y = act(x + noise_w[c]*noise[n,hw] + bias[c]*bias_scale); noise/noise_w and bias may be NULL. */
+int ganlab_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w,
+                        float* y, int N, int C, long long HW, float bias_scale, int act, float slope,
+                        void* stream);
+/* gz = gy * (y > 0 ? 1 : slope)   (LeakyReLU backward from the saved OUTPUT) */
+int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, float slope, void* stream);
+/* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
+int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
+                           float scale, void* workspace, size_t workspace_bytes, void* stream);
+size_t ganlab_channel_sum_workspace(int N, int C, long long HW);
+
+/* ---- normalisation ---- */
+/* InstanceNorm2d(eps, biased var) statistics per (n,c) plane: mean, rstd (custom_layers.py:98-99) */
+int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long long planes, long long HW,
+                              float eps, void* stream);
+/* y = (x-mean)*rstd*(ys+1)+yb with style (N,2,C) (stylegan/architectures.py:524-526); style may be
+ * NULL (plain InstanceNorm). */
+int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float* rstd,
+                                  const float* style, float* y, int N, int C, long long HW, void* stream);
+/* s1[n,c] = sum gy ; s2[n,c] = sum gy * xhat */
+int ganlab_instnorm_style_bwd_reduce_f32(const float* gy, const float* x, const float* mean,
+                                         const float* rstd, float* s1, float* s2, long long planes,
+                                         long long HW, void* stream);
+/* gx = rstd*(ys+1)*(gy - s1/HW - xhat*s2/HW) */
+int ganlab_instnorm_style_bwd_apply_f32(const float* gy, const float* x, const float* mean,
+                                        const float* rstd, const float* style, const float* s1,
+                                        const float* s2, float* gx, int N, int C, long long HW,
+                                        void* stream);
+/* PixelNorm over the channel dim (custom_layers.py:81-86): y = x*rsqrt(mean_c x^2 + eps) */
+int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long HW, float eps, void* stream);
+int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, int C, long long HW,
+                             float eps, void* stream);
+
+/* ---- minibatch stddev statistic (custom_layers.py:117-140), contiguous groups of gs samples ---- */
+/* stat[g] = mean_f sqrt(var_unbiased_i(x[g,i,f]) + eps),  f over F = C*H*W features */
+int ganlab_mbstd_fwd_f32(const float* x, float* stat, int G, int gs, long long F, float eps, void* stream);
+/* gx[g,i,f] = gstat[g]/(F(gs-1)) * (x-mu)/s */
+int ganlab_mbstd_bwd_f32(const float* x, const float* gstat, float* gx, int G, int gs, long long F,
+                         float eps, void* stream);
+/* backward of ganlab_mbstd_bwd: given ggx (cotangent of gx) -> g_gstat[g] and g_x[g,i,f] */
+int ganlab_mbstd_bwdbwd_f32(const float* x, const float* gstat, const float* ggx, float* g_gstat,
+                            float* g_x, int G, int gs, long long F, float eps, void* stream);
+
+/* ---- elementwise / reductions ---- */
+/* out = a*x + b*y (y may be NULL -> out = a*x); fade-in blends progan/architectures.py:163-167,311-315 */
+int ganlab_axpby_f32(const float* x, const float* y, float* out, long long n, float a, float b, void* stream);
+/* out = a * gout[0] * (x ? x : 1): backward of the scalar reductions, gout stays on the device */
+int ganlab_scale_dev_f32(const float* x, const float* gout, float* out, long long n, float a, void* stream);
+/* out[n,:] = t[n]*a[n,:] + (1-t[n])*b[n,:]  (WGAN-GP interpolates, resnetgan/learner.py:793-796) */
+int ganlab_lerp_rows_f32(const float* a, const float* b, const float* t, float* out, long long N, long long M,
+                         void* stream);
+/* out[0] = scale * sum x  |  scale * sum x^2 */
+int ganlab_sum_f32(const float* x, float* out, long long n, float scale, int squared, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t ganlab_sum_workspace(long long n);
+/* BCE-with-logits vs a constant target t, mean over n (progan/learner.py:793-800, :886-896) */
+int ganlab_bce_logits_fwd_f32(const float* x, float* out, int n, float target, void* stream);
+int ganlab_bce_logits_bwd_f32(const float* x, const float* gout, float* gx, int n, float target, void* stream);
+/* WGAN-GP style penalty on channel-norms (resnetgan/learner.py:817-825):
+ * out[0] = scale * sum_{n,hw} (sqrt(sum_c g^2) - gamma)^2 ;  bwd: gg = gout*scale*2*(s-gamma)*g/s */
+int ganlab_chnorm_penalty_fwd_f32(const float* g, float* out, int N, int C, long long HW, float gamma,
+                                  float scale, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_chnorm_penalty_bwd_f32(const float* g, const float* gout, float* gg, int N, int C, long long HW,
+                                  float gamma, float scale, void* stream);
+
+/* ---- optimiser (torch.optim.Adam as configured by backprop_utils.py:109-120; EWMA progan/learner.py:909-916) */
+/* One fused Adam step over a flat parameter arena; bias corrections are passed in by the host. */
+int ganlab_adam_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                    float beta2, float eps, float wd, float bc1, float bc2, void* stream);
+/* lagged = p*(1-beta) + lagged*beta */
+int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void* stream);
+/* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) for latents / per-layer noise */
+int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANLAB_HIP_H */
