@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the full G+D training step (1 D-iteration + 1 G-iteration),
+StyleGAN 1024^2, batch 32 per GPU, fp32, nonsaturating loss + R1 (lambda 10) + drift, stabilised phase
+at the final resolution, synthetic FFHQ-shaped data (BASELINE.json metric / configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+             --master-port P bench.py --gpus N --steps K --warmup W)
+
+Prints ONE JSON line on rank 0.  ``roofline``: the dominant kernel family is the fp32 MFMA
+implicit-GEMM conv; its north-star instance (3x3, 16->16 channels, 1024^2, batch 32) is timed with
+device events on the launch stream and priced with its algorithmic FLOPs 2*9*16*16*1024^2*32.
+``cpu_baseline``: the CPU oracle's (oracle/, kind "port") G+D step on the host cores at a reduced
+batch - a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TFLOP_PER_IMAGE = {1024: 1.536, 128: 0.752}      # 4 G passes + 14 D passes
+PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=3)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--res', type=int, default=1024)
+    p.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-baseline-res', type=int, default=None)
+    p.add_argument('--cpu-baseline-batch', type=int, default=1)
+    p.add_argument('--no-roofline', action='store_true')
+    return p.parse_args()
+
+
+def build_learner(res, batch, device):
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.stylegan.learner import StyleGANLearner
+    bs_dict = {r: batch for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
+    cfg = make_config('stylegan', dev='cuda', pin_memory=False, loss='nonsaturating', gradient_penalty='r1',
+                      lda=10., res_samples=res, res_dataset=res, init_res=res, batch_size=batch, bs_dict=bs_dict,
+                      num_iters_save_model=10 ** 9, log_every=0,
+                      cutoff_trunc_trick=4 if res >= 64 else None)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        learner = StyleGANLearner(cfg)
+    learner.beta = learner.get_smoothing_ewma_beta(half_life=10.)
+    learner.gen_model.train()
+    learner.disc_model.train()
+    return learner
+
+
+def one_step(learner, real):
+    learner.set_requires_grad_disc(True)
+    ld = learner.d_step(real, defer_update=True)
+    learner.set_requires_grad_disc(False)
+    lg = learner.g_step(d_update_pending=True)
+    return ld, lg
+
+
+def measure_dominant_kernel(torch, batch, res, reps=5):
+    """Average launch duration of the north-star conv kernel instance, device events on the launch stream."""
+    from gan_lab_amd import ops
+    c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
+    x = torch.randn(batch, c, res, res, device='cuda')
+    w = torch.randn(c, c, 3, 3, device='cuda')
+    g = ops.Geom(batch, c, res, res, c, 3, 1, 0)
+    for _ in range(2):
+        ops.k_conv_fwd(x, w, None, g, 0.05)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.k_conv_fwd(x, w, None, g, 0.05)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * 9 * c * c * res * res * batch
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'kernel': f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
+                      f'{c}->{c} @{res}^2 x{batch}',
+            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
+
+
+def cpu_baseline(torch, res, batch):
+    """The oracle's G+D step (same math, same loss config) on the host cores; bounded sample."""
+    from gan_lab_amd import progressive as P
+    from gan_lab_amd.progan.architectures import StyleDiscriminator
+    from gan_lab_amd.stylegan.architectures import StyleGenerator
+    from oracle import nets, step
+    torch.manual_seed(0)
+    P.StyleGAN.reset_state()
+    g = StyleGenerator(final_res=res, blur_type='binomial',
+                       truncation_trick_params={'beta': .995, 'psi': .7, 'cutoff_stage': 4 if res >= 64 else None})
+    d = StyleDiscriminator(final_res=res, blur_type='binomial')
+    import numpy as np
+    for _ in range(int(np.log2(res)) - 2):
+        g.increase_scale()
+        d.increase_scale()
+    gan = step.FunctionalGAN(g.state_dict(), d.state_dict(), nets.make_cfg(), model='stylegan',
+                             loss='nonsaturating', gp='r1', lda=10., eps_drift=.001)
+    del g, d
+    L = nets.stylegen_num_layers(gan.g)
+    noise = lambda: [torch.randn(batch, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2)) for n in range(L)]  # noqa: E731
+    real = torch.rand(batch, 3, res, res) * 2 - 1
+    t0 = time.perf_counter()
+    gan.d_step(torch.randn(batch, 512), real, noise())
+    gan.g_step(torch.randn(batch, 512), noise(), beta=0.999)
+    dt = time.perf_counter() - t0
+    return {'value': round(batch / dt, 5), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 G+D step of StyleGAN {res}^2 at batch {batch} (oracle/step.py FunctionalGAN, torch CPU '
+                      f'fp32, {torch.get_num_threads()} threads), {dt:.1f} s'}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f'warning: --gpus {a.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+    from gan_lab_amd import _lib, rng
+    _lib.lib()
+    rng.manual_seed(1234, rank)
+    torch.manual_seed(1234 + rank)
+
+    learner = build_learner(a.res, a.batch, 'cuda')
+    # synthetic FFHQ-shaped reals, resident in HBM before the timed region: U(-1,1) fp32 (B,3,R,R)
+    real = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step(learner, real)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ld, lg = one_step(learner, real)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ld, lg = float(ld), float(lg)
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    if rank == 0:
+        ips = world * a.batch * a.steps / dt
+        out = {
+            'metric': 'images/sec (G+D step), StyleGAN 1024^2 bs32/GPU' if a.res == 1024 and a.batch == 32 else
+                      f'images/sec (G+D step), StyleGAN {a.res}^2 bs{a.batch}/GPU',
+            'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'StyleGAN res_samples={a.res} FFHQ-shaped synthetic, bs={a.batch}/GPU fp32, '
+                                   f'nonsaturating + R1(lambda=10) + drift, stabilised phase, 1 D-iter + 1 G-iter',
+                       'global_batch': world * a.batch, 'per_gpu_batch': a.batch,
+                       'parallelism': f'dp{world}' if world > 1 else 'single'},
+            'achieved_tflops_step': round(ips * TFLOP_PER_IMAGE.get(a.res, 0.0), 2) if a.res in TFLOP_PER_IMAGE
+            else None,
+            'frac_of_f32_mfma_peak_step': round(ips * TFLOP_PER_IMAGE[a.res] / (PEAK_F32_MFMA_TFLOPS * world), 4)
+            if a.res in TFLOP_PER_IMAGE else None,
+            'loss_d': ld, 'loss_g': lg, 'peak_mem_gib': round(peak_mem, 1),
+        }
+    del learner, real
+    torch.cuda.empty_cache()
+    if rank == 0:
+        out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res)
+        torch.cuda.empty_cache()
+        if world == 1 and not a.no_cpu_baseline:
+            cres = a.cpu_baseline_res or a.res
+            out['cpu_baseline'] = cpu_baseline(torch, cres, a.cpu_baseline_batch)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,11 @@ import ctypes
 import os
 import subprocess
 
+# PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It MUST be loaded before our
+# library so that `libamdhip64.so.7` resolves to that same runtime: otherwise two runtimes coexist,
+# torch's stream handles are foreign to ours and every launch fails.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.path.join(CSRC, 'libganlab_hip.so')

@@ -7,7 +7,23 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define GL_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? GANLAB_OK : GANLAB_ELAUNCH)
+// hipGetLastError() reports the last error of ANY runtime call on this thread (e.g. a
+// hipErrorNotReady left behind by an event query in the caller's allocator), so it is cleared right
+// before each launch and sampled right after it; the per-thread status is collected by
+// GL_CHECK_LAUNCH() at the end of the entry point.
+static thread_local int gl_launch_status = GANLAB_OK;
+#define GL_LAUNCH(...)                                                           \
+  do {                                                                           \
+    (void)hipGetLastError();                                                     \
+    hipLaunchKernelGGL(__VA_ARGS__);                                             \
+    if (hipGetLastError() != hipSuccess) gl_launch_status = GANLAB_ELAUNCH;      \
+  } while (0)
+static inline int gl_take_status() {
+  const int s = gl_launch_status;
+  gl_launch_status = GANLAB_OK;
+  return s;
+}
+#define GL_CHECK_LAUNCH() gl_take_status()
 
 static inline hipStream_t gl_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -329,7 +329,7 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
   a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
   const long long grid = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -425,7 +425,7 @@ int launch_wgrad(WgradArgs a, const WgPlan& pl, hipStream_t st) {
   a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.tiles_n = pl.tiles_n;
   a.tiles_co = pl.tiles_co; a.tiles_ci = pl.tiles_ci; a.S = pl.S;
   const long long grid = (long long)pl.tiles_co * pl.tiles_ci * pl.S;
-  hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  GL_LAUNCH(conv_wgrad_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -470,7 +470,7 @@ long long ganlab_conv_pack_f32(const float* w, float* out, int Cout, int Cin, in
   if (!w) return GANLAB_EINVAL;
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, gl_stream(stream), w, out, Cout, Cin,
+  GL_LAUNCH(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, gl_stream(stream), w, out, Cout, Cin,
                      ks * ks, rows, cols, rows_p, cols_p, mode == GANLAB_PACK_DGRAD ? 1 : 0, scale);
   return GL_CHECK_LAUNCH() == GANLAB_OK ? total : GANLAB_ELAUNCH;
 }
@@ -516,7 +516,7 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   hipStream_t st = gl_stream(stream);
   const int rc = g->ks == 1 ? run_wgrad_ks<1>(a, pl, st) : run_wgrad_ks<3>(a, pl, st);
   if (rc != GANLAB_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st,
+  GL_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st,
                      (const float*)workspace, gw, nw, pl.slots, scale);
   return GL_CHECK_LAUNCH();
 }

@@ -635,19 +635,19 @@ int ganlab_abi_version(void) { return 1; }
 
 int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream) {
   if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(blur3x3_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, ST, x, y, planes, H, W);
+  GL_LAUNCH(blur3x3_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, ST, x, y, planes, H, W);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_up2_f32(const float* x, float* y, long long planes, int H, int W, float scale, void* stream) {
   if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(up2_kernel, dim3(ew_blocks(planes * H * W * 4)), dim3(256), 0, ST, x, y, planes, H, W, scale);
+  GL_LAUNCH(up2_kernel, dim3(ew_blocks(planes * H * W * 4)), dim3(256), 0, ST, x, y, planes, H, W, scale);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_pool2_f32(const float* x, float* y, long long planes, int Hout, int Wout, float scale, void* stream) {
   if (!x || !y || planes <= 0 || Hout <= 0 || Wout <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(pool2_kernel, dim3(ew_blocks(planes * Hout * Wout)), dim3(256), 0, ST, x, y, planes, Hout,
+  GL_LAUNCH(pool2_kernel, dim3(ew_blocks(planes * Hout * Wout)), dim3(256), 0, ST, x, y, planes, Hout,
                      Wout, scale);
   return GL_CHECK_LAUNCH();
 }
@@ -656,17 +656,17 @@ int ganlab_bias_act_f32(const float* x, const float* bias, const float* noise, c
                         int N, int C, long long HW, float bias_scale, int act, float slope, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
   if ((HW & 3) == 0)
-    hipLaunchKernelGGL(bias_act_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST, x, bias,
+    GL_LAUNCH(bias_act_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST, x, bias,
                        noise, noise_w, y, N, C, HW, bias_scale, act, slope);
   else
-    hipLaunchKernelGGL(bias_act_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x, bias,
+    GL_LAUNCH(bias_act_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x, bias,
                        noise, noise_w, y, N, C, HW, bias_scale, act, slope);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, float slope, void* stream) {
   if (!gy || !y || !gz || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, gy, y, gz, n, slope);
+  GL_LAUNCH(act_bwd_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, gy, y, gz, n, slope);
   return GL_CHECK_LAUNCH();
 }
 
@@ -679,9 +679,9 @@ int ganlab_channel_sum_f32(const float* a, const float* b, float* out, int N, in
   if (!a || !out || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const int chunks = channel_chunks(N, HW);
   if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return GANLAB_EWORKSPACE;
-  hipLaunchKernelGGL(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (float*)workspace, N, C, HW,
+  GL_LAUNCH(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (float*)workspace, N, C, HW,
                      chunks);
-  hipLaunchKernelGGL(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, out, C, chunks, scale);
+  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, out, C, chunks, scale);
   return GL_CHECK_LAUNCH();
 }
 
@@ -689,10 +689,10 @@ int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long lon
                               void* stream) {
   if (!x || !mean || !rstd || planes <= 0 || HW <= 0) return GANLAB_EINVAL;
   if (HW >= 1024)
-    hipLaunchKernelGGL(instnorm_stats_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, x, mean, rstd, planes,
+    GL_LAUNCH(instnorm_stats_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, x, mean, rstd, planes,
                        HW, eps);
   else
-    hipLaunchKernelGGL(instnorm_stats_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, x, mean,
+    GL_LAUNCH(instnorm_stats_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, x, mean,
                        rstd, planes, HW, eps);
   return GL_CHECK_LAUNCH();
 }
@@ -701,10 +701,10 @@ int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float
                                   float* y, int N, int C, long long HW, void* stream) {
   if (!x || !mean || !rstd || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   if ((HW & 3) == 0)
-    hipLaunchKernelGGL(instnorm_style_fwd_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
+    GL_LAUNCH(instnorm_style_fwd_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
                        x, mean, rstd, style, y, N, C, HW);
   else
-    hipLaunchKernelGGL(instnorm_style_fwd_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x,
+    GL_LAUNCH(instnorm_style_fwd_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x,
                        mean, rstd, style, y, N, C, HW);
   return GL_CHECK_LAUNCH();
 }
@@ -713,10 +713,10 @@ int ganlab_instnorm_style_bwd_reduce_f32(const float* gy, const float* x, const 
                                          float* s1, float* s2, long long planes, long long HW, void* stream) {
   if (!gy || !x || !mean || !rstd || !s1 || !s2 || planes <= 0 || HW <= 0) return GANLAB_EINVAL;
   if (HW >= 1024)
-    hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, gy, x, mean,
+    GL_LAUNCH(instnorm_bwd_reduce_kernel<256>, dim3((unsigned)planes), dim3(256), 0, ST, gy, x, mean,
                        rstd, s1, s2, planes, HW);
   else
-    hipLaunchKernelGGL(instnorm_bwd_reduce_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, gy, x,
+    GL_LAUNCH(instnorm_bwd_reduce_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, gy, x,
                        mean, rstd, s1, s2, planes, HW);
   return GL_CHECK_LAUNCH();
 }
@@ -726,17 +726,17 @@ int ganlab_instnorm_style_bwd_apply_f32(const float* gy, const float* x, const f
                                         int C, long long HW, void* stream) {
   if (!gy || !x || !mean || !rstd || !s1 || !s2 || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   if ((HW & 3) == 0)
-    hipLaunchKernelGGL(instnorm_bwd_apply_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
+    GL_LAUNCH(instnorm_bwd_apply_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
                        gy, x, mean, rstd, style, s1, s2, gx, N, C, HW);
   else
-    hipLaunchKernelGGL(instnorm_bwd_apply_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, gy,
+    GL_LAUNCH(instnorm_bwd_apply_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, gy,
                        x, mean, rstd, style, s1, s2, gx, N, C, HW);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long HW, float eps, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, x, y, N, C, HW,
+  GL_LAUNCH(pixelnorm_fwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, x, y, N, C, HW,
                      eps);
   return GL_CHECK_LAUNCH();
 }
@@ -744,21 +744,21 @@ int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long H
 int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, int C, long long HW, float eps,
                              void* stream) {
   if (!gy || !x || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, gy, x, gx, N, C,
+  GL_LAUNCH(pixelnorm_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, gy, x, gx, N, C,
                      HW, eps);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_mbstd_fwd_f32(const float* x, float* stat, int G, int gs, long long F, float eps, void* stream) {
   if (!x || !stat || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(G), dim3(256), 0, ST, x, stat, gs, F, eps);
+  GL_LAUNCH(mbstd_fwd_kernel, dim3(G), dim3(256), 0, ST, x, stat, gs, F, eps);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_mbstd_bwd_f32(const float* x, const float* gstat, float* gx, int G, int gs, long long F, float eps,
                          void* stream) {
   if (!x || !gstat || !gx || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(ew_blocks((long long)G * F)), dim3(256), 0, ST, x, gstat, gx, G, gs, F,
+  GL_LAUNCH(mbstd_bwd_kernel, dim3(ew_blocks((long long)G * F)), dim3(256), 0, ST, x, gstat, gx, G, gs, F,
                      eps);
   return GL_CHECK_LAUNCH();
 }
@@ -766,26 +766,26 @@ int ganlab_mbstd_bwd_f32(const float* x, const float* gstat, float* gx, int G, i
 int ganlab_mbstd_bwdbwd_f32(const float* x, const float* gstat, const float* ggx, float* g_gstat, float* g_x,
                             int G, int gs, long long F, float eps, void* stream) {
   if (!x || !gstat || !ggx || !g_gstat || !g_x || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(mbstd_bwdbwd_kernel, dim3(G), dim3(256), 0, ST, x, gstat, ggx, g_gstat, g_x, gs, F, eps);
+  GL_LAUNCH(mbstd_bwdbwd_kernel, dim3(G), dim3(256), 0, ST, x, gstat, ggx, g_gstat, g_x, gs, F, eps);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_axpby_f32(const float* x, const float* y, float* out, long long n, float a, float b, void* stream) {
   if (!x || !out || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, x, y, out, n, a, b);
+  GL_LAUNCH(axpby_kernel, dim3(ew_blocks((n >> 2) + 4)), dim3(256), 0, ST, x, y, out, n, a, b);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_scale_dev_f32(const float* x, const float* gout, float* out, long long n, float a, void* stream) {
   if (!gout || !out || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, x, gout, out, n, a);
+  GL_LAUNCH(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, x, gout, out, n, a);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_lerp_rows_f32(const float* a, const float* b, const float* t, float* out, long long N, long long M,
                          void* stream) {
   if (!a || !b || !t || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(lerp_rows_kernel, dim3(ew_blocks(N * M)), dim3(256), 0, ST, a, b, t, out, N, M);
+  GL_LAUNCH(lerp_rows_kernel, dim3(ew_blocks(N * M)), dim3(256), 0, ST, a, b, t, out, N, M);
   return GL_CHECK_LAUNCH();
 }
 
@@ -796,20 +796,20 @@ int ganlab_sum_f32(const float* x, float* out, long long n, float scale, int squ
   if (!x || !out || n <= 0) return GANLAB_EINVAL;
   const int nb = sum_blocks(n);
   if (!workspace || workspace_bytes < (size_t)nb * sizeof(float)) return GANLAB_EWORKSPACE;
-  hipLaunchKernelGGL(sum_stage1, dim3(nb), dim3(256), 0, ST, x, (float*)workspace, n, squared);
-  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
+  GL_LAUNCH(sum_stage1, dim3(nb), dim3(256), 0, ST, x, (float*)workspace, n, squared);
+  GL_LAUNCH(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_bce_logits_fwd_f32(const float* x, float* out, int n, float target, void* stream) {
   if (!x || !out || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, ST, x, out, n, target);
+  GL_LAUNCH(bce_fwd_kernel, dim3(1), dim3(256), 0, ST, x, out, n, target);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_bce_logits_bwd_f32(const float* x, const float* gout, float* gx, int n, float target, void* stream) {
   if (!x || !gout || !gx || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, x, gout, gx, n, target);
+  GL_LAUNCH(bce_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, x, gout, gx, n, target);
   return GL_CHECK_LAUNCH();
 }
 
@@ -818,15 +818,15 @@ int ganlab_chnorm_penalty_fwd_f32(const float* g, float* out, int N, int C, long
   if (!g || !out || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const int nb = sum_blocks((long long)N * HW);
   if (!workspace || workspace_bytes < (size_t)nb * sizeof(float)) return GANLAB_EWORKSPACE;
-  hipLaunchKernelGGL(chnorm_pen_stage1, dim3(nb), dim3(256), 0, ST, g, (float*)workspace, N, C, HW, gamma);
-  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
+  GL_LAUNCH(chnorm_pen_stage1, dim3(nb), dim3(256), 0, ST, g, (float*)workspace, N, C, HW, gamma);
+  GL_LAUNCH(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)workspace, out, nb, scale);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_chnorm_penalty_bwd_f32(const float* g, const float* gout, float* gg, int N, int C, long long HW,
                                   float gamma, float scale, void* stream) {
   if (!g || !gout || !gg || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(chnorm_pen_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, g, gout, gg, N,
+  GL_LAUNCH(chnorm_pen_bwd_kernel, dim3(ew_blocks((long long)N * HW)), dim3(256), 0, ST, g, gout, gg, N,
                      C, HW, gamma, scale);
   return GL_CHECK_LAUNCH();
 }
@@ -834,20 +834,20 @@ int ganlab_chnorm_penalty_bwd_f32(const float* g, const float* gout, float* gg, 
 int ganlab_adam_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, float wd, float bc1, float bc2, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, wd,
+  GL_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, wd,
                      bc1, bc2);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void* stream) {
   if (!lagged || !p || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(ewma_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, lagged, p, n, beta);
+  GL_LAUNCH(ewma_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, lagged, p, n, beta);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream) {
   if (!out || n <= 0) return GANLAB_EINVAL;
-  hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, offset);
+  GL_LAUNCH(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, offset);
   return GL_CHECK_LAUNCH();
 }
 

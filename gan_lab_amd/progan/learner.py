@@ -1,0 +1,445 @@
+"""ProGANLearner on the HIP path (drop-in surface of gan_lab/progan/learner.py).
+
+Same constructor / ``train(train_dl, valid_dl=None, z_valid_dl=None, num_main_iters=None,
+num_gen_iters=None, num_disc_iters=None)`` contract and the same training algorithm
+(progan/learner.py:418-1030): phase machine -> D iterations -> G iterations -> EWMA -> alpha -> LR
+schedule; but
+  * every tensor op of the step runs in the hand-written kernels (gan_lab_amd.ops),
+  * the phase machine is the host-only ``schedule.PhaseSchedule`` (pinned to the reference's trace),
+  * parameters / gradients / Adam moments / the EWMA shadow live in flat arenas (optim.py),
+  * with torch.distributed initialised the step is data parallel over RCCL (parallel.py): the D
+    gradient all-reduce overlaps the next G forward,
+  * the fade-in of the real images (``up(down(x))*(1-a) + x*a``, :771-779) runs on the device,
+  * losses are only synchronised to the host every ``log_every`` iterations.
+Validation metrics, image grids and plotting (:249-416, :1147-1234) are outside the hot path.
+"""
+import copy
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from .. import ops, parallel, rng
+from .._int import LearnerConfigCopy
+from ..optim import EwmaTracker, ParamArena
+from ..resnetgan.learner import GANLearner
+from ..schedule import FINAL, GROW, STABILISE, PhaseSchedule, ewma_beta
+from ..utils import backprop_utils as bp
+from ..utils.backprop_utils import configure_adam_for_gan
+from ..utils.latent_utils import gen_rand_latent_vars
+from .architectures import ProDiscriminator, ProGenerator
+from .base import ProGAN
+
+NONREDEFINABLE_ATTRS = ('model', 'init_res', 'res_samples', 'res_dataset', 'len_latent', 'num_classes',
+                        'class_condition', 'use_auxiliary_classifier', 'model_upsample_type',
+                        'model_downsample_type', 'align_corners', 'blur_type', 'nonlinearity', 'use_equalized_lr',
+                        'normalize_z', 'use_pixelnorm', 'mbstd_group_size', 'use_ewma_gen',)
+REDEFINABLE_FROM_LEARNER_ATTRS = ('batch_size', 'loss', 'gradient_penalty', 'optimizer', 'lr_sched',
+                                  'latent_distribution',)
+COMPUTE_EWMA_VIA_HALFLIFE = True
+EWMA_SMOOTHING_HALFLIFE = 10.
+EWMA_SMOOTHING_BETA = .999
+
+_EXCL_G = ['prev_torgb.conv2d.weight', 'prev_torgb.conv2d.bias']
+_EXCL_D = ['prev_fromrgb.0.conv2d.weight', 'prev_fromrgb.0.conv2d.bias']
+
+
+class ProGANLearner(GANLearner):
+    """GAN learner for progressively grown architectures (ProGAN here, StyleGAN in the subclass)."""
+    _family = ProGAN
+    _nonredefinable = NONREDEFINABLE_ATTRS
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.curr_phase_num = 0
+        self.lagged_params = None
+        self._progressively_grow = True
+        self.sched = None
+        self.reducer = parallel.GradReducer()
+        self.log_every = getattr(config, 'log_every', 50)
+        self.last_losses = {}
+        if self.model == 'ProGAN':
+            self._init_progressive(config, self.__class__.__name__)
+
+    # ------------------------------------------------------------------------------------------------
+    def _build_networks(self):
+        c = self.config
+        gen = ProGenerator(final_res=c.res_samples, len_latent=c.len_latent, upsampler=self.gen_model_upsampler,
+                           blur_type=c.blur_type, nl=self.nl, num_classes=self.num_classes_gen,
+                           equalized_lr=c.use_equalized_lr, normalize_z=c.normalize_z,
+                           use_pixelnorm=c.use_pixelnorm)
+        disc = ProDiscriminator(final_res=c.res_samples, pooler=self.disc_model_downsampler, blur_type=c.blur_type,
+                                nl=self.nl, num_classes=self.num_classes_disc, equalized_lr=c.use_equalized_lr,
+                                mbstd_group_size=c.mbstd_group_size)
+        return gen, disc
+
+    def _init_progressive(self, config, learner_name):
+        """Common constructor body of ProGANLearner / StyleGANLearner (progan/learner.py:104-206)."""
+        self.config = LearnerConfigCopy(config, learner_name, self._nonredefinable, REDEFINABLE_FROM_LEARNER_ATTRS)
+        self._is_data_configed = False
+        self._update_data_config(raise_exception=False)
+        self.latent_distribution = self.config.latent_distribution
+        self._family.reset_state()
+        self.gen_model, self.disc_model = self._build_networks()
+        assert self.config.init_res <= self.config.res_samples
+        if self.config.init_res > 4:
+            import numpy as np
+            l2 = int(np.log2(self.config.init_res))
+            if float(self.config.init_res) != 2 ** l2:
+                raise ValueError('Only resolutions that are powers of 2 are supported.')
+            for _ in range(l2 - 2):
+                self.gen_model.increase_scale()
+                self.disc_model.increase_scale()
+            self.gen_model.fade_in_phase = False
+        assert self.gen_model.cls_base.__dict__ == self.disc_model.cls_base.__dict__
+        self.gen_model.to(self.config.dev)
+        self.disc_model.to(self.config.dev)
+        self.batch_size = self.config.bs_dict[self.gen_model.curr_res]
+        self._loss = config.loss.casefold()
+        self._set_loss()
+        self._make_arenas(first=True)
+        self._set_optimizer()
+        self.eps = self.config.eps_drift > 0
+        if parallel.rank() == 0:
+            print('-------- Initialized Model Configuration --------')
+            print(self.config)
+            print('-------------------------------------------------')
+            print('\n    Ready to train!\n')
+
+    # ------------------------------------------------------------------------------------------------
+    def _make_arenas(self, first=False, old_lagged=None):
+        """Flat parameter / gradient arenas for G and D (+ the EWMA shadow of G)."""
+        dev = self.config.dev
+        self.arena_g = ParamArena(self.gen_model.named_parameters(), dev)
+        self.arena_d = ParamArena(self.disc_model.named_parameters(), dev)
+        if first:
+            parallel.broadcast_params(self.arena_g.flat)
+            parallel.broadcast_params(self.arena_d.flat)
+        self.ewma = None
+        self.gen_model_lagged = None
+        if self.config.use_ewma_gen:
+            if first or old_lagged is None:
+                self.ewma = EwmaTracker(self.arena_g)
+            else:
+                # progan/learner.py:662-684: torgb.* becomes prev_torgb.*, new parameters start from
+                # their current value, order follows named_parameters()
+                self.ewma = EwmaTracker.__new__(EwmaTracker)
+                self.ewma.rebuild(self.arena_g, old_lagged, rename={'torgb.conv2d.weight': 'prev_torgb.conv2d.weight',
+                                                                    'torgb.conv2d.bias': 'prev_torgb.conv2d.bias'})
+            self.lagged_params = self.ewma.lagged_params
+
+    def _set_optimizer(self):
+        """Fresh Adam (state reset) over the current parameter set; prev_torgb / prev_fromrgb are left
+        out once the fade-in is over (progan/learner.py:1064-1095)."""
+        if self._optimizer != 'adam':
+            if self._optimizer in ('rmsprop', 'momentum', 'sgd'):
+                raise NotImplementedError(f'{self._optimizer} optimizer not yet implemented.')
+            raise ValueError("config does not support this optimizer.\nSupported Optimizers are: "
+                             "[ 'adam', 'rmsprop', 'momentum', 'sgd' ]")
+        c = self.config
+        adam_gan = configure_adam_for_gan(lr_base=c.lr_base, betas=(c.beta1, c.beta2), eps=c.eps, wd=c.wd)
+        fade = self.gen_model.fade_in_phase
+        self.opt_gen = adam_gan(params=list(self.gen_model.most_parameters(excluded_params=[] if fade else _EXCL_G)))
+        self.opt_disc = adam_gan(params=list(self.disc_model.most_parameters(excluded_params=[] if fade else _EXCL_D)))
+
+    def _set_scheduler(self):
+        """LambdaLR whose factor follows the current resolution (progan/learner.py:1034-1062)."""
+        if self._lr_sched == 'resolution dependent':
+            self.scheduler_fn = lambda _: self.config.lr_fctr_dict[self.gen_model.curr_res]
+        elif self._lr_sched == 'linear decay':
+            self.scheduler_fn = lambda it: 1. - (it + self.sched_stop_step) * (1. / self.num_main_iters)
+        elif self._lr_sched == 'custom':
+            self.scheduler_fn = eval(self.config.lr_sched_custom)
+        else:
+            raise ValueError("config does not support this LR scheduler.\nCurrently supported LR Schedulers are: "
+                             "[ 'resolution dependent', 'linear decay', 'custom' ]")
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            self.scheduler_gen = torch.optim.lr_scheduler.LambdaLR(self.opt_gen, self.scheduler_fn, last_epoch=-1)
+            self.scheduler_disc = torch.optim.lr_scheduler.LambdaLR(self.opt_disc, self.scheduler_fn, last_epoch=-1)
+
+    def _reset_opt_and_sched(self):
+        self._set_optimizer()
+        if self.sched_bool:
+            self.sched_stop_step += self.scheduler_gen._step_count if self.scheduler_gen is not None else 0
+            self._set_scheduler()
+
+    def get_smoothing_ewma_beta(self, half_life):
+        assert isinstance(half_life, float)
+        return ewma_beta(self.batch_size, self.config.gen_bs_mult, half_life)
+
+    @property
+    def progressively_grow(self):
+        return self._progressively_grow
+
+    # ------------------------------------------------------------------------------------------------
+    # the hot path: one D iteration, one G iteration
+    # ------------------------------------------------------------------------------------------------
+    def _gen_forward(self, zb, **kw):
+        return self.gen_model(zb, **kw)
+
+    def fade_in_real(self, xb):
+        """Real images follow the generator's fade-in: up(down(x))*(1-alpha) + x*alpha
+        (progan/learner.py:771-779, the non-bit-exact branch), on the device."""
+        if not self.gen_model.fade_in_phase:
+            return xb
+        return ops.lerp(ops.k_up2(ops.k_pool2(xb, 0.25), 1.0), xb, self.gen_model.alpha)
+
+    def d_step(self, xb, zb=None, defer_update=False, gen_kwargs=None, eps_interp=None):
+        """One discriminator iteration (progan/learner.py:734-816).  ``xb``: real batch on the device,
+        already at the current resolution.  Returns the (device) loss scalar."""
+        c = self.config
+        self.arena_d.zero_grad()
+        if zb is None:
+            zb = gen_rand_latent_vars(num_samples=self.batch_size, length=c.len_latent,
+                                      distribution=self.latent_distribution, device=c.dev)
+        with torch.no_grad():                    # the generator is frozen in the D step (:752-753)
+            xgenb = self._gen_forward(zb, **(gen_kwargs or {}))
+        xb = self.fade_in_real(xb)
+        d_gen, d_real = self.disc_model(xgenb), self.disc_model(xb)
+        loss = self.loss_func_disc(d_gen, d_real)
+        if self.gradient_penalty is not None:
+            loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
+        if self.eps:
+            loss = loss + bp.drift_loss(d_real, c.eps_drift)
+        loss.backward()
+        self.reducer.start(self.arena_d.gflat)   # RCCL mean all-reduce, overlaps what follows
+        if not defer_update:
+            self._finish_d_update()
+        return loss.detach()
+
+    def _finish_d_update(self):
+        self.reducer.finish()
+        self.opt_disc.step()
+
+    def g_step(self, zb=None, d_update_pending=False, gen_kwargs=None):
+        """One generator iteration (progan/learner.py:857-916) + EWMA shadow update."""
+        c = self.config
+        self.arena_g.zero_grad()
+        if zb is None:
+            zb = gen_rand_latent_vars(num_samples=self.batch_size * c.gen_bs_mult, length=c.len_latent,
+                                      distribution=self.latent_distribution, device=c.dev)
+        fake = self._gen_forward(zb, **(gen_kwargs or {}))   # needs G weights only -> overlaps the D all-reduce
+        if d_update_pending:
+            self._finish_d_update()
+        loss = self.loss_func_gen(self.disc_model(fake))
+        loss.backward()
+        self.reducer.allreduce(self.arena_g.gflat)
+        self.opt_gen.step()
+        if c.use_ewma_gen:
+            self.ewma.update(self.beta)
+        return loss.detach()
+
+    def set_requires_grad_disc(self, flag):
+        for p in self.disc_model.parameters():
+            p.requires_grad_(flag)
+
+    # ------------------------------------------------------------------------------------------------
+    def _grow(self):
+        """Growth event (progan/learner.py:562-685)."""
+        old_lagged = dict(self.lagged_params) if self.lagged_params is not None else None
+        self.gen_model.increase_scale()
+        self.disc_model.increase_scale()
+        assert self.gen_model.cls_base.__dict__ == self.disc_model.cls_base.__dict__
+        self.gen_model.to(self.config.dev)
+        self.disc_model.to(self.config.dev)
+        self._make_arenas(old_lagged=old_lagged)
+        self.batch_size = self.config.bs_dict[self.gen_model.curr_res]
+        self._reset_opt_and_sched()
+        self._set_loss()
+        self.gen_model.alpha = 0
+        if self.config.use_ewma_gen and COMPUTE_EWMA_VIA_HALFLIFE:
+            self.beta = self.get_smoothing_ewma_beta(half_life=EWMA_SMOOTHING_HALFLIFE)
+
+    def _bump_loader(self, dl):
+        """train_dl duck type: assignable batch size + a Resize in the transform list."""
+        if dl is None:
+            return
+        dl.batch_sampler.batch_size = self.batch_size
+        tf = getattr(getattr(getattr(dl, 'dataset', None), 'transforms', None), 'transform', None)
+        if tf is not None and hasattr(self, 'increase_real_data_res'):
+            tf.transforms = self.increase_real_data_res(transforms_lst=tf.transforms)
+
+    def increase_real_data_res(self, transforms_lst: list):
+        """Swap the first Resize for one at the current resolution (progan/learner.py:1099-1112)."""
+        res = self.gen_model.curr_res
+        n_rsz = 0
+        for n, tr in enumerate(transforms_lst):
+            if tr.__class__.__name__ == 'Resize':
+                n_rsz += 1
+                if n_rsz < 2:
+                    kw = dict(size=(res, res,))
+                    interp = getattr(self.data_config, 'dataset_downsample_type', None) if self.data_config else None
+                    if interp is not None:
+                        kw['interpolation'] = interp
+                    transforms_lst[n] = tr.__class__(**kw)
+                else:
+                    raise RuntimeWarning('Warning: More than 1 `Resize` transform found; only resized the first '
+                                         '`Resize` in transforms list.')
+        return transforms_lst
+
+    # ------------------------------------------------------------------------------------------------
+    def train(self, train_dl, valid_dl=None, z_valid_dl=None, num_main_iters=None, num_gen_iters=None,
+              num_disc_iters=None):
+        """Progressive GAN training (see the module docstring); re-entrant like the reference."""
+        c = self.config
+        num_main_iters = c.num_main_iters if num_main_iters is None else num_main_iters
+        num_gen_iters = c.num_gen_iters if num_gen_iters is None else num_gen_iters
+        num_disc_iters = c.num_disc_iters if num_disc_iters is None else num_disc_iters
+        self.num_main_iters = num_main_iters
+        self.dataset_sz = len(train_dl.dataset)
+        self.gen_model.to(c.dev).train()
+        self.disc_model.to(c.dev).train()
+        if self.not_trained_yet:
+            self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, c.bs_dict,
+                                       c.nimg_transition, num_disc_iters)
+            self.beta = None
+            if c.use_ewma_gen:
+                self.beta = self.get_smoothing_ewma_beta(half_life=EWMA_SMOOTHING_HALFLIFE) \
+                    if COMPUTE_EWMA_VIA_HALFLIFE else EWMA_SMOOTHING_BETA
+            self.train_dataiter = iter(train_dl)
+            if parallel.rank() == 0:
+                print('STARTING FROM ITERATION 0:\n')
+        elif parallel.rank() == 0:
+            print('CONTINUING FROM WHERE YOU LEFT OFF:\n')
+        if self.sched_bool:
+            if self.scheduler_gen is None:
+                self.sched_stop_step = 0
+            self._set_scheduler()
+        sched = self.sched
+        self.nimg_transition_lst = sched.nimg_transition_lst
+
+        for itr in range(num_main_iters):
+            self.set_requires_grad_disc(True)
+            for ev in sched.begin_iter():
+                if ev == GROW:
+                    prev = self.gen_model.curr_res
+                    self._grow()
+                    self._bump_loader(train_dl)
+                    self._bump_loader(valid_dl)
+                    if z_valid_dl is not None:
+                        z_valid_dl.batch_sampler.batch_size = self.batch_size
+                    if parallel.rank() == 0:
+                        print(f'\n\n\nRESOLUTION INCREASED FROM {prev}x{prev} to {self.gen_model.curr_res}x'
+                              f'{self.gen_model.curr_res}\n\nFADING IN {self.gen_model.curr_res}x'
+                              f'{self.gen_model.curr_res} RESOLUTION...\n')
+                elif ev == STABILISE:
+                    self._reset_opt_and_sched()
+                    if parallel.rank() == 0:
+                        print('\nSTABILIZING...\n')
+                elif ev == FINAL:
+                    self._reset_opt_and_sched()
+                    self._progressively_grow = False
+                    if parallel.rank() == 0:
+                        print('\nSTABILIZING (FINAL)...\n')
+            self.curr_phase_num = sched.curr_phase_num
+            assert sched.curr_res == self.gen_model.curr_res and sched.batch_size == self.batch_size
+
+            # ------------------------- TRAIN DISCRIMINATOR -------------------------
+            for disc_iter in range(num_disc_iters):
+                batch = next(self.train_dataiter, None)
+                if batch is None:
+                    self.curr_epoch_num += 1
+                    self.train_dataiter = iter(train_dl)
+                    batch = next(self.train_dataiter)
+                xb = batch[0].to(c.dev, non_blocking=True).float()
+                last = disc_iter == num_disc_iters - 1
+                loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0)
+                self.curr_dataset_batch_num += 1
+                sched.after_d_iter()
+                self.curr_img_num = sched.curr_img_num
+
+            # --------------------------- TRAIN GENERATOR ---------------------------
+            self.set_requires_grad_disc(False)
+            loss_g = None
+            for gen_iter in range(num_gen_iters):
+                loss_g = self.g_step(d_update_pending=(gen_iter == 0))
+            if num_gen_iters == 0:
+                self._finish_d_update()
+
+            # alpha, LR schedule (progan/learner.py:951-956)
+            sched.end_iter()
+            if self.gen_model.fade_in_phase:
+                if sched.fade_in_phase:
+                    self.gen_model.alpha = sched.alpha
+                else:
+                    self.gen_model.alpha = 1      # snaps and leaves the fade-in phase for both networks
+            if self.sched_bool:
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    self.scheduler_gen.step()
+                    self.scheduler_disc.step()
+            self.not_trained_yet = False
+            if self.log_every and (itr % self.log_every == 0 or itr == num_main_iters - 1):
+                self.last_losses = dict(itr=itr, loss_d=float(loss_d), loss_g=float(loss_g) if loss_g is not None
+                                        else None, res=self.gen_model.curr_res, alpha=float(self.gen_model.alpha),
+                                        fade_in=bool(self.gen_model.fade_in_phase), batch=self.batch_size)
+                if parallel.rank() == 0:
+                    print(('%9s' * 6) % (f'{self.curr_epoch_num}', f'{self.gen_model.curr_res}X'
+                                         f'{self.gen_model.curr_res}',
+                                         'Fade In' if self.gen_model.fade_in_phase else 'Stab.',
+                                         '%.4g' % self.last_losses['loss_d'],
+                                         '%.4g' % (self.last_losses['loss_g'] or 0.), itr))
+            if (itr + 1) % c.num_iters_save_model == 0:
+                self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+        self.set_requires_grad_disc(True)
+
+    # ------------------------------------------------------------------------------------------------
+    def materialize_lagged_generator(self):
+        """EWMA generator as a module (progan/learner.py:223-242): a deep copy of G with the lagged
+        parameter values loaded."""
+        g = copy.deepcopy(self.gen_model)
+        if self.config.use_ewma_gen and self.lagged_params is not None:
+            sd = g.state_dict()
+            for k, v in self.lagged_params.items():
+                sd[k] = v.detach().clone()
+            g.load_state_dict(sd)
+        self.gen_model_lagged = g
+        return g
+
+    def save_model(self, save_path):
+        """Checkpoint (plain data; key names follow progan/learner.py:1257-1298)."""
+        save_path = str(save_path)
+        os.makedirs(os.path.dirname(save_path) or '.', exist_ok=True)
+        lagged = self.materialize_lagged_generator() if self.config.use_ewma_gen else None
+        torch.save({
+            'config': {k: v for k, v in vars(self.config).items() if not k.startswith('_') and
+                       isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))},
+            'curr_res': self.gen_model.curr_res,
+            'alpha': self.gen_model.alpha,
+            'gen_model_state_dict': {k: v.detach().cpu() for k, v in self.gen_model.state_dict().items()},
+            'disc_model_state_dict': {k: v.detach().cpu() for k, v in self.disc_model.state_dict().items()},
+            'gen_model_lagged_state_dict': None if lagged is None else
+            {k: v.detach().cpu() for k, v in lagged.state_dict().items()},
+            'curr_img_num': self.curr_img_num,
+            'curr_phase_num': self.curr_phase_num,
+            'nimg_transition_lst': list(self.sched.nimg_transition_lst) if self.sched else None,
+            'not_trained_yet': self.not_trained_yet,
+        }, save_path)
+
+    def load_model(self, load_path, dev_of_saved_model='cpu'):
+        """Restore networks by replaying ``increase_scale`` up to the saved resolution
+        (progan/learner.py:1348-1360); ``weights_only=False`` is required on torch >= 2.6."""
+        ck = torch.load(str(load_path), map_location=dev_of_saved_model, weights_only=False)
+        self._family.reset_state()
+        self.gen_model, self.disc_model = self._build_networks()
+        import numpy as np
+        for _ in range(int(np.log2(ck['curr_res'])) - 2):
+            self.gen_model.increase_scale()
+            self.disc_model.increase_scale()
+        self.gen_model.load_state_dict(ck['gen_model_state_dict'])
+        self.disc_model.load_state_dict(ck['disc_model_state_dict'])
+        self.gen_model.fade_in_phase = ck['alpha'] != 1
+        self.gen_model.alpha = ck['alpha']
+        self.gen_model.to(self.config.dev)
+        self.disc_model.to(self.config.dev)
+        self.batch_size = self.config.bs_dict[self.gen_model.curr_res]
+        self._make_arenas(first=True)
+        if ck.get('gen_model_lagged_state_dict') is not None and self.lagged_params is not None:
+            with torch.no_grad():
+                for k, v in ck['gen_model_lagged_state_dict'].items():
+                    if k in self.lagged_params:
+                        self.lagged_params[k].copy_(v.to(self.config.dev))
+        self._set_optimizer()
+        self.pretrained_model = True

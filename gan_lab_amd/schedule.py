@@ -1,0 +1,88 @@
+"""Progressive-growing phase machine as pure host logic (no torch, no GPU).
+
+Restates the control flow of ProGANLearner.train (gan_lab/progan/learner.py:451-459, :560-729,
+:848, :951-952): per resolution above ``init_res`` one FADE-IN phase then one
+STABILISE phase, each ``nimg_transition`` real images long (rounded UP to a multiple of the current
+batch size); the image counter advances by ``batch_size`` per D iteration; after the last
+resolution's fade-in a FINAL phase of unbounded length starts.  The learner asks ``begin_iter()``
+what to do before each main iteration and reports progress with ``after_d_iter()`` /
+``end_iter()``; everything numeric (alpha, delta_alpha, batch size) is returned as plain numbers.
+"""
+import math
+
+GROW, STABILISE, FINAL = 'grow', 'stabilise', 'final'
+
+
+def round_nimg_transition(nimg_transition, batch_size):
+    """progan/learner.py:451-455 / :646-649."""
+    if nimg_transition % batch_size != 0:
+        return batch_size * (int(nimg_transition / batch_size) + 1)
+    return nimg_transition
+
+
+def delta_alpha(batch_size, nimg_transition, num_disc_iters):
+    """progan/learner.py:653."""
+    return batch_size / ((nimg_transition / num_disc_iters) - batch_size)
+
+
+def ewma_beta(batch_size, gen_bs_mult=1, half_life=10.):
+    """progan/learner.py:1124-1127."""
+    return .5 ** ((batch_size * gen_bs_mult) / (half_life * 1000.)) if half_life > 0. else 0.
+
+
+class PhaseSchedule(object):
+    def __init__(self, init_res, final_res, bs_dict, nimg_transition_cfg, num_disc_iters=1):
+        self.curr_res, self.final_res = init_res, final_res
+        self.bs_dict = dict(bs_dict)
+        self.nimg_transition_cfg = nimg_transition_cfg
+        self.num_disc_iters = num_disc_iters
+        self.batch_size = self.bs_dict[init_res]
+        self.nimg_transition = round_nimg_transition(nimg_transition_cfg, self.batch_size)
+        self.nimg_transition_lst = [self.nimg_transition]
+        self.curr_img_num = 0
+        self.curr_phase_num = 0
+        self.progressively_grow = True
+        self.fade_in_phase = False
+        self.alpha = 1
+        self.delta_alpha = None
+        self.alpha_tol = 1.e-8
+
+    def begin_iter(self):
+        """Returns the list of events to apply before this main iteration: any of GROW, STABILISE,
+        FINAL (at most one of the first two, then possibly FINAL never together with them)."""
+        events = []
+        at_boundary = self.curr_img_num == sum(self.nimg_transition_lst)
+        if self.curr_res < self.final_res and at_boundary:
+            self.curr_phase_num += 1
+            if self.curr_phase_num % 2 == 1:
+                self.curr_res *= 2
+                self.batch_size = self.bs_dict[self.curr_res]
+                self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.batch_size)
+                self.delta_alpha = delta_alpha(self.batch_size, self.nimg_transition, self.num_disc_iters)
+                self.alpha = 0
+                self.fade_in_phase = True
+                events.append(GROW)
+            else:
+                events.append(STABILISE)
+            self.nimg_transition_lst.append(self.nimg_transition)
+        if self.curr_img_num == sum(self.nimg_transition_lst):
+            self.curr_phase_num += 1
+            self.nimg_transition_lst.append(math.inf)
+            self.progressively_grow = False
+            events.append(FINAL)
+        return events
+
+    def after_d_iter(self):
+        self.curr_img_num += self.batch_size
+
+    def end_iter(self):
+        """alpha += delta_alpha with the setter's snap-to-1 (base.py:161-170)."""
+        if self.fade_in_phase:
+            new_alpha = self.alpha + self.delta_alpha
+            if not (0. <= new_alpha < 1. + self.alpha_tol):
+                raise ValueError('Input alpha parameter must be in the range [0,1].')
+            if 1. - self.alpha_tol < new_alpha < 1. + self.alpha_tol:
+                self.fade_in_phase = False
+                self.alpha = 1
+            else:
+                self.alpha = new_alpha

@@ -136,6 +136,8 @@ class FunctionalGAN:
             p.grad = None
         with torch.no_grad():
             fake = self.gen(z, noise, alpha, fade_in, cutoff_idx, z_mix)
+            if fade_in:   # reals follow the fade-in: up(down(x))*(1-a) + x*a  (progan/learner.py:771-779)
+                real = ops.upsample2(ops.avgpool2(real)) * (1.0 - alpha) + real * alpha
         total, parts = d_loss(self.d, self.cfg, fake, real, self.loss, self.gp, self.lda, self.gamma,
                               self.eps_drift, alpha, fade_in, eps_interp, return_parts=True)
         total.backward()

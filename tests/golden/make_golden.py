@@ -360,6 +360,11 @@ def golden_step(kind, res, tag, loss, gp, fade_in=False, alpha=1.0, b=4, lr=1e-3
             p.requires_grad_(True)
         d.zero_grad()
         fake = (g(zd, noise=nd) if kind == 'stylegan' else g(zd)).detach()
+        if fade_in:
+            # real images are faded in like the generator's output (progan/learner.py:771-779)
+            with torch.no_grad():
+                real = F.interpolate(F.avg_pool2d(real, kernel_size=2, stride=2), scale_factor=2, mode='nearest') * \
+                    (1. - g.alpha) + real * g.alpha
         d_fake, d_real = d(fake), d(real)
         if loss == 'wgan':
             ld = (d_fake - d_real).mean()

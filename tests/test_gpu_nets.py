@@ -1,0 +1,137 @@
+"""GPU parity of the product generator / discriminator modules (HIP path) against golden vectors
+captured from the reference itself, and against the CPU oracle: outputs, parameter gradients, the
+R1 / WGAN-GP penalty value and its double-backward gradients.  Tolerance 1e-3 relative fp32 (the
+north-star bar); typical error is ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, load_golden, sub, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def build_pair(kind, res, sd_g, sd_d):
+    from gan_lab_amd import progressive as P
+    from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator, StyleDiscriminator
+    from gan_lab_amd.stylegan.architectures import StyleGenerator
+    P.FMAP_BASE, P.FMAP_MAX = 64, 16       # the fixtures' shrunken widths (tests/golden/make_golden.py)
+    if kind == 'stylegan':
+        P.StyleGAN.reset_state()
+        g = StyleGenerator(final_res=64, len_latent=16, len_dlatent=16, mapping_num_fcs=2, blur_type='binomial')
+        d = StyleDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4)
+    else:
+        P.ProGAN.reset_state()
+        g = ProGenerator(final_res=64, len_latent=16, blur_type='binomial')
+        d = ProDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4)
+    for _ in range(int(np.log2(res)) - 2):
+        g.increase_scale()
+        d.increase_scale()
+    g.load_state_dict(sd_g)
+    if sd_d is not None:
+        d.load_state_dict(sd_d)
+    return g.cuda(), d.cuda()
+
+
+@pytest.fixture(autouse=True)
+def _restore_widths():
+    from gan_lab_amd import progressive as P
+    yield
+    P.FMAP_BASE, P.FMAP_MAX = 8192, 512
+
+
+NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'progan_stab16', 'progan_fade8']
+
+
+@pytest.mark.parametrize('name', NETS)
+def test_nets_match_reference_golden(name):
+    from gan_lab_amd import ops
+    from gan_lab_amd.utils import backprop_utils as bp
+    G = load_golden(name + '.npz')
+    kind, loss, gp = [str(s) for s in G['meta']]
+    res, alpha, fade = int(G['res']), float(G['alpha']), bool(G['fade_in'])
+    g, d = build_pair(kind, res, sub(G, 'g.'), sub(G, 'd.'))
+    g.fade_in_phase = fade
+    g.alpha = alpha if fade else 1
+    g.eval()
+    d.train()
+    z, real = t(G['z']).cuda(), t(G['real']).cuda()
+    if kind == 'stylegan':
+        g.use_truncation_trick = False
+        noise = [t(G[f'noise{i}']).cuda() for i in range(len(g.gen_layers))]
+        img = g(z, noise=noise)
+    else:
+        img = g(z)
+    assert_close(img, G['img'], TOL, 'G(z)')
+    # ---- G step gradients through a frozen D (progan/learner.py:857-904) ----
+    for p in d.parameters():
+        p.requires_grad_(False)
+    dout = d(img)
+    assert_close(dout, G['d_of_img'], TOL, 'D(G(z))')
+    lg = bp.loss_gen(loss, dout)
+    assert_close(lg, G['loss_g'], TOL, 'loss_g')
+    g.zero_grad()
+    lg.backward()
+    ref = sub(G, 'gg.')
+    for k, p in g.named_parameters():
+        if k in ref:
+            assert p.grad is not None, k
+            assert_close(p.grad, ref[k], TOL, 'G grad ' + k)
+    for p in d.parameters():
+        p.requires_grad_(True)
+    # ---- D step: adversarial + gradient penalty + drift (progan/learner.py:788-815) ----
+    fake = img.detach()
+    d.zero_grad()
+    d_fake, d_real = d(fake), d(real)
+    adv = bp.loss_disc(loss, d_fake, d_real)
+    assert_close(adv, G['loss_d_adv'], TOL, 'adv')
+    gpv = bp.calc_gp(d, gp, fake, real, lda=10., gamma=1., eps_interp=t(G['eps_interp']).cuda())
+    assert_close(gpv, G['gp'], TOL, 'gradient penalty')
+    total = adv + gpv + ops.sumsq_all(d_real, 0.001 / d_real.numel())
+    assert_close(total, G['loss_d'], TOL, 'loss_d')
+    total.backward()
+    for k, v in sub(G, 'gd.').items():
+        assert_close(dict(d.named_parameters())[k].grad, v, TOL, 'D grad ' + k)
+    # ---- GP-only double backward ----
+    d.zero_grad()
+    bp.calc_gp(d, gp, fake, real, lda=10., gamma=1., eps_interp=t(G['eps_interp']).cuda()).backward()
+    for k, v in sub(G, 'ggp.').items():
+        assert_close(dict(d.named_parameters())[k].grad, v, TOL, 'GP grad ' + k)
+
+
+def test_stylegan_mixing_and_w_ewma():
+    G = load_golden('stylegan_mixing16.npz')
+    from gan_lab_amd.stylegan.architectures import StyleAddNoise
+    g, _ = build_pair('stylegan', 16, sub(G, 'g.'), None)
+    g.cuda().train()
+    g.fade_in_phase = False
+    g.alpha = 1
+    noise = [t(G[f'noise{i}']).cuda() for i in range(len(g.gen_layers))]
+    StyleAddNoise.honour_noise_in_training = True
+    try:
+        img = g(t(G['z']).cuda(), noise=noise, _mix=(int(G['cutoff_idx']), t(G['z_mix']).cuda()))
+    finally:
+        StyleAddNoise.honour_noise_in_training = False
+    assert_close(img, G['img'], TOL, 'mixing-regularised G(z)')
+    assert_close(g.w_ewma, G['w_ewma'], TOL, 'w_ewma')
+
+
+def test_full_width_layer_shapes_vs_oracle():
+    """Real channel widths (512 -> 256 -> ...) at small batch: one generator block + one discriminator
+    block of the 1024^2 network's shapes, HIP vs oracle, so the thick-channel kernel configs are hit."""
+    from gan_lab_amd import ops
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 512, 8, 8, generator=gen)
+    w = torch.randn(512, 512, 3, 3, generator=gen)
+    b = torch.randn(512, generator=gen)
+    ws = O.conv_wscale(w, 2.0)
+    ref = O.lrelu(O.conv2d_ex(x, w, b, ws, padding=1))
+    y = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), scale=ws, padding=1, act='lrelu')
+    assert_close(y, ref, TOL)
+    x2 = torch.randn(2, 512, 16, 16, generator=gen)
+    w2 = torch.randn(256, 512, 3, 3, generator=gen)
+    ref = O.blur_binomial(O.conv2d_ex(O.upsample2(x2), w2, None, O.conv_wscale(w2, 2.0), padding=1))
+    y = ops.blur(ops.conv2d(x2.cuda(), w2.cuda(), None, scale=O.conv_wscale(w2, 2.0), padding=1, up=True))
+    assert_close(y, ref, TOL)

@@ -1,0 +1,322 @@
+"""GPU parity of every HIP op (through the C-ABI) against the CPU oracle, on seeded inputs.
+Tolerance: the north star allows 1e-3 relative fp32; we assert 2e-4 (fp32 re-association only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from gan_lab_amd import ops as _ops, _lib
+    _lib.lib()  # raises if the HIP library is missing - no fallback
+    return _ops
+
+
+def gpu(x):
+    return x.detach().clone().cuda()
+
+
+def rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, ks, pad, up, bias, act
+    (3, 6, 7, 7, 5, 3, 1, False, True, None),          # odd sizes, channel padding
+    (2, 16, 64, 64, 16, 3, 1, False, False, None),     # thin 16->16 (the 1024^2 layer shape, small image)
+    (2, 32, 32, 32, 16, 3, 1, True, False, None),      # upsample folded in: 32@32^2 -> 16@64^2
+    (2, 3, 64, 64, 16, 1, 0, False, True, 'lrelu'),    # fromRGB
+    (2, 16, 64, 64, 3, 1, 0, False, True, None),       # toRGB
+    (4, 64, 16, 16, 64, 3, 1, False, True, 'lrelu'),   # thick, 16x16 tile geometry
+    (4, 128, 8, 8, 96, 3, 1, False, True, 'lrelu'),    # 8x8x4 geometry, 2 co tiles with a ragged one
+    (8, 256, 4, 4, 256, 3, 1, False, True, 'lrelu'),   # 4x4x16 geometry
+    (4, 257, 4, 4, 64, 3, 1, False, True, 'lrelu'),    # mbstd-style odd Cin (513 in the real net)
+    (2, 32, 8, 8, 32, 3, 1, True, False, None),        # up at small res
+    (1, 16, 128, 96, 16, 3, 1, False, False, None),    # non-square, 32x8 geometry with ragged tiles
+    (5, 24, 20, 20, 40, 3, 1, False, True, None),      # nothing a power of two
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    n, cin, h, w, cout, ks, pad, up, has_b, act = case
+    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = rnd(gen, n, cin, h, w).requires_grad_(True)
+    wt = rnd(gen, cout, cin, ks, ks).requires_grad_(True)
+    b = (rnd(gen, cout) if has_b else None)
+    if b is not None:
+        b.requires_grad_(True)
+    scale = 1.0 / np.sqrt(cin * ks * ks)
+    xi = F.interpolate(x, scale_factor=2, mode='nearest') if up else x
+    y_ref = F.conv2d(xi * scale, wt, b, padding=pad)
+    if act:
+        y_ref = F.leaky_relu(y_ref, 0.2)
+    cot = rnd(gen, *y_ref.shape)
+    (y_ref * cot).sum().backward()
+
+    xg, wg = gpu(x).requires_grad_(True), gpu(wt).requires_grad_(True)
+    bg = gpu(b).requires_grad_(True) if has_b else None
+    y = ops.conv2d(xg, wg, bg, scale=scale, padding=pad, up=up, act=act)
+    assert_close(y, y_ref, TOL, 'y')
+    (y * cot.cuda()).sum().backward()
+    assert_close(xg.grad, x.grad, TOL, 'dgrad')
+    assert_close(wg.grad, wt.grad, TOL, 'wgrad')
+    if has_b:
+        assert_close(bg.grad, b.grad, TOL, 'bias grad')
+
+
+LIN_CASES = [(8, 512, 512, 0.01), (4, 16, 32, 1.0), (32, 512, 1, 1.0), (5, 24, 70, 1.0), (32, 512, 1024, 1.0)]
+
+
+@pytest.mark.parametrize('case', LIN_CASES, ids=[str(c) for c in LIN_CASES])
+def test_linear(ops, case):
+    n, cin, cout, lrmul = case
+    gen = torch.Generator().manual_seed(cin * 7 + cout)
+    x = rnd(gen, n, cin).requires_grad_(True)
+    wt = (rnd(gen, cout, cin) / lrmul).requires_grad_(True)
+    b = rnd(gen, cout).requires_grad_(True)
+    ws = np.sqrt(2.0 / cin)
+    y_ref = F.leaky_relu((F.linear(x * ws, wt, b)) * lrmul, 0.2)
+    cot = rnd(gen, n, cout)
+    (y_ref * cot).sum().backward()
+    xg, wg, bg = gpu(x).requires_grad_(True), gpu(wt).requires_grad_(True), gpu(b).requires_grad_(True)
+    y = ops.linear(xg, wg, bg, scale=ws * lrmul, bias_scale=lrmul, act='lrelu')
+    assert_close(y, y_ref, TOL, 'y')
+    (y * cot.cuda()).sum().backward()
+    assert_close(xg.grad, x.grad, TOL, 'gx')
+    assert_close(wg.grad, wt.grad, TOL, 'gw')
+    assert_close(bg.grad, b.grad, TOL, 'gb')
+
+
+def test_conv4x4_valid_as_linear(ops):
+    gen = torch.Generator().manual_seed(44)
+    x = rnd(gen, 6, 32, 4, 4).requires_grad_(True)
+    wt = rnd(gen, 48, 32, 4, 4).requires_grad_(True)
+    b = rnd(gen, 48).requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(x * 0.05, wt, b), 0.2)
+    cot = rnd(gen, *y_ref.shape)
+    (y_ref * cot).sum().backward()
+    xg, wg, bg = gpu(x).requires_grad_(True), gpu(wt).requires_grad_(True), gpu(b).requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, scale=0.05, padding=0, act='lrelu')
+    assert_close(y, y_ref, TOL)
+    (y * cot.cuda()).sum().backward()
+    assert_close(xg.grad, x.grad, TOL)
+    assert_close(wg.grad, wt.grad, TOL)
+    assert_close(bg.grad, b.grad, TOL)
+
+
+def test_conv_golden_vectors(ops):
+    """Directly against the reference's own Conv2dEx / LinearEx outputs (tests/golden/ops.npz)."""
+    from oracle import ops as O
+    G = load_golden('ops.npz')
+    x, w, b = gpu(t(G['conv_x'])).requires_grad_(True), gpu(t(G['conv_w'])).requires_grad_(True), \
+        gpu(t(G['conv_b'])).requires_grad_(True)
+    y = ops.conv2d(x, w, b, scale=float(G['conv_wscale']), padding=1)
+    assert_close(y, G['conv_y'], TOL)
+    (y * t(G['conv_cot']).cuda()).sum().backward()
+    assert_close(x.grad, G['conv_gx'], TOL)
+    assert_close(w.grad, G['conv_gw'], TOL)
+    assert_close(b.grad, G['conv_gb'], TOL)
+    y4 = ops.conv2d(gpu(t(G['conv4_x'])), gpu(t(G['conv4_w'])), gpu(t(G['conv4_b'])), scale=float(G['conv4_wscale']))
+    assert_close(y4, G['conv4_y'], TOL)
+    y1 = ops.conv2d(gpu(t(G['conv1_x'])), gpu(t(G['conv1_w'])), gpu(t(G['conv1_b'])), scale=float(G['conv1_wscale']))
+    assert_close(y1, G['conv1_y'], TOL)
+    xl, wl, bl = gpu(t(G['lin_x'])).requires_grad_(True), gpu(t(G['lin_w'])).requires_grad_(True), \
+        gpu(t(G['lin_b'])).requires_grad_(True)
+    yl = ops.linear(xl, wl, bl, scale=float(G['lin_wscale']) * 0.01, bias_scale=0.01)
+    assert_close(yl, G['lin_y'], TOL)
+    (yl * t(G['lin_cot']).cuda()).sum().backward()
+    assert_close(xl.grad, G['lin_gx'], TOL)
+    assert_close(wl.grad, G['lin_gw'], TOL)
+    assert_close(bl.grad, G['lin_gb'], TOL)
+
+
+def test_conv_double_backward(ops):
+    """R1-shaped second order: d/dw of || d(sum lrelu(conv(x,w)+b))/dx ||^2 through the HIP kernels."""
+    gen = torch.Generator().manual_seed(9)
+    for (n, cin, h, cout, up) in [(2, 8, 8, 12, False), (2, 16, 16, 16, False), (2, 8, 4, 8, True)]:
+        x = rnd(gen, n, cin, h, h).requires_grad_(True)
+        w1 = rnd(gen, cout, cin, 3, 3).requires_grad_(True)
+        b1 = rnd(gen, cout).requires_grad_(True)
+        w2 = rnd(gen, 4, cout, 3, 3).requires_grad_(True)
+
+        def net_ref(x):
+            xi = F.interpolate(x, scale_factor=2, mode='nearest') if up else x
+            hmid = F.leaky_relu(F.conv2d(xi * 0.1, w1, b1, padding=1), 0.2)
+            return F.conv2d(hmid * 0.2, w2, None, padding=1)
+        out = net_ref(x)
+        g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+        pen = (g ** 2).sum()
+        pen.backward()
+
+        xg = gpu(x).requires_grad_(True)
+        w1g, b1g, w2g = gpu(w1).requires_grad_(True), gpu(b1).requires_grad_(True), gpu(w2).requires_grad_(True)
+        hmid = ops.conv2d(xg, w1g, b1g, scale=0.1, padding=1, up=up, act='lrelu')
+        outg = ops.conv2d(hmid, w2g, None, scale=0.2, padding=1)
+        gg, = torch.autograd.grad(ops.sum_all(outg), xg, create_graph=True)
+        assert_close(gg, g, TOL, 'first-order grad')
+        peng = ops.sumsq_all(gg)
+        assert_close(peng, pen, TOL, 'penalty')
+        peng.backward()
+        assert_close(w1g.grad, w1.grad, 5e-4, 'ggw1')
+        assert_close(w2g.grad, w2.grad, 5e-4, 'ggw2')
+        assert b1g.grad is None or b1g.grad.abs().max() < 1e-6  # LeakyReLU'' == 0
+
+
+def test_blur_pool_up(ops):
+    from oracle import ops as O
+    G = load_golden('ops.npz')
+    x = gpu(t(G['blur_x'])).requires_grad_(True)
+    y = ops.blur(x)
+    assert_close(y, G['blur_y'], TOL)
+    (y * t(G['blur_cot']).cuda()).sum().backward()
+    assert_close(x.grad, G['blur_gx'], TOL)
+    gen = torch.Generator().manual_seed(3)
+    for shape in [(2, 5, 8, 8), (1, 3, 64, 32), (3, 16, 4, 4)]:
+        a = rnd(gen, *shape).requires_grad_(True)
+        ag = gpu(a).requires_grad_(True)
+        for f_ref, f_gpu in ((O.avgpool2, ops.avg_pool2), (O.upsample2, ops.upsample2), (O.blur_binomial, ops.blur)):
+            a.grad = ag.grad = None
+            r = f_ref(a)
+            cot = rnd(gen, *r.shape)
+            (r * cot).sum().backward()
+            o = f_gpu(ag)
+            assert_close(o, r, TOL)
+            (o * cot.cuda()).sum().backward()
+            assert_close(ag.grad, a.grad, TOL)
+
+
+def test_bias_act_noise(ops):
+    gen = torch.Generator().manual_seed(5)
+    for shape in [(2, 6, 5, 5), (2, 16, 32, 32)]:
+        n, c, h, w = shape
+        x = rnd(gen, *shape).requires_grad_(True)
+        b = rnd(gen, 1, c, 1, 1).requires_grad_(True)
+        nw = rnd(gen, 1, c, 1, 1).requires_grad_(True)
+        nz = rnd(gen, n, 1, h, w)
+        ref = F.leaky_relu(x + nw * nz + b, 0.2)
+        cot = rnd(gen, *shape)
+        (ref * cot).sum().backward()
+        xg, bg, nwg = gpu(x).requires_grad_(True), gpu(b).requires_grad_(True), gpu(nw).requires_grad_(True)
+        y = ops.bias_act(xg, bg, nz.cuda(), nwg, act='lrelu')
+        assert_close(y, ref, TOL)
+        (y * cot.cuda()).sum().backward()
+        assert_close(xg.grad, x.grad, TOL)
+        assert_close(bg.grad, b.grad, TOL)
+        assert_close(nwg.grad, nw.grad, TOL)
+
+
+def test_instnorm_style_and_pixelnorm(ops):
+    from oracle import ops as O
+    G = load_golden('ops.npz')
+    x = gpu(t(G['in_x'])).requires_grad_(True)
+    y = ops.instnorm_style(x, None)
+    assert_close(y, G['in_y'], TOL)
+    (y * t(G['in_cot']).cuda()).sum().backward()
+    assert_close(x.grad, G['in_gx'], TOL)
+    x = gpu(t(G['pn_x'])).requires_grad_(True)
+    y = ops.pixelnorm(x)
+    assert_close(y, G['pn_y'], TOL)
+    (y * t(G['pn_cot']).cuda()).sum().backward()
+    assert_close(x.grad, G['pn_gx'], TOL)
+    gen = torch.Generator().manual_seed(8)
+    for shape in [(3, 8, 4, 4), (2, 16, 64, 64), (2, 5, 7, 9)]:
+        n, c = shape[0], shape[1]
+        a = (rnd(gen, *shape) * 2 + 0.5).requires_grad_(True)
+        st = rnd(gen, n, 2 * c).requires_grad_(True)
+        ref = O.adain_affine(O.instancenorm(a), st)
+        cot = rnd(gen, *shape)
+        (ref * cot).sum().backward()
+        ag, sg = gpu(a).requires_grad_(True), gpu(st).requires_grad_(True)
+        o = ops.instnorm_style(ag, sg)
+        assert_close(o, ref, TOL)
+        (o * cot.cuda()).sum().backward()
+        assert_close(ag.grad, a.grad, 5e-4)
+        assert_close(sg.grad, st.grad, TOL)
+    z = rnd(gen, 6, 32).requires_grad_(True)
+    ref = O.pixelnorm(z)
+    cot = rnd(gen, 6, 32)
+    (ref * cot).sum().backward()
+    zg = gpu(z).requires_grad_(True)
+    o = ops.pixelnorm(zg)
+    assert_close(o, ref, TOL)
+    (o * cot.cuda()).sum().backward()
+    assert_close(zg.grad, z.grad, TOL)
+
+
+@pytest.mark.parametrize('tag', ['mb8', 'mb6'])
+def test_mbstd_first_and_second_order(ops, tag):
+    from gan_lab_amd.utils.custom_layers import concat_mbstd_layer
+    G = load_golden('ops.npz')
+    x = gpu(t(G[f'{tag}_x'])).requires_grad_(True)
+    y = concat_mbstd_layer(x, 4)
+    assert_close(y, G[f'{tag}_y'], TOL)
+    gx, = torch.autograd.grad((y * t(G[f'{tag}_cot']).cuda()).sum(), x, create_graph=True)
+    assert_close(gx, G[f'{tag}_gx'], TOL)
+    ggx, = torch.autograd.grad((gx * t(G[f'{tag}_cot2']).cuda()).sum(), x)
+    assert_close(ggx, G[f'{tag}_ggx'], 5e-4)
+
+
+def test_mbstd_known_answer(ops):
+    from gan_lab_amd.utils.custom_layers import concat_mbstd_layer
+    y = concat_mbstd_layer(torch.full((4, 3, 4, 4), 2.5).cuda(), 4)
+    assert torch.allclose(y[:, 3].cpu(), torch.full((4, 4, 4), 1e-4), rtol=1e-5)
+
+
+def test_losses_and_reductions(ops):
+    G = load_golden('ops.npz')
+    a, b = gpu(t(G['loss_a'])).requires_grad_(True), gpu(t(G['loss_b'])).requires_grad_(True)
+    assert_close(ops.bce_logits_mean(a, 1.0), G['loss_ns_g'], TOL)
+    assert_close(ops.bce_logits_mean(a, 0.0) + ops.bce_logits_mean(b, 1.0), G['loss_mm_d'], TOL)
+    assert_close(ops.sum_all(a, 1 / 8) - ops.sum_all(b, 1 / 8), G['loss_wgan_d'], TOL)
+    ac = t(G['loss_a']).requires_grad_(True)
+    F.binary_cross_entropy_with_logits(ac, torch.ones(8)).backward()
+    ops.bce_logits_mean(a, 1.0).backward()
+    assert_close(a.grad, ac.grad, TOL)
+    gen = torch.Generator().manual_seed(12)
+    g = rnd(gen, 4, 3, 16, 16).requires_grad_(True)
+    ref = ((g.norm(2, dim=1) - 1.0) ** 2).mean() * 10.0 / 2
+    ref.backward()
+    gg = gpu(g).requires_grad_(True)
+    o = ops.chnorm_penalty(gg, 1.0, 10.0 / 2 / (4 * 16 * 16))
+    assert_close(o, ref, TOL)
+    o.backward()
+    assert_close(gg.grad, g.grad, TOL)
+    big = rnd(gen, 3, 3, 64, 64)
+    assert_close(ops.sumsq_all(big.cuda(), 0.5), (big ** 2).sum() * 0.5, TOL)
+
+
+def test_adam_ewma_randn(ops):
+    from oracle import step as S
+    gen = torch.Generator().manual_seed(21)
+    p, g = rnd(gen, 1000), rnd(gen, 1000)
+    st = S.new_adam_state(p)
+    pg, m, v = p.cuda(), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
+    pc = p.clone()
+    for step in range(1, 4):
+        S.adam_update(pc, g, st, 1e-3, 0.0, 0.99, 1e-8)
+        ops.adam_step(pg, g.cuda(), m, v, 1e-3, 0.0, 0.99, 1e-8, 0.0, 1 - 0.0 ** step, 1 - 0.99 ** step)
+        g = g * 0.5 + 0.1
+    assert_close(pg - p.cuda(), pc - p, 1e-4, 'adam update')
+    lag, cur = rnd(gen, 777), rnd(gen, 777)
+    lg = lag.cuda()
+    ops.ewma_step(lg, cur.cuda(), 0.999)
+    assert_close(lg, S.ewma_update(lag, cur, 0.999), 1e-6)
+    z = ops.randn((1 << 20,), 1234, 0, 'cuda')
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert abs((z ** 4).mean().item() - 3.0) < 0.1
+    z2 = ops.randn((1 << 20,), 1234, 0, 'cuda')
+    assert torch.equal(z, z2)
+    assert not torch.equal(z, ops.randn((1 << 20,), 1234, 1 << 18, 'cuda'))
+
+
+def test_cpu_tensor_is_rejected(ops):
+    with pytest.raises(TypeError):
+        ops.blur(torch.zeros(1, 1, 4, 4))

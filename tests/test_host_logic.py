@@ -1,0 +1,138 @@
+"""CPU tests of the host-side logic: phase machine vs the trace of the REAL reference learner,
+config / LearnerConfigCopy behaviour, C-ABI surface.  No GPU, no compute kernels."""
+import argparse
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_phase_schedule_matches_reference_trace():
+    from gan_lab_amd.schedule import FINAL, GROW, STABILISE, PhaseSchedule, ewma_beta
+    g = load_golden('schedule_progan_4to16.npz')
+    cols = [str(c) for c in g['columns']]
+    tr = g['trace']
+    bs_dict = {int(k): int(v) for k, v in g['bs_dict']}
+    lr_fctr = {int(k): float(v) for k, v in g['lr_fctr']}
+    ps = PhaseSchedule(4, 16, bs_dict, int(g['cfg_nimg_transition']), num_disc_iters=1)
+    saw = []
+    for row in tr:
+        r = dict(zip(cols, row))
+        ev = ps.begin_iter()
+        saw += ev
+        ps.after_d_iter()                      # one D iteration
+        # state seen by the G-step of this main iteration
+        assert ps.curr_res == int(r['curr_res']), r
+        assert int(ps.fade_in_phase) == int(r['fade_in']), r
+        assert abs(ps.alpha - r['alpha']) < 1e-9, r
+        assert ps.batch_size == int(r['batch']), r
+        assert ps.curr_phase_num == int(r['phase_num']), r
+        assert ps.curr_img_num == int(r['curr_img_num_after_dstep']), r
+        assert abs(1e-3 * lr_fctr[ps.curr_res] - r['lr_gen']) < 1e-12
+        ps.end_iter()
+    assert saw == [GROW, STABILISE, GROW, FINAL]
+    ref_lst = [x if x >= 0 else math.inf for x in g['nimg_transition_lst']]
+    assert ps.nimg_transition_lst == ref_lst
+    assert abs(ewma_beta(ps.batch_size) - float(g['final_beta'])) < 1e-15
+    # the real-image stream the reference consumed: (batch, resolution) per D iteration
+    assert [tuple(x) for x in g['real_batches']] == [(int(r[4]), int(r[1])) for r in tr]
+
+
+def test_schedule_known_answers():
+    from gan_lab_amd.schedule import delta_alpha, ewma_beta, round_nimg_transition
+    assert round_nimg_transition(600000, 64) == 600000
+    assert round_nimg_transition(600000, 7) == 7 * (600000 // 7 + 1)
+    assert delta_alpha(64, 600000, 1) == 64 / (600000 - 64)
+    assert abs(ewma_beta(32) - 0.5 ** (32 / 10000)) < 1e-15
+    assert ewma_beta(32, half_life=0.) == 0.
+
+
+def test_fmap_table_and_lockstep_state():
+    from gan_lab_amd import progressive as P
+    assert (P.FMAP_BASE, P.FMAP_MAX) == (8192, 512)
+    want = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
+    for res, f in want.items():
+        assert P._fmap(int(np.log2(res)) - 1) == f
+
+    class A(P.StyleGAN):
+        def forward(self, x):
+            return x
+
+    class B(P.StyleGAN):
+        def forward(self, x):
+            return x
+    P.StyleGAN.reset_state()
+    P.ProGAN.reset_state()
+    a, b = A(64), B(64)
+    a.increase_scale()
+    assert b.curr_res == 8 and b.fade_in_phase and b.scale_inc_metadata_updated
+    a.alpha = 0.25
+    assert b.alpha == 0.25
+    a.alpha = 1 - 1e-9          # snaps to 1 and leaves the fade-in phase (base.py:161-170)
+    assert b.alpha == 1 and not b.fade_in_phase
+    with pytest.raises(ValueError):
+        a.alpha = 1.5
+    assert a.cls_base.__dict__ == b.cls_base.__dict__
+    assert P.ProGAN._state.curr_res == 4     # the two families do not share state
+    P.StyleGAN.reset_state()
+
+
+def test_learner_config_copy_guards():
+    from gan_lab_amd._int import LearnerConfigCopy
+    ns = argparse.Namespace(model='StyleGAN', res_samples=128, batch_size=8, lda=10.0)
+    c = LearnerConfigCopy(ns, 'StyleGANLearner', ('model', 'res_samples'), ('batch_size',))
+    c.lda = 5.0
+    assert c.lda == 5.0 and ns.lda == 10.0
+    with pytest.raises(AttributeError):
+        c.res_samples = 256
+    with pytest.raises(AttributeError):
+        c.batch_size = 4
+    with pytest.raises(ValueError):
+        LearnerConfigCopy(ns, 'Nope', (), ())
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'ganlab_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ganlab_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads on a CPU-only box and exports exactly the functions the header
+    declares (no compute call is made here)."""
+    from gan_lab_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    declared = _header_functions()
+    assert len(declared) >= 30
+    assert sorted(_lib.SIGNATURES) == declared
+    handle = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    L = _lib.lib()
+    assert L.ganlab_abi_version() == 1
+    # pure host-side queries are callable without a GPU
+    g = _lib.ConvGeom(32, 16, 1024, 1024, 16, 3, 1, 0)
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    assert L.ganlab_conv_out_hw(ctypes.byref(g), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (ho.value, wo.value) == (1024, 1024)
+    assert L.ganlab_conv_pack_f32(None, None, 16, 32, 3, 0, 1.0, None) == 9 * 32 * 64
+    assert L.ganlab_conv_wgrad_workspace(ctypes.byref(g)) > 0
+    bad = _lib.ConvGeom(1, 1, 4, 4, 1, 5, 0, 0)
+    assert L.ganlab_conv_out_hw(ctypes.byref(bad), None, None) == -1
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    import torch
+    from gan_lab_amd import ops
+    with pytest.raises(TypeError):
+        ops.conv2d(torch.zeros(1, 3, 4, 4), torch.zeros(4, 3, 3, 3), padding=1)
+    with pytest.raises(TypeError):
+        ops.pixelnorm(torch.zeros(2, 8))
