@@ -180,16 +180,17 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
       const float4* p4 = reinterpret_cast<const float4*>(p);
       for (long long i = t; i < (HW >> 2); i += T) {
         const float4 v = p4[i];
-        const float a = (v.x + v.y) + (v.z + v.w);
-        const float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        s += a;
-        ss += q;
+        // squares and sums in fp64: a float product is exact in double, so var = E[x^2] - mean^2 does
+        // not suffer the fp32 cancellation (planes with |mean| >> std: e.g. the constant 4x4 input)
+        const double a = (double)v.x, b = (double)v.y, c = (double)v.z, d = (double)v.w;
+        s += (a + b) + (c + d);
+        ss += (a * a + b * b) + (c * c + d * d);
       }
     } else {
       for (long long i = t; i < HW; i += T) {
-        const float v = p[i];
+        const double v = (double)p[i];
         s += v;
-        ss += (double)v * v;
+        ss += v * v;
       }
     }
   }
@@ -228,13 +229,15 @@ __global__ void instnorm_style_fwd_kernel(const float* __restrict__ x, const flo
     const float m = mean[pl], r = rstd[pl];
     const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
     const float yb = style ? style[(n * 2 + 1) * C + c] : 0.f;
-    const float a = r * ys, b = yb - m * r * ys;
+    const float a = r * ys;
+    // subtract the mean FIRST: a constant plane must normalise to exactly 0 like the reference's
+    // (x - mean) / sqrt(var + eps), not to rounding noise amplified by rstd = 1e4
     if (VEC == 4) {
       float4 v = reinterpret_cast<const float4*>(x)[i];
-      v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+      v.x = (v.x - m) * a + yb; v.y = (v.y - m) * a + yb; v.z = (v.z - m) * a + yb; v.w = (v.w - m) * a + yb;
       reinterpret_cast<float4*>(y)[i] = v;
     } else {
-      y[i] = x[i] * a + b;
+      y[i] = (x[i] - m) * a + yb;
     }
   }
 }

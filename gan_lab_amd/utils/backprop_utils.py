@@ -87,6 +87,15 @@ def calc_gp(nn_disc, gp_type, gen_data, real_data, lda=10., gamma=1., eps_interp
         raise ValueError(f"unsupported gradient penalty '{gp_type}'")
     xb.requires_grad_(True)
     outb = nn_disc(xb)
+    return gp_from_output(outb, xb, gp_type, lda, gamma)
+
+
+def gp_from_output(outb, xb, gp_type, lda=10., gamma=1.):
+    """Penalty from an existing D(xb) graph: g = d outb / d xb with create_graph=True, then the
+    channel-norm reduction of resnetgan/learner.py:811-825.  Lets the D step evaluate D(real) ONCE and
+    use it both for the adversarial/drift terms and for R1 (the reference evaluates the identical
+    forward twice, progan/learner.py:789 and resnetgan/learner.py:809)."""
+    gp_type = gp_type.casefold()
     ones = torch.ones(outb.shape[0], device=outb.device)
     outb_grads = torch.autograd.grad(outb, xb, grad_outputs=ones, create_graph=True, retain_graph=True,
                                      only_inputs=True)[0]

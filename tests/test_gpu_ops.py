@@ -320,3 +320,24 @@ def test_adam_ewma_randn(ops):
 def test_cpu_tensor_is_rejected(ops):
     with pytest.raises(TypeError):
         ops.blur(torch.zeros(1, 1, 4, 4))
+
+
+def test_instnorm_near_constant_planes(ops):
+    """|mean| >> std (the generator's constant 4x4 input + weak noise): the statistics must not lose the
+    variance to fp32 cancellation, and an exactly constant plane must normalise to exactly 0."""
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(31)
+    for shape, std in [((4, 8, 4, 4), 1e-3), ((2, 4, 64, 64), 1e-2), ((3, 5, 16, 16), 3e-4)]:
+        a = (1.0 + std * torch.randn(*shape, generator=gen)).requires_grad_(True)
+        st = torch.randn(shape[0], 2 * shape[1], generator=gen)
+        ref = O.adain_affine(O.instancenorm(a), st)
+        cot = torch.randn(*shape, generator=gen)
+        (ref * cot).sum().backward()
+        ag = gpu(a).requires_grad_(True)
+        o = ops.instnorm_style(ag, st.cuda())
+        assert_close(o, ref, TOL, f'near-constant fwd {shape} {std}')
+        (o * cot.cuda()).sum().backward()
+        assert_close(ag.grad, a.grad, 2e-3, f'near-constant bwd {shape} {std}')
+    c = torch.full((2, 3, 4, 4), 1.0)
+    o = ops.instnorm_style(c.cuda(), None)
+    assert o.abs().max().item() == 0.0
