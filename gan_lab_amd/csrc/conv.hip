@@ -12,58 +12,227 @@
 //                      D[i][j]        (lane l holds rows (l>>4)*4+r, r=0..3, column l&15)
 //   so every lane ends up with 4 consecutive output channels of ONE pixel and the 16 lanes of a
 //   quarter-wave cover 16 consecutive pixels -> 64-byte coalesced NCHW stores.
-// A workgroup (256 threads = 4 waves, one per SIMD) owns a tile of CO_T channels x PX_T pixels,
-// where the pixels are an NI x TH x TW patch; per K-chunk of CI_T input channels the (halo'd)
-// activation patch and the [tap][ci][co] weight slab are staged in LDS, then each wave runs
-// KK * CI_T/4 * MB * NB MFMAs straight out of LDS (one ds_read_b32 per operand fragment).
-// LDS strides are padded so the two ci-halves of a 32-lane read group land on disjoint banks.
+// A workgroup (256 threads = 4 waves, one per SIMD) owns CO_T channels x PX_T pixels (an NI x TH x TW
+// patch).  Per K-chunk of CI_T input channels the halo'd activation patch and the [tap][ci][co]
+// weight slab go global -> registers -> LDS; the registers of chunk k+1 are loaded BEFORE the MFMA
+// phase of chunk k (software prefetch: HBM/L2 latency hides under 72..288 MFMAs per wave) and
+// every staging access is 16 bytes wide where the shape allows:
+//   XMODE 1 (VEC)   : rows [ox0-4, ox0+TW+4) as aligned float4 (W % 4 == 0, stride-1 source)
+//   XMODE 2 (VECUP) : low-res rows as aligned float4, duplicated 2x2 while being written to LDS
+//   XMODE 0         : per-element path for ragged / tiny shapes (4x4, 8x8, linears, odd sizes)
+// LDS strides are padded so the two k-halves of a 32-lane read group land on disjoint banks.
 #include "common.h"
 
 namespace {
 
 constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int ceil_div_c(int a, int b) { return (a + b - 1) / b; }
 // smallest s >= v with s % 32 == r
 constexpr int pad_mod32(int v, int r) { return v + ((r - (v % 32)) + 32) % 32; }
 
-struct ConvArgs {
+enum { XSCALAR = 0, XVEC = 1, XVECUP = 2 };
+
+// ---- activation-patch geometry shared by the forward and the weight-gradient kernels ----------------
+template <int KS_, int TWL_, int THL_, int NIL_, int XMODE_>
+struct PatchGeo {
+  static constexpr int KS = KS_, KK = KS_ * KS_, XMODE = XMODE_;
+  static constexpr int TWL = TWL_, THL = THL_, NIL = NIL_;
+  static constexpr int TW = 1 << TWL_, TH = 1 << THL_, NI = 1 << NIL_;
+  static constexpr int PX_T = TW * TH * NI;
+  static constexpr int PADC = (KS_ - 1) / 2;                       // "same" padding (vector modes)
+  static constexpr int LP = XMODE_ == XVECUP ? 8 : (XMODE_ == XVEC ? (KS_ == 3 ? 4 : 0) : 0);
+  static constexpr int R = TH + KS_ - 1;
+  static constexpr int RP = XMODE_ == XSCALAR ? TW + KS_ - 1 : TW + 2 * LP;   // LDS row pitch
+  static constexpr int XOFF = XMODE_ == XSCALAR ? 0 : LP - PADC;   // column of tap kx=0 for tx=0
+  static constexpr int IMG = R * RP;
+  // vector staging items (float4) per input channel
+  static constexpr int ROW4 = RP / 4;                // XVEC: float4 per patch row
+  static constexpr int LR = TH / 2 + 2;              // XVECUP: low-res rows per patch
+  static constexpr int LROW4 = RP / 8;               // XVECUP: float4 per low-res row
+  static constexpr int ITEMS_PER_CI =
+      XMODE_ == XSCALAR ? NI * IMG : (XMODE_ == XVEC ? NI * R * ROW4 : NI * LR * LROW4);
+  static_assert(XMODE_ == XSCALAR || (TW >= 8 && NI == 1), "vector staging needs TW >= 8, one image per tile");
+};
+
+struct PatchArgs {
   const float* x;
+  int N, Cin, Hi, Wi, Hv, Wv, pad, up;
+};
+
+// Descriptor of one staging item: LDS offset + channel, and the global offset relative to
+// x + n0*Cin*Hi*Wi (fits an int: NI*Cin*Hi*Wi < 2^31), or -1 when it is padding.
+template <class G, int CI_T, int PLANE>
+struct XStage {
+  static constexpr int NITEMS = CI_T * G::ITEMS_PER_CI;
+  static constexpr int PT = G::XMODE == XSCALAR ? 1 : ceil_div_c(NITEMS, 256);
+  int goff[PT];
+  int loff[PT];  // LDS offset | (ci << 20); for XVECUP bit 30/31 = write row 2lr-1 / 2lr
+  int n0_, oy0_, ox0_;  // scalar mode: tile origin (items are re-derived while staging)
+
+  __device__ __forceinline__ void init(const PatchArgs& p, int tid, int n0, int oy0, int ox0) {
+    const int plane = p.Hi * p.Wi;
+    n0_ = n0; oy0_ = oy0; ox0_ = ox0;
+    if (G::XMODE == XSCALAR) return;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int e = tid + i * 256;
+      int g = -1, l = 0;
+      if (G::XMODE == XVEC) {
+        const int q = e % G::ROW4;
+        int t = e / G::ROW4;
+        const int r = t % G::R, ci = t / G::R;
+        const int vy = oy0 + r - G::PADC, vx = ox0 - G::LP + 4 * q;
+        l = (ci * PLANE + r * G::RP + 4 * q) | (ci << 20);
+        if (e < NITEMS && n0 < p.N && (unsigned)vy < (unsigned)p.Hi && (unsigned)vx < (unsigned)p.Wi)
+          g = ci * plane + vy * p.Wi + vx;
+      } else {  // XVECUP: item = one low-res float4; expands to virtual rows 2lr-1, 2lr and 8 columns
+        const int q = e % G::LROW4;
+        int t = e / G::LROW4;
+        const int lr = t % G::LR, ci = t / G::LR;
+        const int ly = (oy0 >> 1) - 1 + lr, lx = ((ox0 - G::LP) >> 1) + 4 * q;
+        l = (ci * PLANE + (2 * lr) * G::RP + 8 * q) | (ci << 20);   // row 2lr; row 2lr-1 is one pitch above
+        if (lr > 0) l |= (1 << 30);
+        if (2 * lr < G::R) l |= (1 << 31);
+        if (e < NITEMS && n0 < p.N && (unsigned)ly < (unsigned)p.Hi && (unsigned)lx < (unsigned)p.Wi)
+          g = ci * plane + ly * p.Wi + lx;
+        else if (e >= NITEMS)
+          l &= ~((1 << 30) | (1 << 31));
+      }
+      goff[i] = g;
+      loff[i] = l;
+    }
+  }
+};
+
+// registers holding one staged chunk of the activation patch
+template <class G, int PT>
+struct XRegs {
+  float4 v[PT];
+};
+
+template <class G, int CI_T, int PLANE>
+__device__ __forceinline__ void x_load(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r, const XStage<G, CI_T, PLANE>& st,
+                                       const float* xb, int ci0, int Cin, int plane) {
+  constexpr int PT = XStage<G, CI_T, PLANE>::PT;
+  if (G::XMODE == XSCALAR) return;  // staged directly in x_store_scalar (no register prefetch)
+  const float* src = xb + (long long)ci0 * plane;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int ci = (st.loff[i] >> 20) & 0x3ff;
+    const bool ok = st.goff[i] >= 0 && ci0 + ci < Cin;
+    r.v[i] = ok ? *reinterpret_cast<const float4*>(src + st.goff[i]) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Per-element staging for ragged / tiny shapes: global -> LDS in batches of 8 independent loads.
+template <class G, int CI_T, int PLANE>
+__device__ __forceinline__ void x_stage_scalar(const XStage<G, CI_T, PLANE>& st, const PatchArgs& p,
+                                               const float* xb, int ci0, float* Xs, int tid) {
+  constexpr int NITEMS = CI_T * G::ITEMS_PER_CI;
+  constexpr int BATCH = 8;
+  const int plane = p.Hi * p.Wi;
+  for (int base = 0; base < NITEMS; base += 256 * BATCH) {
+    float v[BATCH];
+    int l[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const int e = base + tid + i * 256;
+      const int c = e % G::RP;
+      int t = e / G::RP;
+      const int r = t % G::R;
+      t /= G::R;
+      const int ni = t % G::NI, ci = t / G::NI;
+      const int vy = st.oy0_ + r - p.pad, vx = st.ox0_ + c - p.pad, n = st.n0_ + ni, cig = ci0 + ci;
+      l[i] = e < NITEMS ? ci * PLANE + ni * G::IMG + r * G::RP + c : -1;
+      v[i] = 0.f;
+      if (e < NITEMS && cig < p.Cin && n < p.N && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
+        const int iy = p.up ? (vy >> 1) : vy, ix = p.up ? (vx >> 1) : vx;
+        v[i] = xb[((long long)ni * p.Cin + cig) * plane + iy * p.Wi + ix];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i)
+      if (l[i] >= 0) Xs[l[i]] = v[i];
+  }
+}
+
+// 16-byte LDS store, or two 8-byte ones when the plane stride is only 8-byte aligned (wgrad)
+template <bool A16>
+__device__ __forceinline__ void lds_store4(float* dst, float4 v) {
+  if (A16) {
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    *reinterpret_cast<float2*>(dst) = float2{v.x, v.y};
+    *reinterpret_cast<float2*>(dst + 2) = float2{v.z, v.w};
+  }
+}
+
+template <class G, int CI_T, int PLANE, bool A16>
+__device__ __forceinline__ void x_store(const XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
+                                        const XStage<G, CI_T, PLANE>& st, float* Xs, int tid) {
+  constexpr int PT = XStage<G, CI_T, PLANE>::PT;
+  constexpr int NITEMS = XStage<G, CI_T, PLANE>::NITEMS;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int l = st.loff[i] & 0xfffff;
+    if (G::XMODE == XSCALAR) {
+      // nothing: see x_stage_scalar
+    } else if (G::XMODE == XVEC) {
+      if (tid + i * 256 < NITEMS) lds_store4<A16>(Xs + l, r.v[i]);
+    } else {
+      const float4 v = r.v[i];
+      const float4 a = float4{v.x, v.x, v.y, v.y}, b = float4{v.z, v.z, v.w, v.w};
+      if (st.loff[i] & (1 << 30)) {   // virtual row 2lr-1
+        lds_store4<A16>(Xs + l - G::RP, a);
+        lds_store4<A16>(Xs + l - G::RP + 4, b);
+      }
+      if (st.loff[i] & (1 << 31)) {   // virtual row 2lr
+        lds_store4<A16>(Xs + l, a);
+        lds_store4<A16>(Xs + l + 4, b);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / input-gradient kernel
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+  PatchArgs in;
   const float* wp;
   const float* bias;
   float* y;
-  int N, Cin, Hi, Wi;  // physical input
-  int Hv, Wv;          // virtual input (after optional up2)
   int Cout, Ho, Wo;
-  int pad, up;
   int Cin_p, Cout_p;   // packed-weight dims: wp[tap][Cin_p][Cout_p]
   int tiles_x, tiles_y, tiles_n, tiles_co;
   float bias_scale, slope;
   int act;
 };
 
-template <int KS_, int MB_, int TWL_, int THL_, int NIL_>
+template <int KS_, int MB_, int TWL_, int THL_, int NIL_, int XMODE_>
 struct FwdCfg {
+  using G = PatchGeo<KS_, TWL_, THL_, NIL_, XMODE_>;
   static constexpr int KS = KS_, KK = KS_ * KS_, MB = MB_;
   static constexpr int WN = 4;  // 4 waves side by side along the pixel dim
-  static constexpr int TWL = TWL_, THL = THL_, NIL = NIL_;
-  static constexpr int TW = 1 << TWL_, TH = 1 << THL_, NI = 1 << NIL_;
-  static constexpr int PX_T = TW * TH * NI;
-  static constexpr int NB = PX_T / (16 * WN);
+  static constexpr int NB = G::PX_T / (16 * WN);
   static constexpr int CO_T = 16 * MB_;
-  static constexpr int CI_T = (KS_ == 1) ? 32 : 8;
-  static constexpr int R = TH + KS_ - 1, C = TW + KS_ - 1;
-  static constexpr int IMG = R * C;
-  static constexpr int PLANE = pad_mod32(NI * IMG, 16);
+  static constexpr int CI_T = (KS_ == 1) ? 32 : (MB_ <= 2 ? 16 : 8);
+  static constexpr int PLANE = pad_mod32(G::NI * G::IMG, 16);
   static constexpr int COP = pad_mod32(CO_T, 16);
   static constexpr int XS = CI_T * PLANE, WS = KK * CI_T * COP;
+  static constexpr int NWI = KK * CI_T * CO_T / 4;  // float4 weight items per chunk
+  static constexpr int WPT = ceil_div_c(NWI, 256);
   static_assert(NB >= 1, "pixel tile too small");
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
+  using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
-  constexpr int C = Cfg::C, R = Cfg::R, IMG = Cfg::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
-  constexpr int NI = Cfg::NI, TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T;
-  __shared__ float smem[Cfg::XS + Cfg::WS];
+  constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
+  constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, WPT = Cfg::WPT, NWI = Cfg::NWI;
+  using XS_t = XStage<G, CI_T, PLANE>;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
   float* Xs = smem;
   float* Ws = smem + Cfg::XS;
 
@@ -76,88 +245,110 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs p) {
   const int tyi = bid % p.tiles_y;
   const int tni = bid / p.tiles_y;
   const int co0 = co_t * CO_T, ox0 = txi * TW, oy0 = tyi * TH, n0 = tni * NI;
+  const int plane = p.in.Hi * p.in.Wi;
+  const float* xb = p.in.x + (long long)n0 * p.in.Cin * plane;
 
+  // ---- staging descriptors (independent of the K-chunk) ----
+  XS_t xst;
+  xst.init(p.in, tid, n0, oy0, ox0);
+  int wg[WPT], wl[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int c4 = e % (CO_T / 4);
+    const int t = e / (CO_T / 4);
+    const int ci = t % CI_T, tap = t / CI_T;
+    wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
+    wg[i] = e < NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
+  }
+  // ---- per-lane MFMA operand offsets ----
   int boff[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
-    const int ni = j >> (Cfg::TWL + Cfg::THL), ty = (j >> Cfg::TWL) & (TH - 1), tx = j & (TW - 1);
-    boff[nb] = ni * IMG + ty * C + tx + (lane >> 4) * PLANE;
+    const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    boff[nb] = ni * IMG + ty * RP + tx + G::XOFF + (lane >> 4) * PLANE;
   }
   const int aoff = (lane >> 4) * COP + (lane & 15);
-
   f32x4 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long long in_plane = (long long)p.Hi * p.Wi;
+  XRegs<G, XS_t::PT> xr;
+  float4 wr[WPT];
+  auto load_w = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+                         : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  x_load<G, CI_T, PLANE>(xr, xst, xb, 0, p.in.Cin, plane);
+  load_w(0);
+
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    if (G::XMODE == XSCALAR) x_stage_scalar<G, CI_T, PLANE>(xst, p.in, xb, ci0, Xs, tid);
+    else x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
-    // ---- stage the activation patch (zero padding, optional nearest-2x upsample) ----
-    for (int e = tid; e < CI_T * NI * IMG; e += 256) {
-      const int c = e % C;
-      int t = e / C;
-      const int r = t % R;
-      t /= R;
-      const int ni = t % NI;
-      const int ci = t / NI;
-      const int vy = oy0 + r - p.pad, vx = ox0 + c - p.pad, n = n0 + ni, cig = ci0 + ci;
-      float v = 0.f;
-      if (cig < p.Cin && n < p.N && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
-        const int iy = p.up ? (vy >> 1) : vy, ix = p.up ? (vx >> 1) : vx;
-        v = p.x[((long long)n * p.Cin + cig) * in_plane + (long long)iy * p.Wi + ix];
-      }
-      Xs[ci * PLANE + ni * IMG + r * C + c] = v;
+    if (ci0 + CI_T < p.Cin_p) {  // prefetch the next chunk: in flight during the MFMA phase below
+      x_load<G, CI_T, PLANE>(xr, xst, xb, ci0 + CI_T, p.in.Cin, plane);
+      load_w(ci0 + CI_T);
     }
-    // ---- stage the weight slab: contiguous CO_T runs of wp[tap][ci][co] ----
-    for (int e = tid; e < KK * CI_T * CO_T; e += 256) {
-      const int co = e % CO_T;
-      const int t = e / CO_T;
-      const int ci = t % CI_T, tap = t / CI_T;
-      Ws[(tap * CI_T + ci) * COP + co] =
-          p.wp[((long long)tap * p.Cin_p + ci0 + ci) * p.Cout_p + co0 + co];
-    }
-    __syncthreads();
-    // ---- MFMA ----
+    // taps: ky is a real loop (bounds the compiler's hoisting of LDS reads, i.e. register pressure),
+    // kx and the 4-channel K-steps are unrolled with immediate LDS offsets
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {
+      const float* wrow = Ws + ky * (KS * CI_T * COP) + aoff;
+      const float* xrow = Xs + ky * RP;
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap) {
-      const int toff = (tap / KS) * C + (tap % KS);
+      for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
-      for (int c4 = 0; c4 < CI_T / 4; ++c4) {
-        float a[MB], b[NB];
+        for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+          float a[MB], b[NB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = Ws[(tap * CI_T + c4 * 4) * COP + aoff + mb * 16];
+          for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[(kx * CI_T + c4 * 4) * COP + mb * 16];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b[nb] = Xs[c4 * 4 * PLANE + boff[nb] + toff];
+          for (int nb = 0; nb < NB; ++nb) b[nb] = xrow[c4 * 4 * PLANE + boff[nb] + kx];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+        }
       }
     }
   }
   // ---- epilogue: + bias, activation, NCHW store ----
   const long long out_plane = (long long)p.Ho * p.Wo;
+  float bv[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+      bv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+    }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
-    const int ni = j >> (Cfg::TWL + Cfg::THL), ty = (j >> Cfg::TWL) & (TH - 1), tx = j & (TW - 1);
+    const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
     const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
-    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-    const long long pix = (long long)oy * p.Wo + ox;
+    if (n >= p.in.N || oy >= p.Ho || ox >= p.Wo) continue;
+    float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * out_plane + (long long)oy * p.Wo + ox;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
         if (co < p.Cout) {
-          float v = acc[mb][nb][r];
-          if (p.bias) v += p.bias[co] * p.bias_scale;
+          float v = acc[mb][nb][r] + bv[mb][r];
           if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
-          p.y[((long long)n * p.Cout + co) * out_plane + pix] = v;
+          dst[(long long)(mb * 16 + r) * out_plane] = v;
         }
       }
     }
@@ -190,40 +381,42 @@ __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ out
 // weight gradient: D[co][ci] (per tap) = sum_px gy[co][px] * Xv[ci][px shifted by tap]
 //   MFMA 16x16x4:  A[i=co][k=px] from a [co][px] LDS tile of gy, B[k=px][j=ci] from the halo'd patch.
 //   Waves are laid out WM (over co blocks) x WK (over the tile's 4-pixel K-steps); each workgroup
-//   walks pixel tiles `split, split+S, ...` and finally dumps its accumulators to a private slot of
-//   the workspace; wgrad_reduce_kernel sums the slots in a fixed order (deterministic).
+//   walks pixel tiles `split, split+S, ...` (next tile prefetched into registers during the MFMA
+//   phase) and finally dumps its accumulators to a private slot of the workspace;
+//   wgrad_reduce_kernel sums the slots in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
+  PatchArgs in;
   const float* gy;
-  const float* x;
   float* part;  // [slots][Cout][Cin][KK]
-  int N, Cin, Hi, Wi, Hv, Wv, Cout, Ho, Wo, pad, up;
+  int Cout, Ho, Wo;
   int tiles_x, tiles_y, tiles_n, tiles_co, tiles_ci, S;
 };
 
-template <int KS_, int WM_, int WK_, int TWL_, int THL_, int NIL_>
+template <int KS_, int NBC_, int WM_, int WK_, int TWL_, int THL_, int NIL_, int XMODE_>
 struct WgCfg {
-  static constexpr int KS = KS_, KK = KS_ * KS_, WM = WM_, WK = WK_;
-  static constexpr int NBC = 2;  // 32 input channels per workgroup
-  static constexpr int TWL = TWL_, THL = THL_, NIL = NIL_;
-  static constexpr int TW = 1 << TWL_, TH = 1 << THL_, NI = 1 << NIL_;
-  static constexpr int PX_T = TW * TH * NI;
-  static constexpr int CO_T = 16 * WM_, CI_T = 16 * NBC;
-  static constexpr int R = TH + KS_ - 1, C = TW + KS_ - 1, IMG = R * C;
-  static constexpr int PLANE = pad_mod32(NI * IMG, 2);
-  static constexpr int GP = pad_mod32(PX_T, 2);
+  using G = PatchGeo<KS_, TWL_, THL_, NIL_, XMODE_>;
+  static constexpr int KS = KS_, KK = KS_ * KS_, WM = WM_, WK = WK_, NBC = NBC_;
+  static constexpr int CO_T = 16 * WM_, CI_T = 16 * NBC_;
+  static constexpr int PLANE = pad_mod32(G::NI * G::IMG, 2);
+  static constexpr int GP = pad_mod32(G::PX_T, 2);
   static constexpr int GS = CO_T * GP, XS = CI_T * PLANE;
+  static constexpr int GVEC = XMODE_ != XSCALAR;
+  static constexpr int NGI = GVEC ? CO_T * G::PX_T / 4 : CO_T * G::PX_T;
+  static constexpr int GPT = ceil_div_c(NGI, 256);
   static_assert(WM_ * WK_ == 4, "4 waves");
-  static_assert(PX_T % (4 * WK_) == 0, "K-steps must split evenly over waves");
+  static_assert(G::PX_T % (4 * WK_) == 0, "K-steps must split evenly over waves");
 };
 
 template <class Cfg>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, NBC = Cfg::NBC, WK = Cfg::WK;
-  constexpr int C = Cfg::C, R = Cfg::R, IMG = Cfg::IMG, PLANE = Cfg::PLANE, GP = Cfg::GP;
-  constexpr int NI = Cfg::NI, TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, CI_T = Cfg::CI_T;
-  constexpr int PX_T = Cfg::PX_T;
-  __shared__ float smem[Cfg::GS + Cfg::XS];
+  constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, GP = Cfg::GP;
+  constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, CI_T = Cfg::CI_T, PX_T = G::PX_T;
+  constexpr int GPT = Cfg::GPT, NGI = Cfg::NGI;
+  using XS_t = XStage<G, CI_T, PLANE>;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::GS + Cfg::XS];
   float* Gs = smem;
   float* Xs = smem + Cfg::GS;
 
@@ -235,6 +428,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int ci_t = bid % p.tiles_ci;
   const int co_t = bid / p.tiles_ci;
   const int co0 = co_t * CO_T, ci0 = ci_t * CI_T;
+  const int plane = p.in.Hi * p.in.Wi, oplane = p.Ho * p.Wo;
 
   f32x4 acc[KK][NBC];
 #pragma unroll
@@ -242,47 +436,74 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int nb = 0; nb < NBC; ++nb) acc[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long long in_plane = (long long)p.Hi * p.Wi, out_plane = (long long)p.Ho * p.Wo;
+  // tile-independent part of the gy staging descriptors
+  int gl_[GPT], gj[GPT], gco[GPT];
+#pragma unroll
+  for (int i = 0; i < GPT; ++i) {
+    const int e = tid + i * 256;
+    const int per = Cfg::GVEC ? PX_T / 4 : PX_T;
+    const int j = (e % per) * (Cfg::GVEC ? 4 : 1), co = e / per;
+    gj[i] = e < NGI ? j : -1;
+    gco[i] = co;
+    gl_[i] = co * GP + j;
+  }
+
+  XS_t xst;
+  XRegs<G, XS_t::PT> xr;
+  float4 gv[Cfg::GVEC ? GPT : 1];
+  float gs[Cfg::GVEC ? 1 : GPT];
+
   const int n_tiles = p.tiles_n * p.tiles_y * p.tiles_x;
-  for (int tile = split; tile < n_tiles; tile += p.S) {
+  auto load_tile = [&](int tile) {
     const int txi = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
     const int tyi = t2 % p.tiles_y, tni = t2 / p.tiles_y;
     const int ox0 = txi * TW, oy0 = tyi * TH, n0 = tni * NI;
-    __syncthreads();
-    for (int e = tid; e < CO_T * PX_T; e += 256) {
-      const int j = e % PX_T, co = e / PX_T;
-      const int ni = j >> (Cfg::TWL + Cfg::THL), ty = (j >> Cfg::TWL) & (TH - 1), tx = j & (TW - 1);
-      const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx, cog = co0 + co;
-      float v = 0.f;
-      if (cog < p.Cout && n < p.N && oy < p.Ho && ox < p.Wo)
-        v = p.gy[((long long)n * p.Cout + cog) * out_plane + (long long)oy * p.Wo + ox];
-      Gs[co * GP + j] = v;
+    xst.init(p.in, tid, n0, oy0, ox0);
+    x_load<G, CI_T, PLANE>(xr, xst, p.in.x + (long long)n0 * p.in.Cin * plane, ci0, p.in.Cin, plane);
+    const float* gb = p.gy + (long long)n0 * p.Cout * oplane;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int j = gj[i];
+      const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+      const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx, cog = co0 + gco[i];
+      const bool ok = j >= 0 && cog < p.Cout && n < p.in.N && oy < p.Ho && ox < p.Wo;
+      const long long off = ((long long)ni * p.Cout + cog) * oplane + oy * p.Wo + ox;
+      if (Cfg::GVEC) gv[i] = ok ? *reinterpret_cast<const float4*>(gb + off) : float4{0.f, 0.f, 0.f, 0.f};
+      else gs[i] = ok ? gb[off] : 0.f;
     }
-    for (int e = tid; e < CI_T * NI * IMG; e += 256) {
-      const int c = e % C;
-      int t = e / C;
-      const int r = t % R;
-      t /= R;
-      const int ni = t % NI;
-      const int ci = t / NI;
-      const int vy = oy0 + r - p.pad, vx = ox0 + c - p.pad, n = n0 + ni, cig = ci0 + ci;
-      float v = 0.f;
-      if (cig < p.Cin && n < p.N && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv) {
-        const int iy = p.up ? (vy >> 1) : vy, ix = p.up ? (vx >> 1) : vx;
-        v = p.x[((long long)n * p.Cin + cig) * in_plane + (long long)iy * p.Wi + ix];
+  };
+
+  int tile = split;
+  if (tile < n_tiles) load_tile(tile);
+  while (tile < n_tiles) {
+    __syncthreads();
+    if (G::XMODE == XSCALAR)
+      x_stage_scalar<G, CI_T, PLANE>(xst, p.in, p.in.x + (long long)xst.n0_ * p.in.Cin * plane, ci0, Xs, tid);
+    else
+      x_store<G, CI_T, PLANE, false>(xr, xst, Xs, tid);
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      if (tid + i * 256 < NGI) {
+        if (Cfg::GVEC) {  // GP is even but not a multiple of 4: two 8-byte stores
+          *reinterpret_cast<float2*>(Gs + gl_[i]) = float2{gv[i].x, gv[i].y};
+          *reinterpret_cast<float2*>(Gs + gl_[i] + 2) = float2{gv[i].z, gv[i].w};
+        } else {
+          Gs[gl_[i]] = gs[i];
+        }
       }
-      Xs[ci * PLANE + ni * IMG + r * C + c] = v;
     }
     __syncthreads();
+    const int next = tile + p.S;
+    if (next < n_tiles) load_tile(next);  // in flight during the MFMA phase
     for (int q = wk; q < PX_T / 4; q += WK) {
       const int j = 4 * q + (lane >> 4);
-      const int ni = j >> (Cfg::TWL + Cfg::THL), ty = (j >> Cfg::TWL) & (TH - 1), tx = j & (TW - 1);
-      const int poff = ni * IMG + ty * C + tx + (lane & 15) * PLANE;
+      const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+      const int poff = ni * IMG + ty * RP + tx + G::XOFF + (lane & 15) * PLANE;
       const float a = Gs[(wm * 16 + (lane & 15)) * GP + j];
 #pragma unroll
       for (int tap = 0; tap < KK; ++tap) {
-        const int toff = (tap / KS) * C + (tap % KS);
+        const int toff = (tap / KS) * RP + (tap % KS);
 #pragma unroll
         for (int nb = 0; nb < NBC; ++nb) {
           const float b = Xs[nb * 16 * PLANE + poff + toff];
@@ -290,10 +511,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
       }
     }
+    tile = next;
   }
   // dump: slot = split*WK + wk ; D rows = co (lane>>4)*4+r, col = ci (lane&15)
   const int slot = split * WK + wk;
-  float* dst = p.part + (long long)slot * p.Cout * p.Cin * KK;
+  float* dst = p.part + (long long)slot * p.Cout * p.in.Cin * KK;
 #pragma unroll
   for (int tap = 0; tap < KK; ++tap)
 #pragma unroll
@@ -302,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wm * 16 + (lane >> 4) * 4 + r;
         const int ci = ci0 + nb * 16 + (lane & 15);
-        if (co < p.Cout && ci < p.Cin) dst[((long long)co * p.Cin + ci) * KK + tap] = acc[tap][nb][r];
+        if (co < p.Cout && ci < p.in.Cin) dst[((long long)co * p.in.Cin + ci) * KK + tap] = acc[tap][nb][r];
       }
 }
 
@@ -318,14 +540,30 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
-inline int cin_pad(int ks) { return ks == 1 ? 32 : 8; }
+inline int cin_pad(int ks) { return ks == 1 ? 32 : 16; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+PatchArgs make_patch(const float* x, int N, int Cin, int Hi, int Wi, int pad, int up) {
+  PatchArgs a{};
+  a.x = x; a.N = N; a.Cin = Cin; a.Hi = Hi; a.Wi = Wi;
+  a.Hv = up ? 2 * Hi : Hi; a.Wv = up ? 2 * Wi : Wi; a.pad = pad; a.up = up;
+  return a;
+}
+
+// staging mode for a patch source: vector paths need 16-byte aligned rows and "same" padding
+int pick_xmode(const PatchArgs& in, int ks, int out_w) {
+  if (out_w < 16 || (in.Wi & 3) || !aligned16(in.x) || in.pad != (ks - 1) / 2) return XSCALAR;
+  if (in.up) return ks == 3 ? XVECUP : XSCALAR;
+  return XVEC;
+}
 
 template <class Cfg>
 int launch_fwd(ConvArgs a, hipStream_t st) {
-  a.tiles_x = ceil_div(a.Wo, Cfg::TW);
-  a.tiles_y = ceil_div(a.Ho, Cfg::TH);
-  a.tiles_n = ceil_div(a.N, Cfg::NI);
+  using G = typename Cfg::G;
+  a.tiles_x = ceil_div(a.Wo, G::TW);
+  a.tiles_y = ceil_div(a.Ho, G::TH);
+  a.tiles_n = ceil_div(a.in.N, G::NI);
   a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
   const long long grid = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
@@ -335,11 +573,20 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
 
 template <int KS, int MB>
 int dispatch_geom(const ConvArgs& a, hipStream_t st) {
-  if (a.Ho == 1 && a.Wo == 1) return launch_fwd<FwdCfg<KS, MB, 0, 0, 6>>(a, st);
-  if (a.Wo >= 32) return launch_fwd<FwdCfg<KS, MB, 5, 3, 0>>(a, st);
-  if (a.Wo >= 16) return launch_fwd<FwdCfg<KS, MB, 4, 4, 0>>(a, st);
-  if (a.Wo >= 8) return launch_fwd<FwdCfg<KS, MB, 3, 3, 2>>(a, st);
-  return launch_fwd<FwdCfg<KS, MB, 2, 2, 4>>(a, st);
+  if (a.Ho == 1 && a.Wo == 1) return launch_fwd<FwdCfg<KS, MB, 0, 0, 6, XSCALAR>>(a, st);
+  const int mode = (aligned16(a.wp)) ? pick_xmode(a.in, KS, a.Wo) : XSCALAR;
+  if (a.Wo >= 32) {
+    if (mode == XVEC) return launch_fwd<FwdCfg<KS, MB, 5, 3, 0, XVEC>>(a, st);
+    if (KS == 3 && mode == XVECUP) return launch_fwd<FwdCfg<3, MB, 5, 3, 0, XVECUP>>(a, st);
+    return launch_fwd<FwdCfg<KS, MB, 5, 3, 0, XSCALAR>>(a, st);
+  }
+  if (a.Wo >= 16) {
+    if (mode == XVEC) return launch_fwd<FwdCfg<KS, MB, 4, 4, 0, XVEC>>(a, st);
+    if (KS == 3 && mode == XVECUP) return launch_fwd<FwdCfg<3, MB, 4, 4, 0, XVECUP>>(a, st);
+    return launch_fwd<FwdCfg<KS, MB, 4, 4, 0, XSCALAR>>(a, st);
+  }
+  if (a.Wo >= 8) return launch_fwd<FwdCfg<KS, MB, 3, 3, 2, XSCALAR>>(a, st);
+  return launch_fwd<FwdCfg<KS, MB, 2, 2, 4, XSCALAR>>(a, st);
 }
 
 template <int KS>
@@ -353,12 +600,12 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
              int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
   ConvArgs a{};
-  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
-  a.N = N; a.Cin = Cin; a.Hi = Hi; a.Wi = Wi;
-  a.Hv = up ? 2 * Hi : Hi; a.Wv = up ? 2 * Wi : Wi;
-  a.Cout = Cout; a.pad = pad; a.up = up;
-  a.Ho = a.Hv + 2 * pad - ks + 1; a.Wo = a.Wv + 2 * pad - ks + 1;
+  a.in = make_patch(x, N, Cin, Hi, Wi, pad, up);
+  a.wp = wp; a.bias = bias; a.y = y;
+  a.Cout = Cout;
+  a.Ho = a.in.Hv + 2 * pad - ks + 1; a.Wo = a.in.Wv + 2 * pad - ks + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return GANLAB_EINVAL;
+  if ((long long)Cin * a.in.Hi * a.in.Wi * 16 >= 0x7fffffffLL) return GANLAB_EINVAL;  // int offsets per tile
   a.Cin_p = round_up_c(Cin, cin_pad(ks)); a.Cout_p = round_up_c(Cout, 64);
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
   if (ks == 1) return dispatch_co<1>(a, st);
@@ -366,36 +613,10 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
   return GANLAB_EINVAL;
 }
 
-struct WgPlan { int thin; int tiles_x, tiles_y, tiles_n, tiles_co, tiles_ci, S, slots; };
-
-template <class Cfg>
-WgPlan plan_wgrad_cfg(int N, int Cin, int Cout, int Ho, int Wo, int thin) {
-  WgPlan pl{};
-  pl.thin = thin;
-  pl.tiles_x = ceil_div(Wo, Cfg::TW); pl.tiles_y = ceil_div(Ho, Cfg::TH); pl.tiles_n = ceil_div(N, Cfg::NI);
-  pl.tiles_co = ceil_div(Cout, Cfg::CO_T); pl.tiles_ci = ceil_div(Cin, Cfg::CI_T);
-  const long long n_tiles = (long long)pl.tiles_x * pl.tiles_y * pl.tiles_n;
-  const long long base = (long long)pl.tiles_co * pl.tiles_ci;
-  long long S = (1024 + base - 1) / base;  // aim for ~4 workgroups per CU
-  if (S > n_tiles) S = n_tiles;
-  if (S < 1) S = 1;
-  pl.S = (int)S;
-  pl.slots = pl.S * Cfg::WK;
-  return pl;
-}
-
-// thin : CO_T = 16, waves split the pixel K-steps (WM=1, WK=4), 256-pixel tiles
-// thick: CO_T = 64, one co block per wave (WM=4, WK=1), 64-pixel tiles
-template <int KS> using WgThinA = WgCfg<KS, 1, 4, 5, 3, 0>;   // 32x8
-template <int KS> using WgThinB = WgCfg<KS, 1, 4, 4, 4, 0>;   // 16x16
-template <int KS> using WgThinC = WgCfg<KS, 1, 4, 3, 3, 2>;   // 8x8 x4 images
-template <int KS> using WgThinD = WgCfg<KS, 1, 4, 2, 2, 4>;   // 4x4 x16 images
-template <int KS> using WgThinE = WgCfg<KS, 1, 4, 0, 0, 6>;   // 1x1 x64 samples (linear)
-template <int KS> using WgThickA = WgCfg<KS, 4, 1, 3, 3, 0>;  // 8x8
-template <int KS> using WgThickD = WgCfg<KS, 4, 1, 2, 2, 2>;  // 4x4 x4 images
-template <int KS> using WgThickE = WgCfg<KS, 4, 1, 0, 0, 6>;  // 1x1 x64 samples (linear)
-
+// ---- weight gradient ----
 enum WgGeom { WG_A, WG_B, WG_C, WG_D, WG_E };
+struct WgPlan { int thin, nbc, geom, xmode; int tiles_x, tiles_y, tiles_n, tiles_co, tiles_ci, S, slots; };
+
 inline WgGeom wg_geom(int Ho, int Wo, int thin) {
   if (Ho == 1 && Wo == 1) return WG_E;
   if (!thin) return (Wo >= 8) ? WG_A : WG_D;
@@ -405,39 +626,102 @@ inline WgGeom wg_geom(int Ho, int Wo, int thin) {
   return WG_D;
 }
 
-template <int KS>
-WgPlan plan_wgrad(int N, int Cin, int Cout, int Ho, int Wo) {
-  const int thin = Cout <= 32;
-  switch (wg_geom(Ho, Wo, thin)) {
-    case WG_A: return thin ? plan_wgrad_cfg<WgThinA<KS>>(N, Cin, Cout, Ho, Wo, 1)
-                           : plan_wgrad_cfg<WgThickA<KS>>(N, Cin, Cout, Ho, Wo, 0);
-    case WG_B: return plan_wgrad_cfg<WgThinB<KS>>(N, Cin, Cout, Ho, Wo, 1);
-    case WG_C: return plan_wgrad_cfg<WgThinC<KS>>(N, Cin, Cout, Ho, Wo, 1);
-    case WG_D: return thin ? plan_wgrad_cfg<WgThinD<KS>>(N, Cin, Cout, Ho, Wo, 1)
-                           : plan_wgrad_cfg<WgThickD<KS>>(N, Cin, Cout, Ho, Wo, 0);
-    default: return thin ? plan_wgrad_cfg<WgThinE<KS>>(N, Cin, Cout, Ho, Wo, 1)
-                         : plan_wgrad_cfg<WgThickE<KS>>(N, Cin, Cout, Ho, Wo, 0);
-  }
-}
-
 template <class Cfg>
-int launch_wgrad(WgradArgs a, const WgPlan& pl, hipStream_t st) {
-  a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.tiles_n = pl.tiles_n;
-  a.tiles_co = pl.tiles_co; a.tiles_ci = pl.tiles_ci; a.S = pl.S;
-  const long long grid = (long long)pl.tiles_co * pl.tiles_ci * pl.S;
-  GL_LAUNCH(conv_wgrad_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  return GL_CHECK_LAUNCH();
+void fill_plan(WgPlan& pl, int N, int Cin, int Cout, int Ho, int Wo) {
+  using G = typename Cfg::G;
+  pl.tiles_x = ceil_div(Wo, G::TW); pl.tiles_y = ceil_div(Ho, G::TH); pl.tiles_n = ceil_div(N, G::NI);
+  pl.tiles_co = ceil_div(Cout, Cfg::CO_T); pl.tiles_ci = ceil_div(Cin, Cfg::CI_T);
+  const long long n_tiles = (long long)pl.tiles_x * pl.tiles_y * pl.tiles_n;
+  const long long base = (long long)pl.tiles_co * pl.tiles_ci;
+  long long S = (1024 + base - 1) / base;  // aim for ~4 workgroups per CU
+  if (S > n_tiles) S = n_tiles;
+  if (S < 1) S = 1;
+  pl.S = (int)S;
+  pl.slots = pl.S * Cfg::WK;
 }
 
-template <int KS>
-int run_wgrad_ks(const WgradArgs& a, const WgPlan& pl, hipStream_t st) {
-  switch (wg_geom(a.Ho, a.Wo, pl.thin)) {
-    case WG_A: return pl.thin ? launch_wgrad<WgThinA<KS>>(a, pl, st) : launch_wgrad<WgThickA<KS>>(a, pl, st);
-    case WG_B: return launch_wgrad<WgThinB<KS>>(a, pl, st);
-    case WG_C: return launch_wgrad<WgThinC<KS>>(a, pl, st);
-    case WG_D: return pl.thin ? launch_wgrad<WgThinD<KS>>(a, pl, st) : launch_wgrad<WgThickD<KS>>(a, pl, st);
-    default: return pl.thin ? launch_wgrad<WgThinE<KS>>(a, pl, st) : launch_wgrad<WgThickE<KS>>(a, pl, st);
+// thin : CO_T = 16, waves split the pixel K-steps (WM=1, WK=4), 256-pixel tiles, 16 or 32 input channels
+// thick: CO_T = 64, one co block per wave (WM=4, WK=1), 64-pixel tiles, 32 input channels
+template <int KS, int NBC, int XM> using WgThinA = WgCfg<KS, NBC, 1, 4, 5, 3, 0, XM>;    // 32x8
+template <int KS, int NBC, int XM> using WgThinB = WgCfg<KS, NBC, 1, 4, 4, 4, 0, XM>;    // 16x16
+template <int KS, int NBC> using WgThinC = WgCfg<KS, NBC, 1, 4, 3, 3, 2, XSCALAR>;       // 8x8 x4 images
+template <int KS, int NBC> using WgThinD = WgCfg<KS, NBC, 1, 4, 2, 2, 4, XSCALAR>;       // 4x4 x16 images
+template <int KS, int NBC> using WgThinE = WgCfg<KS, NBC, 1, 4, 0, 0, 6, XSCALAR>;       // 1x1 x64 samples
+template <int KS, int XM> using WgThickA = WgCfg<KS, 2, 4, 1, 3, 3, 0, XM>;              // 8x8
+template <int KS> using WgThickD = WgCfg<KS, 2, 4, 1, 2, 2, 2, XSCALAR>;                 // 4x4 x4 images
+template <int KS> using WgThickE = WgCfg<KS, 2, 4, 1, 0, 0, 6, XSCALAR>;                 // 1x1 x64 samples
+
+// Calls F::template run<Cfg>() for the configuration selected by the plan's (thin, nbc, geom, xmode).
+template <int KS, class F>
+int wg_select(const WgPlan& pl, F&& f) {
+  const int xm = pl.xmode;
+  if (pl.thin) {
+    if (pl.nbc == 1) {
+      switch (pl.geom) {
+        case WG_A: return xm == XVEC ? f.template run<WgThinA<KS, 1, XVEC>>()
+                        : (KS == 3 && xm == XVECUP) ? f.template run<WgThinA<3, 1, XVECUP>>()
+                                                    : f.template run<WgThinA<KS, 1, XSCALAR>>();
+        case WG_B: return xm == XVEC ? f.template run<WgThinB<KS, 1, XVEC>>()
+                        : (KS == 3 && xm == XVECUP) ? f.template run<WgThinB<3, 1, XVECUP>>()
+                                                    : f.template run<WgThinB<KS, 1, XSCALAR>>();
+        case WG_C: return f.template run<WgThinC<KS, 1>>();
+        case WG_D: return f.template run<WgThinD<KS, 1>>();
+        default: return f.template run<WgThinE<KS, 1>>();
+      }
+    }
+    switch (pl.geom) {
+      case WG_A: return xm == XVEC ? f.template run<WgThinA<KS, 2, XVEC>>()
+                      : (KS == 3 && xm == XVECUP) ? f.template run<WgThinA<3, 2, XVECUP>>()
+                                                  : f.template run<WgThinA<KS, 2, XSCALAR>>();
+      case WG_B: return xm == XVEC ? f.template run<WgThinB<KS, 2, XVEC>>()
+                      : (KS == 3 && xm == XVECUP) ? f.template run<WgThinB<3, 2, XVECUP>>()
+                                                  : f.template run<WgThinB<KS, 2, XSCALAR>>();
+      case WG_C: return f.template run<WgThinC<KS, 2>>();
+      case WG_D: return f.template run<WgThinD<KS, 2>>();
+      default: return f.template run<WgThinE<KS, 2>>();
+    }
   }
+  switch (pl.geom) {
+    case WG_A: return xm == XVEC ? f.template run<WgThickA<KS, XVEC>>()
+                    : (KS == 3 && xm == XVECUP) ? f.template run<WgThickA<3, XVECUP>>()
+                                                : f.template run<WgThickA<KS, XSCALAR>>();
+    case WG_D: return f.template run<WgThickD<KS>>();
+    default: return f.template run<WgThickE<KS>>();
+  }
+}
+
+struct PlanFn {
+  WgPlan* pl; int N, Cin, Cout, Ho, Wo;
+  template <class Cfg> int run() { fill_plan<Cfg>(*pl, N, Cin, Cout, Ho, Wo); return 0; }
+};
+
+struct LaunchFn {
+  WgradArgs a; const WgPlan* pl; hipStream_t st;
+  template <class Cfg> int run() {
+    a.tiles_x = pl->tiles_x; a.tiles_y = pl->tiles_y; a.tiles_n = pl->tiles_n;
+    a.tiles_co = pl->tiles_co; a.tiles_ci = pl->tiles_ci; a.S = pl->S;
+    const long long grid = (long long)pl->tiles_co * pl->tiles_ci * pl->S;
+    GL_LAUNCH(conv_wgrad_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+    return GL_CHECK_LAUNCH();
+  }
+};
+
+// The plan must not depend on pointer alignment for the WORKSPACE SIZE (queried without pointers):
+// slots only depend on (thin, geom) through TW/TH/NI/WK, which are the same for every xmode.
+WgPlan plan_wgrad(const PatchArgs& in, const float* gy, int ks, int Cout, int Ho, int Wo) {
+  WgPlan pl{};
+  pl.thin = Cout <= 32;
+  pl.nbc = (pl.thin && in.Cin <= 16) ? 1 : 2;
+  pl.geom = wg_geom(Ho, Wo, pl.thin);
+  int xm = XSCALAR;
+  const int tw = pl.thin ? (pl.geom == WG_A ? 32 : (pl.geom == WG_B ? 16 : 0)) : (pl.geom == WG_A ? 8 : 0);
+  if (tw >= 8 && in.x && gy && !(in.Wi & 3) && !(Wo & 3) && aligned16(in.x) && aligned16(gy) &&
+      in.pad == (ks - 1) / 2)
+    xm = in.up ? (ks == 3 ? XVECUP : XSCALAR) : XVEC;
+  pl.xmode = xm;
+  PlanFn f{&pl, in.N, in.Cin, Cout, Ho, Wo};
+  if (ks == 1) wg_select<1>(pl, f); else wg_select<3>(pl, f);
+  return pl;
 }
 
 bool geom_ok(const ganlab_conv_geom* g) {
@@ -471,7 +755,7 @@ long long ganlab_conv_pack_f32(const float* w, float* out, int Cout, int Cin, in
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   GL_LAUNCH(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, gl_stream(stream), w, out, Cout, Cin,
-                     ks * ks, rows, cols, rows_p, cols_p, mode == GANLAB_PACK_DGRAD ? 1 : 0, scale);
+            ks * ks, rows, cols, rows_p, cols_p, mode == GANLAB_PACK_DGRAD ? 1 : 0, scale);
   return GL_CHECK_LAUNCH() == GANLAB_OK ? total : GANLAB_ELAUNCH;
 }
 
@@ -495,8 +779,8 @@ int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual, c
 size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g) {
   int ho, wo;
   if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK) return 0;
-  const WgPlan pl = g->ks == 1 ? plan_wgrad<1>(g->N, g->Cin, g->Cout, ho, wo)
-                               : plan_wgrad<3>(g->N, g->Cin, g->Cout, ho, wo);
+  const PatchArgs in = make_patch(nullptr, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
+  const WgPlan pl = plan_wgrad(in, nullptr, g->ks, g->Cout, ho, wo);
   return (size_t)pl.slots * g->Cout * g->Cin * g->ks * g->ks * sizeof(float);
 }
 
@@ -504,20 +788,19 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
                           void* workspace, size_t workspace_bytes, void* stream) {
   int ho, wo;
   if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK || !gy || !x || !gw) return GANLAB_EINVAL;
-  const WgPlan pl = g->ks == 1 ? plan_wgrad<1>(g->N, g->Cin, g->Cout, ho, wo)
-                               : plan_wgrad<3>(g->N, g->Cin, g->Cout, ho, wo);
+  if ((long long)g->Cin * g->Hin * g->Win * 64 >= 0x7fffffffLL && g->Hin * g->Win < 64) return GANLAB_EINVAL;
+  const PatchArgs in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
+  const WgPlan pl = plan_wgrad(in, gy, g->ks, g->Cout, ho, wo);
   const long long nw = (long long)g->Cout * g->Cin * g->ks * g->ks;
   if (!workspace || workspace_bytes < (size_t)pl.slots * nw * sizeof(float)) return GANLAB_EWORKSPACE;
-  WgradArgs a{};
-  a.gy = gy; a.x = x; a.part = (float*)workspace;
-  a.N = g->N; a.Cin = g->Cin; a.Hi = g->Hin; a.Wi = g->Win;
-  a.Hv = g->up ? 2 * g->Hin : g->Hin; a.Wv = g->up ? 2 * g->Win : g->Win;
-  a.Cout = g->Cout; a.Ho = ho; a.Wo = wo; a.pad = g->pad; a.up = g->up;
-  hipStream_t st = gl_stream(stream);
-  const int rc = g->ks == 1 ? run_wgrad_ks<1>(a, pl, st) : run_wgrad_ks<3>(a, pl, st);
+  LaunchFn f{};
+  f.a.in = in; f.a.gy = gy; f.a.part = (float*)workspace;
+  f.a.Cout = g->Cout; f.a.Ho = ho; f.a.Wo = wo;
+  f.pl = &pl; f.st = gl_stream(stream);
+  const int rc = g->ks == 1 ? wg_select<1>(pl, f) : wg_select<3>(pl, f);
   if (rc != GANLAB_OK) return rc;
-  GL_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st,
-                     (const float*)workspace, gw, nw, pl.slots, scale);
+  GL_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, f.st,
+            (const float*)workspace, gw, nw, pl.slots, scale);
   return GL_CHECK_LAUNCH();
 }
 
