@@ -45,6 +45,7 @@ SIGNATURES = {
     'ganlab_pool2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_bias_act_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_act_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_f, _c_p]),
+    'ganlab_act_bwd_bias_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_channel_sum_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_channel_sum_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
     'ganlab_instnorm_stats_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_f, _c_p]),

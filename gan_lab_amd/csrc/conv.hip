@@ -528,13 +528,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
       }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, long long n,
-                                    int slots, float scale) {
+// Deterministic slot reduction.  grid = (ceil(n/256), groups): block (bx, g) sums slots
+// g, g+groups, ... of outputs [256*bx, 256*bx+256) into out[g][.]; with groups == 1 the result is
+// final (scaled), otherwise a second launch with slots = groups finishes it.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n,
+                                    int slots, int groups, float scale) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < slots; ++k) s += part[(long long)k * n + i];
-  gw[i] = s * scale;
+  const int g = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = g;
+  for (; k + 3 * groups < slots; k += 4 * groups) {
+    s0 += part[(long long)k * n + i];
+    s1 += part[(long long)(k + groups) * n + i];
+    s2 += part[(long long)(k + 2 * groups) * n + i];
+    s3 += part[(long long)(k + 3 * groups) * n + i];
+  }
+  for (; k < slots; k += groups) s0 += part[(long long)k * n + i];
+  out[(long long)g * n + i] = ((s0 + s1) + (s2 + s3)) * scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,7 +792,7 @@ size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g) {
   if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK) return 0;
   const PatchArgs in = make_patch(nullptr, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
   const WgPlan pl = plan_wgrad(in, nullptr, g->ks, g->Cout, ho, wo);
-  return (size_t)pl.slots * g->Cout * g->Cin * g->ks * g->ks * sizeof(float);
+  return (size_t)(pl.slots + 32) * g->Cout * g->Cin * g->ks * g->ks * sizeof(float);
 }
 
 int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
@@ -792,15 +803,25 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   const PatchArgs in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
   const WgPlan pl = plan_wgrad(in, gy, g->ks, g->Cout, ho, wo);
   const long long nw = (long long)g->Cout * g->Cin * g->ks * g->ks;
-  if (!workspace || workspace_bytes < (size_t)pl.slots * nw * sizeof(float)) return GANLAB_EWORKSPACE;
+  if (!workspace || workspace_bytes < (size_t)(pl.slots + 32) * nw * sizeof(float)) return GANLAB_EWORKSPACE;
   LaunchFn f{};
   f.a.in = in; f.a.gy = gy; f.a.part = (float*)workspace;
   f.a.Cout = g->Cout; f.a.Ho = ho; f.a.Wo = wo;
   f.pl = &pl; f.st = gl_stream(stream);
   const int rc = g->ks == 1 ? wg_select<1>(pl, f) : wg_select<3>(pl, f);
   if (rc != GANLAB_OK) return rc;
-  GL_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, f.st,
-            (const float*)workspace, gw, nw, pl.slots, scale);
+  // two-stage when there are many slots and few outputs (thin layers: 4096 slots x 2304 weights)
+  const unsigned nblk = (unsigned)((nw + 255) / 256);
+  const int groups = pl.slots >= 64 ? 32 : 1;
+  float* ws = (float*)workspace;
+  if (groups == 1) {
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, f.st, (const float*)ws, gw, nw, pl.slots, 1, scale);
+  } else {
+    float* stage2 = ws + (long long)pl.slots * nw;
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk, groups), dim3(256), 0, f.st, (const float*)ws, stage2, nw, pl.slots,
+              groups, 1.0f);
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, f.st, (const float*)stage2, gw, nw, groups, 1, scale);
+  }
   return GL_CHECK_LAUNCH();
 }
 

@@ -155,6 +155,43 @@ __global__ void channel_sum_stage2(const float* __restrict__ part, float* __rest
   if (threadIdx.x == 0) out[c] = s * scale;
 }
 
+// gz = gy * lrelu'(y) AND the per-channel sums of gz (bias gradient) in one pass:
+// grid (chunks, C); partial sums go to part[c][chunk], channel_sum_stage2 finishes them.
+__global__ __launch_bounds__(256) void act_bwd_bias_stage1(const float* __restrict__ gy, const float* __restrict__ y,
+                                                           float* __restrict__ gz, float* __restrict__ part, int N,
+                                                           int C, long long HW, int chunks, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.y, chunk = blockIdx.x;
+  float s = 0.f;
+  if ((HW & 3) == 0) {
+    const long long hw4 = HW >> 2, total = (long long)N * hw4;
+    for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
+      const long long n = i / hw4, q = i - n * hw4;
+      const long long off = ((n * C + c) * hw4 + q);
+      const float4 g = reinterpret_cast<const float4*>(gy)[off];
+      const float4 o = reinterpret_cast<const float4*>(y)[off];
+      float4 r;
+      r.x = o.x > 0.f ? g.x : g.x * slope;
+      r.y = o.y > 0.f ? g.y : g.y * slope;
+      r.z = o.z > 0.f ? g.z : g.z * slope;
+      r.w = o.w > 0.f ? g.w : g.w * slope;
+      reinterpret_cast<float4*>(gz)[off] = r;
+      s += (r.x + r.y) + (r.z + r.w);
+    }
+  } else {
+    const long long total = (long long)N * HW;
+    for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
+      const long long n = i / HW, hw = i - n * HW;
+      const long long off = (n * C + c) * HW + hw;
+      const float r = y[off] > 0.f ? gy[off] : gy[off] * slope;
+      gz[off] = r;
+      s += r;
+    }
+  }
+  s = gl_block_sum_256(s, red);
+  if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s;
+}
+
 inline int channel_chunks(int N, long long HW) {
   long long c = ((long long)N * HW + 256 * 32 - 1) / (256 * 32);
   if (c < 1) c = 1;
@@ -685,6 +722,17 @@ int ganlab_channel_sum_f32(const float* a, const float* b, float* out, int N, in
   GL_LAUNCH(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (float*)workspace, N, C, HW,
                      chunks);
   GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, out, C, chunks, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_act_bwd_bias_f32(const float* gy, const float* y, float* gz, float* gb, int N, int C, long long HW,
+                            float slope, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gy || !y || !gz || !gb || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  const int chunks = channel_chunks(N, HW);
+  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return GANLAB_EWORKSPACE;
+  GL_LAUNCH(act_bwd_bias_stage1, dim3(chunks, C), dim3(256), 0, ST, gy, y, gz, (float*)workspace, N, C, HW, chunks,
+            slope);
+  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, scale);
   return GL_CHECK_LAUNCH();
 }
 

@@ -105,6 +105,28 @@ def _packed(w, mode, scale):
     return out
 
 
+# ---- "input gradient only" mode ---------------------------------------------------------------------
+# torch.autograd.grad(D(x), x, create_graph=True) (the gradient-penalty pass) only needs d/dx, but a
+# Python autograd.Function cannot see which of its outputs the engine will keep: without this flag
+# every conv would also run its weight-gradient kernel there and throw the result away.  The flag is
+# a module global (the autograd engine runs backward on its own device thread).
+_INPUT_GRAD_ONLY = [False]
+
+
+class input_grad_only(object):
+    def __enter__(self):
+        self._prev = _INPUT_GRAD_ONLY[0]
+        _INPUT_GRAD_ONLY[0] = True
+
+    def __exit__(self, *exc):
+        _INPUT_GRAD_ONLY[0] = self._prev
+        return False
+
+
+def _want_param_grads():
+    return not _INPUT_GRAD_ONLY[0]
+
+
 # ---------------------------------------------------------------------------------------------- #
 # kernel launchers
 # ---------------------------------------------------------------------------------------------- #
@@ -203,6 +225,18 @@ def k_act_bwd(gy, y, slope):
     return gz
 
 
+def k_act_bwd_bias(gy, y, slope, scale):
+    gy, y = _c(gy), _c(y)
+    assert gy.shape == y.shape
+    n, c, hw = _nchw(gy)
+    L = _lib.lib()
+    ws = torch.empty((L.ganlab_channel_sum_workspace(n, c, hw) + 3) // 4, dtype=torch.float32, device=gy.device)
+    gz, gb = torch.empty_like(gy), _new((c,), gy)
+    check(L.ganlab_act_bwd_bias_f32(_p(gy), _p(y), _p(gz), _p(gb), n, c, hw, slope, scale, _p(ws), ws.numel() * 4,
+                                    _st()), 'act_bwd_bias')
+    return gz, gb
+
+
 def k_channel_sum(a, b=None, scale=1.0):
     a = _c(a)
     n, c, hw = _nchw(a)
@@ -282,7 +316,7 @@ class _ConvFwd(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and _want_param_grads()) else None
         return gx, gw, None, None
 
 
@@ -331,6 +365,28 @@ class _ActBwd(Function):
         return _ActBwd.apply(gg, y, ctx.slope), None, None
 
 
+class _ActBwdBias(Function):
+    """(gz, gb) = (gy * lrelu'(y), bias_scale * sum_{n,hw} gz) in one pass over the tensors."""
+
+    @staticmethod
+    def forward(ctx, gy, y, slope, bias_scale):
+        ctx.save_for_backward(y)
+        ctx.slope, ctx.bias_scale = slope, bias_scale
+        gz, gb = k_act_bwd_bias(gy, y, slope, bias_scale)
+        return gz, gb
+
+    @staticmethod
+    def backward(ctx, ggz, ggb):
+        y, = ctx.saved_tensors
+        g = ggz
+        if ggb is not None:
+            shape = y.shape
+            view = [1, shape[1]] + [1] * (len(shape) - 2)
+            b = _Scale.apply(ggb.view(view).expand(shape), ctx.bias_scale)
+            g = b if g is None else _Axpby.apply(g, b, 1.0, 1.0)
+        return (_ActBwd.apply(g, y, ctx.slope) if g is not None else None), None, None, None
+
+
 class _ChanSum(Function):
     """(N,C,...) -> (C,) sum, optionally weighted by a (N,1,...) map (noise-weight gradient)."""
 
@@ -364,13 +420,18 @@ class _ConvBiasAct(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
-        gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        params = _want_param_grads()
+        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[2] and params
         gb = None
-        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
-            gb = _ChanSum.apply(gz, None, ctx.bias_scale).view(ctx.bias_shape)
-        return gx, gw, gb, None, None, None, None, None
+        if ctx.act != ACT_NONE and want_b:
+            gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
+        else:
+            gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+            if want_b:
+                gb = _ChanSum.apply(gz, None, ctx.bias_scale)
+        gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and params) else None
+        return gx, gw, (gb.view(ctx.bias_shape) if gb is not None else None), None, None, None, None, None
 
 
 class _BiasAct(Function):
@@ -389,13 +450,19 @@ class _BiasAct(Function):
     @staticmethod
     def backward(ctx, gy):
         y, noise = ctx.saved_tensors
-        gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+        params = _want_param_grads()
+        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
         gb = gnw = None
-        if ctx.bias_shape is not None and ctx.needs_input_grad[1]:
-            gb = _ChanSum.apply(gz, None, ctx.bias_scale).view(ctx.bias_shape)
-        if ctx.nw_shape is not None and ctx.needs_input_grad[3]:
+        if ctx.act != ACT_NONE and want_b:
+            gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
+        else:
+            gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+            if want_b:
+                gb = _ChanSum.apply(gz, None, ctx.bias_scale)
+        if ctx.nw_shape is not None and ctx.needs_input_grad[3] and params:
             gnw = _ChanSum.apply(gz, noise, 1.0).view(ctx.nw_shape)
-        return (gz if ctx.needs_input_grad[0] else None), gb, None, gnw, None, None, None
+        return (gz if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if gb is not None else None), \
+            None, gnw, None, None, None
 
 
 class _Blur(Function):

@@ -97,8 +97,9 @@ def gp_from_output(outb, xb, gp_type, lda=10., gamma=1.):
     forward twice, progan/learner.py:789 and resnetgan/learner.py:809)."""
     gp_type = gp_type.casefold()
     ones = torch.ones(outb.shape[0], device=outb.device)
-    outb_grads = torch.autograd.grad(outb, xb, grad_outputs=ones, create_graph=True, retain_graph=True,
-                                     only_inputs=True)[0]
+    with ops.input_grad_only():      # only d/dx is wanted here: skip every weight / bias gradient kernel
+        outb_grads = torch.autograd.grad(outb, xb, grad_outputs=ones, create_graph=True, retain_graph=True,
+                                         only_inputs=True)[0]
     n_pix = outb_grads.numel() // outb_grads.shape[1]          # B*H*W
     if gp_type == 'wgan-gp':
         if gamma != 1.:

@@ -93,6 +93,10 @@ int ganlab_bias_act_f32(const float* x, const float* bias, const float* noise, c
                         void* stream);
 /* gz = gy * (y > 0 ? 1 : slope)   (LeakyReLU backward from the saved OUTPUT) */
 int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, float slope, void* stream);
+/* gz = gy * (y > 0 ? 1 : slope) and gb[c] = scale * sum_{n,hw} gz[n,c,hw] in ONE pass (the backward of
+ * Conv2dBias + LeakyReLU, custom_layers.py:222-226); workspace as ganlab_channel_sum_workspace */
+int ganlab_act_bwd_bias_f32(const float* gy, const float* y, float* gz, float* gb, int N, int C, long long HW,
+                            float slope, float scale, void* workspace, size_t workspace_bytes, void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);
