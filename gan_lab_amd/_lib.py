@@ -26,7 +26,7 @@ PACK_FWD, PACK_DGRAD = 0, 1
 class ConvGeom(ctypes.Structure):
     """Mirror of `ganlab_conv_geom` (include/ganlab_hip.h)."""
     _fields_ = [('N', _c_int), ('Cin', _c_int), ('Hin', _c_int), ('Win', _c_int),
-                ('Cout', _c_int), ('ks', _c_int), ('pad', _c_int), ('up', _c_int)]
+                ('Cout', _c_int), ('ks', _c_int), ('pad', _c_int), ('up', _c_int), ('pool', _c_int)]
 
 
 _GP = ctypes.POINTER(ConvGeom)
@@ -40,6 +40,12 @@ SIGNATURES = {
     'ganlab_conv_dgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
     'ganlab_conv_wgrad_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_s2_supported': (_c_int, [_GP]),
+    'ganlab_conv_s2_pack_f32': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_conv_s2_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_s2_dgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_s2_wgrad_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_s2_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_blur3x3_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_p]),
     'ganlab_up2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_pool2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),

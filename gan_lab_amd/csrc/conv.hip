@@ -737,7 +737,8 @@ WgPlan plan_wgrad(const PatchArgs& in, const float* gy, int ks, int Cout, int Ho
 
 bool geom_ok(const ganlab_conv_geom* g) {
   return g && g->N > 0 && g->Cin > 0 && g->Hin > 0 && g->Win > 0 && g->Cout > 0 &&
-         (g->ks == 1 || g->ks == 3) && g->pad >= 0 && g->pad < g->ks && (g->up == 0 || g->up == 1);
+         (g->ks == 1 || g->ks == 3) && g->pad >= 0 && g->pad < g->ks && (g->up == 0 || g->up == 1) &&
+         g->pool == 0;
 }
 
 }  // namespace

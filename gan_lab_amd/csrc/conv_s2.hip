@@ -1,0 +1,771 @@
+// Stride-2 fused convolutions on the fp32 MFMA (v_mfma_f32_16x16x4_f32), NCHW.
+//
+// Two layer patterns of the reference carry 2/3 of all conv FLOPs of the G+D step:
+//   D "down" layer : AvgPool2d(2)( conv3x3(x, W, pad 1) )            progan/architectures.py:261-284
+//   G "up"   layer : conv3x3( Upsample(2x nearest)(x), W, pad 1 )    stylegan/architectures.py:292-334
+// Both are linear maps that collapse EXACTLY to a 4x4 stride-2 kernel K4 = M (x) M applied to W
+// (M = 4x3 combination matrix, below):
+//   down:  y[Y,X]          = sum_{a,b<4} K4d[a][b] * xpad[2Y+a-1, 2X+b-1]          ("S": strided conv)
+//   up  :  y[2Y+py,2X+px]  = sum_{Y',X'} K4u[2(Y-Y')+py+1][2(X-X')+px+1] * x[Y',X'] ("T": its transpose)
+// which needs 16 MACs per (ci,co) per low-res pixel instead of 36 (9 taps at 4 high-res pixels):
+// 2.25x fewer matrix-core FLOPs, no full-resolution intermediate, and the pool / upsample kernels
+// disappear.  The three derivatives of each pattern are again S / T / a 16-tap weight gradient "W":
+//   down: fwd = S(K4d), dgrad = T(K4d), wgrad = W(low = gy, high = x)
+//   up  : fwd = T(K4u), dgrad = S(K4u), wgrad = W(low = x, high = gy)   (then gw = M^T gK4 M)
+// Results differ from the reference only by fp32 re-association (weights are pre-summed).
+//
+// S stages the high-res patch into LDS split by pixel parity (space-to-depth on the fly) so that the
+// MFMA B-operand reads are stride-1; T keeps 4 output-phase accumulators per low-res pixel and stores
+// float2 {px=0, px=1} pairs (128-byte coalesced rows); all staging is 16-byte vectorised with the
+// next K-chunk prefetched into registers during the MFMA phase (same scheme as conv.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int ceil_div_c(int a, int b) { return (a + b - 1) / b; }
+constexpr int pad_mod32(int v, int r) { return v + ((r - (v % 32)) + 32) % 32; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// tap a in 0..3 of the stride-2 kernel reads high row 2Y + a - 1 = 2(Y + DY[a]) + PY[a]
+__device__ __constant__ const int kDY[4] = {-1, 0, 0, 1};
+__device__ __constant__ const int kPY[4] = {1, 0, 1, 0};
+constexpr int cDY(int a) { return a == 0 ? -1 : (a == 3 ? 1 : 0); }
+constexpr int cPY(int a) { return (a == 0 || a == 2) ? 1 : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// pack: OIHW 3x3 -> K4 packed [16 taps][rows_p][cols_p];  K4[a][b] = scale * sum M[a][ky] M[b][kx] w[ky][kx]
+//   down: M = 0.25-normalised {D0={0}, D1={0,1}, D2={1,2}, D3={2}}   (0.25 overall -> 0.5 per dim)
+//   up  : M = {U0={2}, U1={1,2}, U2={0,1}, U3={0}}
+//   transpose = 1: rows = co, cols = ci (the operator consumes gy)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float comb(int up, int a, int k) {
+  if (up) {
+    const int lo = (a == 0) ? 2 : (a == 1 ? 1 : 0), hi = (a == 0) ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 0));
+    return (k >= lo && k <= hi) ? 1.f : 0.f;
+  }
+  const int lo = (a <= 1) ? 0 : (a == 2 ? 1 : 2), hi = (a == 0) ? 0 : (a == 1 ? 1 : 2);
+  return (k >= lo && k <= hi) ? 0.5f : 0.f;
+}
+
+__global__ void pack_s2_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int rows,
+                               int cols, int rows_p, int cols_p, int up, int transpose, float scale) {
+  const long long total = 16LL * rows_p * cols_p;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % cols_p);
+    const long long t = e / cols_p;
+    const int row = (int)(t % rows_p), tap = (int)(t / rows_p);
+    float v = 0.f;
+    if (row < rows && col < cols) {
+      const int co = transpose ? row : col, ci = transpose ? col : row;
+      const int a = tap >> 2, b = tap & 3;
+      const float* ws = w + ((long long)co * Cin + ci) * 9;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v += comb(up, a, ky) * comb(up, b, kx) * ws[ky * 3 + kx];
+      v *= scale;
+    }
+    out[e] = v;
+  }
+}
+
+// ================================================================================================
+// S : strided 4x4 conv.  in: high-res (N, Cin, H, W) ; out: low-res (N, Cout, H/2, W/2)
+//   tile = 32x8 low-res pixels x CO_T channels; LDS X = [4 parities][CI_T][PL] (parity planes of the
+//   high-res patch, (TH+2) x (TW+4) low-res positions each), W = [16 taps][CI_T][COP]
+// ================================================================================================
+struct S2Args {
+  const float* x;     // S: high-res input ; T: low-res input
+  const float* wp;    // [16][Cin_p][Cout_p]
+  const float* bias;
+  float* y;
+  int N, Cin, Cout;
+  int Hl, Wl;         // LOW resolution (high = 2x)
+  int Cin_p, Cout_p;
+  int tiles_x, tiles_y, tiles_co;
+  float bias_scale, slope;
+  int act;
+};
+
+template <int MB_>
+struct SCfg {
+  static constexpr int MB = MB_, NB = 4, TW = 32, TH = 8, TWL = 5;
+  static constexpr int CO_T = 16 * MB_;
+  static constexpr int CI_T = MB_ == 4 ? 4 : 8;
+  static constexpr int RPL = TW + 4, RL = TH + 2;             // parity-plane geometry (low-res units)
+  static constexpr int PL = pad_mod32(RL * RPL, 16);
+  static constexpr int HROWS = 2 * RL, HROW4 = (2 * TW + 8) / 4;   // high-res rows / float4 per row
+  static constexpr int COP = pad_mod32(CO_T, 16);
+  static constexpr int XS = 4 * CI_T * PL, WS = 16 * CI_T * COP;
+  static constexpr int NXI = CI_T * HROWS * HROW4, XPT = ceil_div_c(NXI, 256);
+  static constexpr int NWI = 16 * CI_T * CO_T / 4, WPT = ceil_div_c(NWI, 256);
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
+  constexpr int MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T, PL = Cfg::PL, RPL = Cfg::RPL, COP = Cfg::COP;
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  float* Xs = smem;
+  float* Ws = smem + Cfg::XS;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_t = bid % p.tiles_co;
+  bid /= p.tiles_co;
+  const int txi = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int tyi = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = co_t * CO_T, ox0 = txi * TW, oy0 = tyi * TH;
+  const int H = 2 * p.Hl, W = 2 * p.Wl, plane = H * W;
+  const float* xb = p.x + (long long)n * p.Cin * plane;
+
+  // staging descriptors: item = one high-res float4
+  int xg[XPT], xl[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % Cfg::HROW4;
+    const int t = e / Cfg::HROW4;
+    const int hr = t % Cfg::HROWS, ci = t / Cfg::HROWS;
+    const int gy_ = 2 * oy0 - 2 + hr, gx_ = 2 * ox0 - 4 + 4 * q;
+    const int ly = hr >> 1, py = hr & 1;
+    xl[i] = ((py * 2) * CI_T + ci) * PL + ly * RPL + 2 * q;  // px = 0 plane; px = 1 plane is CI_T*PL further
+    xl[i] |= ci << 20;
+    xg[i] = (e < Cfg::NXI && (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W)
+                ? ci * plane + gy_ * W + gx_ : -1;
+    if (e >= Cfg::NXI) xl[i] = -1;
+  }
+  int wg[WPT], wl[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int c4 = e % (CO_T / 4);
+    const int t = e / (CO_T / 4);
+    const int ci = t % CI_T, tap = t / CI_T;
+    wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
+    wg[i] = e < Cfg::NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
+  }
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
+    boff[nb] = (ty + 1) * RPL + tx + 2 + (lane >> 4) * PL;
+  }
+  const int aoff = (lane >> 4) * COP + (lane & 15);
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 xr[XPT], wr[WPT];
+  auto load = [&](int ci0) {
+    const float* src = xb + (long long)ci0 * plane;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int ci = (xl[i] >> 20) & 0x3ff;
+      xr[i] = (xg[i] >= 0 && ci0 + ci < p.Cin) ? *reinterpret_cast<const float4*>(src + xg[i])
+                                                 : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+                         : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  load(0);
+  for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      if (xl[i] != -1) {
+        const int l = xl[i] & 0xfffff;
+        *reinterpret_cast<float2*>(Xs + l) = float2{xr[i].x, xr[i].z};              // px = 0
+        *reinterpret_cast<float2*>(Xs + l + CI_T * PL) = float2{xr[i].y, xr[i].w};  // px = 1
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
+    __syncthreads();
+    if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);
+#pragma unroll 1
+    for (int a = 0; a < 4; ++a) {
+      const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
+      const float* wrow = Ws + a * (4 * CI_T * COP) + aoff;
+      const float* xrow = Xs + (py * 2) * CI_T * PL + dy * RPL;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int dx = cDY(b), px = cPY(b);
+#pragma unroll
+        for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+          float av[MB], bv[NB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) av[mb] = wrow[(b * CI_T + c4 * 4) * COP + mb * 16];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bv[nb] = xrow[(px * CI_T + c4 * 4) * PL + boff[nb] + dx];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue (low-res): + bias, activation
+  const long long oplane = (long long)p.Hl * p.Wl;
+  float bvv[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+      bvv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+    }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int oy = oy0 + (j >> Cfg::TWL), ox = ox0 + (j & (TW - 1));
+    if (oy >= p.Hl || ox >= p.Wl) continue;
+    float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * oplane + (long long)oy * p.Wl + ox;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Cout) {
+          float v = acc[mb][nb][r] + bvv[mb][r];
+          if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+          dst[(long long)(mb * 16 + r) * oplane] = v;
+        }
+      }
+  }
+}
+
+// ================================================================================================
+// T : transposed stride-2 4x4 conv.  in: low-res (N, Cin, Hl, Wl) ; out: high-res (N, Cout, 2Hl, 2Wl)
+//   out[2Y+py, 2X+px] = sum_{(dy,a) in taps(py)} sum_{(dx,b) in taps(px)} K4[a][b] * x[Y+dy, X+dx]
+//   taps(0) = {(-1,3), (0,1)}   taps(1) = {(0,2), (+1,0)}
+//   tile = TWl x THl low-res pixels (NBL blocks of 16 per wave), 4 phase accumulators per block
+// ================================================================================================
+template <int MB_, int NBL_>
+struct TCfg {
+  static constexpr int MB = MB_, NBL = NBL_;
+  static constexpr int TW = NBL_ == 4 ? 32 : 16, TH = NBL_ == 1 ? 4 : 8, TWL = NBL_ == 4 ? 5 : 4;
+  static constexpr int CO_T = 16 * MB_;
+  static constexpr int CI_T = MB_ == 4 ? 8 : 16;
+  static constexpr int RP = TW + 8, R = TH + 2;
+  static constexpr int PLANE = pad_mod32(R * RP, 16);
+  static constexpr int ROW4 = RP / 4;
+  static constexpr int COP = pad_mod32(CO_T, 16);
+  static constexpr int XS = CI_T * PLANE, WS = 16 * CI_T * COP;
+  static constexpr int NXI = CI_T * R * ROW4, XPT = ceil_div_c(NXI, 256);
+  static constexpr int NWI = 16 * CI_T * CO_T / 4, WPT = ceil_div_c(NWI, 256);
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void conv_s2_up_kernel(S2Args p) {
+  constexpr int MB = Cfg::MB, NBL = Cfg::NBL, CI_T = Cfg::CI_T, PLANE = Cfg::PLANE, RP = Cfg::RP, COP = Cfg::COP;
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  float* Xs = smem;
+  float* Ws = smem + Cfg::XS;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_t = bid % p.tiles_co;
+  bid /= p.tiles_co;
+  const int txi = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int tyi = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int co0 = co_t * CO_T, ox0 = txi * TW, oy0 = tyi * TH;
+  const int plane = p.Hl * p.Wl;
+  const float* xb = p.x + (long long)n * p.Cin * plane;
+
+  int xg[XPT], xl[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % Cfg::ROW4;
+    const int t = e / Cfg::ROW4;
+    const int r = t % Cfg::R, ci = t / Cfg::R;
+    const int gy_ = oy0 - 1 + r, gx_ = ox0 - 4 + 4 * q;
+    xl[i] = (ci * PLANE + r * RP + 4 * q) | (ci << 20);
+    xg[i] = (e < Cfg::NXI && (unsigned)gy_ < (unsigned)p.Hl && (unsigned)gx_ < (unsigned)p.Wl)
+                ? ci * plane + gy_ * p.Wl + gx_ : -1;
+    if (e >= Cfg::NXI) xl[i] = -1;
+  }
+  int wg[WPT], wl[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int c4 = e % (CO_T / 4);
+    const int t = e / (CO_T / 4);
+    const int ci = t % CI_T, tap = t / CI_T;
+    wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
+    wg[i] = e < Cfg::NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
+  }
+  int boff[NBL];
+#pragma unroll
+  for (int nb = 0; nb < NBL; ++nb) {
+    const int j = wn * (16 * NBL) + nb * 16 + (lane & 15);
+    const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
+    boff[nb] = (ty + 1) * RP + tx + 4 + (lane >> 4) * PLANE;
+  }
+  const int aoff = (lane >> 4) * COP + (lane & 15);
+
+  f32x4 acc[4][MB][NBL];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 xr[XPT], wr[WPT];
+  auto load = [&](int ci0) {
+    const float* src = xb + (long long)ci0 * plane;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int ci = (xl[i] >> 20) & 0x3ff;
+      xr[i] = (xg[i] >= 0 && ci0 + ci < p.Cin) ? *reinterpret_cast<const float4*>(src + xg[i])
+                                                 : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+                         : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  load(0);
+  for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < XPT; ++i)
+      if (xl[i] != -1) *reinterpret_cast<float4*>(Xs + (xl[i] & 0xfffff)) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
+    __syncthreads();
+    if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);
+    // K-steps of 4 channels are a real loop (bounds register pressure); the 16 (phase, tap) combinations
+    // inside are unrolled with immediate LDS offsets and static accumulator indices
+#pragma unroll 1
+    for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+      const float* wc = Ws + c4 * 4 * COP + aoff;
+      const float* xc = Xs + c4 * 4 * PLANE;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+#pragma unroll
+          for (int iy = 0; iy < 2; ++iy) {
+            // taps(0) = {(-1,3), (0,1)} ; taps(1) = {(0,2), (+1,0)}
+            const int dy = py == 0 ? (iy == 0 ? -1 : 0) : (iy == 0 ? 0 : 1);
+            const int a = py == 0 ? (iy == 0 ? 3 : 1) : (iy == 0 ? 2 : 0);
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+              const int dx = px == 0 ? (ix == 0 ? -1 : 0) : (ix == 0 ? 0 : 1);
+              const int b = px == 0 ? (ix == 0 ? 3 : 1) : (ix == 0 ? 2 : 0);
+              float av[MB], bv[NBL];
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb) av[mb] = wc[((a * 4 + b) * CI_T) * COP + mb * 16];
+#pragma unroll
+              for (int nb = 0; nb < NBL; ++nb) bv[nb] = xc[boff[nb] + dy * RP + dx];
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NBL; ++nb)
+                  acc[py * 2 + px][mb][nb] =
+                      __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[py * 2 + px][mb][nb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // epilogue (high-res): lane holds px = 0 and px = 1 of its low-res pixel -> float2 stores
+  const int Wo = 2 * p.Wl;
+  const long long oplane = 4LL * p.Hl * p.Wl;
+  float bvv[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+      bvv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+    }
+#pragma unroll
+  for (int nb = 0; nb < NBL; ++nb) {
+    const int j = wn * (16 * NBL) + nb * 16 + (lane & 15);
+    const int Y = oy0 + (j >> Cfg::TWL), X = ox0 + (j & (TW - 1));
+    if (Y >= p.Hl || X >= p.Wl) continue;
+    float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * oplane + (long long)(2 * Y) * Wo + 2 * X;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Cout) {
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            float v0 = acc[py * 2 + 0][mb][nb][r] + bvv[mb][r], v1 = acc[py * 2 + 1][mb][nb][r] + bvv[mb][r];
+            if (p.act == GANLAB_ACT_LRELU) { v0 = gl_lrelu(v0, p.slope); v1 = gl_lrelu(v1, p.slope); }
+            *reinterpret_cast<float2*>(dst + (long long)(mb * 16 + r) * oplane + py * Wo) = float2{v0, v1};
+          }
+        }
+      }
+  }
+}
+
+// ================================================================================================
+// W : 16-tap weight gradient.  gK4[tap][cl][ch] = sum_{n,Y,X} low[n,cl,Y,X] * high_pad[n,ch,2Y+a-1,2X+b-1]
+//   A = low tile [cl][px] (16 channels per workgroup), B = parity planes of the high patch
+//   [4 parities][16 ch][PL]; the 4 waves split the tile's 4-pixel K-steps; accumulators 16 taps x f32x4.
+//   Each workgroup walks tiles split, split+S, ... and dumps to its slot; reduce_s2_kernel sums the
+//   slots and folds K4 back to 3x3:  gw[ky][kx] = scale * sum_{a,b} M[a][ky] M[b][kx] gK4[a][b].
+// ================================================================================================
+struct W2Args {
+  const float* low;
+  const float* high;
+  float* part;  // [slots][16][Cl][Ch]
+  int N, Cl, Ch, Hl, Wl;
+  int tiles_x, tiles_y, tiles_cl, tiles_ch, S;
+};
+
+template <int NBA_>
+struct WCfg {
+  static constexpr int NBA = NBA_, CL_T = 16 * NBA_;
+  static constexpr int TW = 16, TH = 4, TWL = 4, PX_T = 64;
+  static constexpr int RPL = TW + 4, RL = TH + 2;
+  static constexpr int PL = pad_mod32(RL * RPL, 2);
+  static constexpr int HROWS = 2 * RL, HROW4 = (2 * TW + 8) / 4;
+  static constexpr int GP = pad_mod32(PX_T, 2);
+  static constexpr int GS = CL_T * GP, XS = 4 * 16 * PL;
+  static constexpr int NXI = 16 * HROWS * HROW4, XPT = ceil_div_c(NXI, 256);
+  static constexpr int NGI = CL_T * PX_T / 4, GPT = ceil_div_c(NGI, 256);
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void conv_s2_wgrad_kernel(W2Args p) {
+  constexpr int NBA = Cfg::NBA;
+  constexpr int PL = Cfg::PL, RPL = Cfg::RPL, GP = Cfg::GP, TW = Cfg::TW, TH = Cfg::TH, XPT = Cfg::XPT,
+                GPT = Cfg::GPT, PX_T = Cfg::PX_T;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::GS + Cfg::XS];
+  float* Gs = smem;
+  float* Xs = smem + Cfg::GS;
+  const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+  int bid = blockIdx.x;
+  const int split = bid % p.S;
+  bid /= p.S;
+  const int ch_t = bid % p.tiles_ch;
+  const int cl_t = bid / p.tiles_ch;
+  const int cl0 = cl_t * Cfg::CL_T, ch0 = ch_t * 16;
+  const int H = 2 * p.Hl, W = 2 * p.Wl, hplane = H * W, lplane = p.Hl * p.Wl;
+
+  f32x4 acc[16][NBA];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // tile-independent descriptor parts
+  int xrel[XPT], xl[XPT];   // (hr, q) packed ; LDS offset | ch<<20
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % Cfg::HROW4;
+    const int t = e / Cfg::HROW4;
+    const int hr = t % Cfg::HROWS, ch = t / Cfg::HROWS;
+    const int ly = hr >> 1, py = hr & 1;
+    xl[i] = e < Cfg::NXI ? ((((py * 2) * 16 + ch) * PL + ly * RPL + 2 * q) | (ch << 20)) : -1;
+    xrel[i] = (hr << 8) | q;
+  }
+  int gl_[GPT], gj[GPT], gc[GPT];
+#pragma unroll
+  for (int i = 0; i < GPT; ++i) {
+    const int e = tid + i * 256;
+    const int j = (e % (PX_T / 4)) * 4, c = e / (PX_T / 4);
+    gj[i] = e < Cfg::NGI ? j : -1;
+    gc[i] = c;
+    gl_[i] = c * GP + j;
+  }
+  float4 xr[XPT], gr[GPT];
+  const int tiles_img = p.tiles_x * p.tiles_y, n_tiles = p.N * tiles_img;
+  auto load_tile = [&](int tile) {
+    const int n = tile / tiles_img, t2 = tile % tiles_img;
+    const int tyi = t2 / p.tiles_x, txi = t2 % p.tiles_x;
+    const int ox0 = txi * TW, oy0 = tyi * TH;
+    const float* hb = p.high + ((long long)n * p.Ch + ch0) * hplane;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int hr = xrel[i] >> 8, q = xrel[i] & 0xff;
+      const int ch = (xl[i] >> 20) & 0x3ff;
+      const int gy_ = 2 * oy0 - 2 + hr, gx_ = 2 * ox0 - 4 + 4 * q;
+      const bool ok = xl[i] != -1 && ch0 + ch < p.Ch && (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;
+      xr[i] = ok ? *reinterpret_cast<const float4*>(hb + (long long)ch * hplane + gy_ * W + gx_)
+                 : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* lb = p.low + ((long long)n * p.Cl + cl0) * lplane;
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int j = gj[i];
+      const int oy = oy0 + (j >> Cfg::TWL), ox = ox0 + (j & (TW - 1));
+      const bool ok = j >= 0 && cl0 + gc[i] < p.Cl && oy < p.Hl && ox < p.Wl;
+      gr[i] = ok ? *reinterpret_cast<const float4*>(lb + (long long)gc[i] * lplane + oy * p.Wl + ox)
+                 : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int tile = split;
+  if (tile < n_tiles) load_tile(tile);
+  while (tile < n_tiles) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      if (xl[i] != -1) {
+        const int l = xl[i] & 0xfffff;
+        *reinterpret_cast<float2*>(Xs + l) = float2{xr[i].x, xr[i].z};
+        *reinterpret_cast<float2*>(Xs + l + 16 * PL) = float2{xr[i].y, xr[i].w};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      if (gj[i] >= 0) {
+        *reinterpret_cast<float2*>(Gs + gl_[i]) = float2{gr[i].x, gr[i].y};
+        *reinterpret_cast<float2*>(Gs + gl_[i] + 2) = float2{gr[i].z, gr[i].w};
+      }
+    }
+    __syncthreads();
+    const int next = tile + p.S;
+    if (next < n_tiles) load_tile(next);
+    for (int q = wk; q < PX_T / 4; q += 4) {
+      const int j = 4 * q + (lane >> 4);
+      const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
+      const int poff = (ty + 1) * RPL + tx + 2 + (lane & 15) * PL;
+      float av[NBA];
+#pragma unroll
+      for (int m = 0; m < NBA; ++m) av[m] = Gs[(m * 16 + (lane & 15)) * GP + j];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float bv = Xs[((cPY(a) * 2 + cPY(b)) * 16) * PL + poff + cDY(a) * RPL + cDY(b)];
+#pragma unroll
+          for (int m = 0; m < NBA; ++m)
+            acc[a * 4 + b][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[a * 4 + b][m], 0, 0, 0);
+        }
+      }
+    }
+    tile = next;
+  }
+  // dump: D rows = cl (lane>>4)*4+r, col = ch (lane&15)
+  const int slot = split * 4 + wk;
+  float* dst = p.part + (long long)slot * 16 * p.Cl * p.Ch;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = cl0 + m * 16 + (lane >> 4) * 4 + r, ch = ch0 + (lane & 15);
+        if (cl < p.Cl && ch < p.Ch) dst[((long long)t * p.Cl + cl) * p.Ch + ch] = acc[t][m][r];
+      }
+}
+
+// stage 1: sum slots (grouped) ; stage 2 (fold = 1): K4 -> 3x3 and write OIHW.
+__global__ void reduce_s2_slots_kernel(const float* __restrict__ part, float* __restrict__ out, long long n,
+                                       int slots, int groups) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  int k = g;
+  for (; k + groups < slots; k += 2 * groups) {
+    s0 += part[(long long)k * n + i];
+    s1 += part[(long long)(k + groups) * n + i];
+  }
+  for (; k < slots; k += groups) s0 += part[(long long)k * n + i];
+  out[(long long)g * n + i] = s0 + s1;
+}
+
+// gw[co][ci][ky][kx] = scale * sum_{a,b} M[a][ky] M[b][kx] * sum_g part[g][a*4+b][cl][ch]
+//   low_is_co = 1: (cl, ch) = (co, ci)  (down layer) ; 0: (cl, ch) = (ci, co)  (up layer)
+__global__ void fold_s2_kernel(const float* __restrict__ part, float* __restrict__ gw, int Cout, int Cin, int Cl,
+                               int Ch, int groups, int up, int low_is_co, float scale) {
+  const long long n = (long long)Cout * Cin;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int co = (int)(i / Cin), ci = (int)(i % Cin);
+  const int cl = low_is_co ? co : ci, ch = low_is_co ? ci : co;
+  float k4[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[((long long)g * 16 + t) * Cl * Ch + (long long)cl * Ch + ch];
+    k4[t] = s;
+  }
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s += comb(up, a, ky) * comb(up, b, kx) * k4[a * 4 + b];
+      gw[i * 9 + ky * 3 + kx] = s * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool s2_ok(const ganlab_conv_geom* g, int* Hl, int* Wl) {
+  if (!g || g->N <= 0 || g->Cin <= 0 || g->Cout <= 0 || g->ks != 3 || g->pad != 1) return false;
+  if ((g->up != 0) == (g->pool != 0)) return false;  // exactly one of them
+  int hl, wl;
+  if (g->up) { hl = g->Hin; wl = g->Win; } else {
+    if ((g->Hin & 1) || (g->Win & 1)) return false;
+    hl = g->Hin / 2; wl = g->Win / 2;
+  }
+  // vector staging: rows of the low tensor must be float4-aligned, and the tiles are 16/32 wide
+  if (hl < 4 || wl < 16 || (wl & 3)) return false;
+  if ((long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * hl * wl * 4 >= 0x7fffffffLL) return false;
+  *Hl = hl; *Wl = wl;
+  return true;
+}
+
+template <class Cfg, class K>
+int launch_s2(K kernel, S2Args a, hipStream_t st) {
+  a.tiles_x = ceil_div(a.Wl, Cfg::TW);
+  a.tiles_y = ceil_div(a.Hl, Cfg::TH);
+  a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
+  const long long grid = (long long)a.tiles_x * a.tiles_y * a.tiles_co * a.N;
+  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  GL_LAUNCH(kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return GL_CHECK_LAUNCH();
+}
+
+int run_S(S2Args a, hipStream_t st) {
+  if (a.Cout <= 16) return launch_s2<SCfg<1>>(conv_s2_down_kernel<SCfg<1>>, a, st);
+  if (a.Cout <= 32) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
+  return launch_s2<SCfg<4>>(conv_s2_down_kernel<SCfg<4>>, a, st);
+}
+
+int run_T(S2Args a, hipStream_t st) {
+  if (a.Cout <= 16) return launch_s2<TCfg<1, 4>>(conv_s2_up_kernel<TCfg<1, 4>>, a, st);
+  if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
+  return launch_s2<TCfg<4, 2>>(conv_s2_up_kernel<TCfg<4, 2>>, a, st);
+}
+
+struct W2Plan { int nba, tiles_x, tiles_y, tiles_cl, tiles_ch, S, slots; };
+W2Plan plan_w2(int N, int Cl, int Ch, int Hl, int Wl) {
+  W2Plan pl{};
+  pl.nba = Cl > 16 ? 2 : 1;
+  pl.tiles_x = ceil_div(Wl, WCfg<1>::TW); pl.tiles_y = ceil_div(Hl, WCfg<1>::TH);
+  pl.tiles_cl = ceil_div(Cl, 16 * pl.nba); pl.tiles_ch = ceil_div(Ch, 16);
+  const long long n_tiles = (long long)pl.tiles_x * pl.tiles_y * N, base = (long long)pl.tiles_cl * pl.tiles_ch;
+  long long S = (1024 + base - 1) / base;
+  if (S > n_tiles) S = n_tiles;
+  if (S < 1) S = 1;
+  pl.S = (int)S;
+  pl.slots = pl.S * 4;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ganlab_conv_s2_supported(const ganlab_conv_geom* g) {
+  int hl, wl;
+  return s2_ok(g, &hl, &wl) ? 1 : 0;
+}
+
+long long ganlab_conv_s2_pack_f32(const float* w, float* out, int Cout, int Cin, int up, int transpose, float scale,
+                                  void* stream) {
+  if (Cout <= 0 || Cin <= 0) return GANLAB_EINVAL;
+  const int rows = transpose ? Cout : Cin, cols = transpose ? Cin : Cout;
+  const int rows_p = round_up_c(rows, 16), cols_p = round_up_c(cols, 64);
+  const long long total = 16LL * rows_p * cols_p;
+  if (!out) return total;
+  if (!w) return GANLAB_EINVAL;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  GL_LAUNCH(pack_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, gl_stream(stream), w, out, Cout, Cin, rows, cols,
+            rows_p, cols_p, up ? 1 : 0, transpose ? 1 : 0, scale);
+  return GL_CHECK_LAUNCH() == GANLAB_OK ? total : GANLAB_ELAUNCH;
+}
+
+int ganlab_conv_s2_fwd_f32(const float* x, const float* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                           float bias_scale, int act, float slope, void* stream) {
+  int hl, wl;
+  if (!s2_ok(g, &hl, &wl) || !x || !wp || !y || !aligned16(x) || !aligned16(wp) || !aligned16(y)) return GANLAB_EINVAL;
+  S2Args a{};
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.Hl = hl; a.Wl = wl;
+  a.Cin_p = round_up_c(g->Cin, 16); a.Cout_p = round_up_c(g->Cout, 64);
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  return g->pool ? run_S(a, gl_stream(stream)) : run_T(a, gl_stream(stream));
+}
+
+int ganlab_conv_s2_dgrad_f32(const float* gy, const float* wp, float* gx, const ganlab_conv_geom* g, void* stream) {
+  int hl, wl;
+  if (!s2_ok(g, &hl, &wl) || !gy || !wp || !gx || !aligned16(gy) || !aligned16(wp) || !aligned16(gx))
+    return GANLAB_EINVAL;
+  S2Args a{};
+  a.x = gy; a.wp = wp; a.bias = nullptr; a.y = gx;
+  a.N = g->N; a.Cin = g->Cout; a.Cout = g->Cin; a.Hl = hl; a.Wl = wl;   // roles swap: the operator consumes gy
+  a.Cin_p = round_up_c(g->Cout, 16); a.Cout_p = round_up_c(g->Cin, 64);
+  a.bias_scale = 0.f; a.slope = 0.f; a.act = GANLAB_ACT_NONE;
+  // down layer: gy is low-res -> T ; up layer: gy is high-res -> S
+  return g->pool ? run_T(a, gl_stream(stream)) : run_S(a, gl_stream(stream));
+}
+
+size_t ganlab_conv_s2_wgrad_workspace(const ganlab_conv_geom* g) {
+  int hl, wl;
+  if (!s2_ok(g, &hl, &wl)) return 0;
+  const int Cl = g->pool ? g->Cout : g->Cin, Ch = g->pool ? g->Cin : g->Cout;
+  const W2Plan pl = plan_w2(g->N, Cl, Ch, hl, wl);
+  return (size_t)(pl.slots + 32) * 16 * Cl * Ch * sizeof(float);
+}
+
+int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  int hl, wl;
+  if (!s2_ok(g, &hl, &wl) || !gy || !x || !gw || !aligned16(gy) || !aligned16(x)) return GANLAB_EINVAL;
+  const int Cl = g->pool ? g->Cout : g->Cin, Ch = g->pool ? g->Cin : g->Cout;
+  const W2Plan pl = plan_w2(g->N, Cl, Ch, hl, wl);
+  const long long nk = 16LL * Cl * Ch;
+  if (!workspace || workspace_bytes < (size_t)(pl.slots + 32) * nk * sizeof(float)) return GANLAB_EWORKSPACE;
+  W2Args a{};
+  a.low = g->pool ? gy : x; a.high = g->pool ? x : gy; a.part = (float*)workspace;
+  a.N = g->N; a.Cl = Cl; a.Ch = Ch; a.Hl = hl; a.Wl = wl;
+  a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.tiles_cl = pl.tiles_cl; a.tiles_ch = pl.tiles_ch; a.S = pl.S;
+  hipStream_t st = gl_stream(stream);
+  const unsigned wgrid = (unsigned)((long long)pl.tiles_cl * pl.tiles_ch * pl.S);
+  if (pl.nba == 2) GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<2>>, dim3(wgrid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<1>>, dim3(wgrid), dim3(256), 0, st, a);
+  float* ws = (float*)workspace;
+  float* stage2 = ws + (long long)pl.slots * nk;
+  const int groups = pl.slots >= 64 ? 32 : 1;
+  const float* folded_src = ws;
+  int fold_groups = pl.slots;
+  if (groups > 1) {
+    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), groups), dim3(256), 0, st, (const float*)ws,
+              stage2, nk, pl.slots, groups);
+    folded_src = stage2;
+    fold_groups = groups;
+  }
+  const long long nw = (long long)g->Cout * g->Cin;
+  GL_LAUNCH(fold_s2_kernel, dim3((unsigned)((nw + 127) / 128)), dim3(128), 0, st, folded_src, gw, g->Cout, g->Cin, Cl,
+            Ch, fold_groups, g->up ? 1 : 0, g->pool ? 1 : 0, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -47,17 +47,24 @@ def _new(shape, like):
 
 
 class Geom:
-    """Static description of one convolution (mirrors ganlab_conv_geom) + derived output size."""
-    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'Ho', 'Wo', '_c')
+    """Static description of one convolution (mirrors ganlab_conv_geom) + derived output size.
+    ``up``: nearest 2x upsample folded in front; ``pool``: 2x2 average pool folded behind (stride-2
+    fused kernels, csrc/conv_s2.hip).  ``s2`` tells whether the stride-2 fast path applies."""
+    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c')
 
-    def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0):
+    def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
         if ks not in (1, 3):
             raise ValueError('conv kernels support ks in {1, 3}; a 4x4 valid conv runs as a linear')
-        self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up = \
-            int(N), int(Cin), int(Hin), int(Win), int(Cout), int(ks), int(pad), int(bool(up))
+        self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool = \
+            int(N), int(Cin), int(Hin), int(Win), int(Cout), int(ks), int(pad), int(bool(up)), int(bool(pool))
         hv, wv = (2 * Hin, 2 * Win) if up else (Hin, Win)
         self.Ho, self.Wo = hv + 2 * pad - ks + 1, wv + 2 * pad - ks + 1
-        self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up)
+        if self.pool:
+            self.Ho, self.Wo = self.Ho // 2, self.Wo // 2
+        self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool)
+        self.s2 = bool((self.up or self.pool) and _lib.lib().ganlab_conv_s2_supported(ctypes.byref(self._c)))
+        if self.pool and not self.s2:
+            raise ValueError('pool=1 geometry is not supported by the stride-2 kernels; compose conv + pool')
 
     def ref(self):
         return ctypes.byref(self._c)
@@ -69,6 +76,14 @@ class Geom:
     @property
     def out_shape(self):
         return (self.N, self.Cout, self.Ho, self.Wo)
+
+
+def pool_fusable(N, Cin, Hin, Win, Cout, ks, pad):
+    """Whether conv(ks, pad) followed by AvgPool2d(2) can run as ONE stride-2 kernel."""
+    if ks != 3 or pad != 1:
+        return False
+    c = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 1)
+    return bool(_lib.lib().ganlab_conv_s2_supported(ctypes.byref(c)))
 
 
 # ---- packed-weight cache ------------------------------------------------------------------------
@@ -85,8 +100,10 @@ def bump_weight_epoch():
     _PACK_CACHE.clear()
 
 
-def _packed(w, mode, scale):
-    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0])
+def _packed(w, mode, scale, s2_up=None):
+    """mode: PACK_FWD / PACK_DGRAD.  s2_up: None -> plain [tap][ci][co] packing; 0 / 1 -> K4 packing of the
+    stride-2 kernels for a down (pool) / up layer."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0], s2_up)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
         return hit[1]
@@ -94,6 +111,17 @@ def _packed(w, mode, scale):
         _PACK_CACHE.clear()
     cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
     L = _lib.lib()
+    if s2_up is not None:
+        tr = 1 if mode == PACK_DGRAD else 0
+        n = L.ganlab_conv_s2_pack_f32(None, None, cout, cin, int(s2_up), tr, scale, None)
+        if n <= 0:
+            raise _lib.GanlabLibraryError(f'conv_s2_pack size query failed ({n}) for weight {tuple(w.shape)}')
+        out = _new((n,), w)
+        rc = L.ganlab_conv_s2_pack_f32(_p(w), _p(out), cout, cin, int(s2_up), tr, scale, _st())
+        if rc != n:
+            raise _lib.GanlabLibraryError(f'conv_s2_pack failed ({rc})')
+        _PACK_CACHE[key] = (w.detach(), out)
+        return out
     n = L.ganlab_conv_pack_f32(None, None, cout, cin, ks, mode, scale, None)
     if n <= 0:
         raise _lib.GanlabLibraryError(f'conv_pack size query failed ({n}) for weight {tuple(w.shape)}')
@@ -134,11 +162,16 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
     x, w = _c(x, 'conv input'), _c(w, 'conv weight')
     assert tuple(x.shape) == g.in_shape, (tuple(x.shape), g.in_shape)
     assert tuple(w.shape) == (g.Cout, g.Cin, g.ks, g.ks), (tuple(w.shape), g.Cout, g.Cin, g.ks)
-    wp = _packed(w, PACK_FWD, scale)
     if bias is not None:
         bias = _c(bias, 'bias')
         assert bias.numel() == g.Cout
     y = _new(g.out_shape, x)
+    if g.s2:   # stride-2 fused layer: conv+avgpool (S kernel) or upsample+conv (T kernel)
+        wp = _packed(w, PACK_FWD, scale, s2_up=g.up)
+        check(_lib.lib().ganlab_conv_s2_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope,
+                                                _st()), 'conv_s2_fwd')
+        return y
+    wp = _packed(w, PACK_FWD, scale)
     check(_lib.lib().ganlab_conv_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _st()),
           'conv_fwd')
     return y
@@ -147,6 +180,11 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
 def k_conv_dgrad(gy, w, g, scale):
     gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
     assert tuple(gy.shape) == g.out_shape, (tuple(gy.shape), g.out_shape)
+    if g.s2:
+        wp = _packed(w, PACK_DGRAD, scale, s2_up=g.up)
+        gx = _new(g.in_shape, gy)
+        check(_lib.lib().ganlab_conv_s2_dgrad_f32(_p(gy), _p(wp), _p(gx), g.ref(), _st()), 'conv_s2_dgrad')
+        return gx
     wp = _packed(w, PACK_DGRAD, scale)
     hv, wv = (2 * g.Hin, 2 * g.Win) if g.up else (g.Hin, g.Win)
     gxv = _new((g.N, g.Cin, hv, wv), gy)
@@ -160,9 +198,15 @@ def k_conv_wgrad(gy, x, g, scale):
     gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     L = _lib.lib()
+    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
+    if g.s2:
+        nbytes = L.ganlab_conv_s2_wgrad_workspace(g.ref())
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+        check(L.ganlab_conv_s2_wgrad_f32(_p(gy), _p(x), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
+              'conv_s2_wgrad')
+        return gw
     nbytes = L.ganlab_conv_wgrad_workspace(g.ref())
     ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
-    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     check(L.ganlab_conv_wgrad_f32(_p(gy), _p(x), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
           'conv_wgrad')
     return gw
@@ -708,15 +752,20 @@ class _ChNormPenalty(Function):
 # ---------------------------------------------------------------------------------------------- #
 # functional API
 # ---------------------------------------------------------------------------------------------- #
-def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2):
-    """act(scale*conv2d(up2?(x), weight, padding) + bias*bias_scale) on the matrix cores."""
+def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False):
+    """act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale) on the matrix cores.
+    ``pool``: the D down layer conv -> AvgPool2d(2) -> +bias -> LeakyReLU (progan/architectures.py:261-284)
+    as one stride-2 kernel when the shape qualifies, else composed from the plain kernels."""
     n, cin, h, w = x.shape
     cout, cin_w, ks, _ = weight.shape
+    if pool and not (not up and pool_fusable(n, cin, h, w, cout, ks, padding)):
+        y = avg_pool2(conv2d(x, weight, None, scale, padding, up))
+        return bias_act(y, bias, bias_scale=bias_scale, act=act, slope=slope)
     if ks == 4 and padding == 0 and h == 4 and w == 4 and not up:
         # 4x4 valid conv on a 4x4 map == linear over (ci, ky, kx)  (progan/architectures.py:227-229)
         y = linear(x.reshape(n, cin * 16), weight.reshape(cout, cin * 16), bias, scale, bias_scale, act, slope)
         return y.view(n, cout, 1, 1)
-    g = Geom(n, cin, h, w, cout, ks, padding, up)
+    g = Geom(n, cin, h, w, cout, ks, padding, up, pool)
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
     if bias is None and a == ACT_NONE:
         return _ConvFwd.apply(x, weight, g, float(scale))

@@ -176,10 +176,15 @@ class Conv2dEx(nn.Module):
         s = self.wscale if (self.equalized_lr and self.wscale is not None) else 1.0
         return s * (self.lrmul if self.use_lrmul else 1.0)
 
-    def forward(self, x, up=False, act=None, slope=0.2):
+    def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None):
         # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
-        return ops.conv2d(x, self.conv2d.weight, self.conv2d.bias, scale=self.scale, padding=self.padding,
-                          up=up, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+        # pool / bias_mod: the D down layer  conv -> AvgPool2d -> Conv2dBias -> LeakyReLU  as one kernel
+        bias, bias_scale = self.conv2d.bias, (self.lrmul if self.use_lrmul else 1.0)
+        if bias_mod is not None:
+            assert bias is None
+            bias, bias_scale = bias_mod.bias, (bias_mod.lrmul if bias_mod.use_lrmul else 1.0)
+        return ops.conv2d(x, self.conv2d.weight, bias, scale=self.scale, padding=self.padding, up=up,
+                          bias_scale=bias_scale, act=act, slope=slope, pool=pool)
 
 
 class Conv2dBias(nn.Module):
@@ -247,7 +252,8 @@ class LinearBias(nn.Module):
 # -- peephole executor ------------------------------------------------------------------------------ #
 def fused_sequential(mods, x):
     """Run a list of modules with kernel fusion where the pattern allows:
-         Upsample2x, Conv2dEx                      -> conv with the upsample folded into the tile load
+         Upsample2x, Conv2dEx                      -> stride-2 transposed kernel (upsample folded in)
+         Conv2dEx, AvgPool2x [, Conv2dBias] [, LeakyReLU] -> stride-2 kernel (pool + bias + act folded in)
          Conv2dEx / LinearEx [, LeakyReLU]         -> bias + LeakyReLU in the MFMA epilogue
          Conv2dBias / LinearBias [, LeakyReLU]     -> one bias+act pass
        Everything else falls through to the module's own (HIP) forward.  nn.Sequential children are
@@ -276,8 +282,17 @@ def fused_sequential(mods, x):
         nxt = flat[i + 1] if i + 1 < n else None
         if isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
             kw = {}
+            if isinstance(m, Conv2dEx) and not up and m.conv2d.bias is None and isinstance(nxt, AvgPool2x):
+                # conv -> AvgPool2d(2) [-> Conv2dBias] [-> LeakyReLU]: one stride-2 kernel
+                kw['pool'] = True
+                i += 1
+                nxt = flat[i + 1] if i + 1 < n else None
+                if isinstance(nxt, Conv2dBias):
+                    kw['bias_mod'] = nxt
+                    i += 1
+                    nxt = flat[i + 1] if i + 1 < n else None
             if isinstance(nxt, LeakyReLU):
-                kw = dict(act='lrelu', slope=nxt.negative_slope)
+                kw.update(act='lrelu', slope=nxt.negative_slope)
                 i += 1
             if up:
                 kw['up'] = True

@@ -47,6 +47,7 @@ typedef struct {
   int N, Cin, Hin, Win; /* physical input (before the optional 2x nearest upsample)     */
   int Cout, ks, pad;    /* square kernel ks in {1,3}; a 4x4 valid conv is run as a linear */
   int up;               /* 1: input is nearest-upsampled 2x on the fly                   */
+  int pool;             /* 1: output is 2x2 average-pooled (ganlab_conv_s2_* entry points only) */
 } ganlab_conv_geom;
 
 /* Output spatial size of a geometry: Hout = (up ? 2*Hin : Hin) + 2*pad - ks + 1. */
@@ -76,6 +77,26 @@ int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual,
 size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g);
 int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g,
                           float scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- stride-2 fused layers (csrc/conv_s2.hip) -------------------------------------------------------
+ * D "down" layer AvgPool2d(2)(conv3x3(x)) (progan/architectures.py:261-284; geom.pool = 1) and G "up"
+ * layer conv3x3(Upsample2x(x)) (stylegan/architectures.py:292-334; geom.up = 1) collapse exactly to a
+ * 4x4 stride-2 kernel K4 = M W M^T: 16 instead of 36 MACs per low-res pixel, no full-resolution
+ * intermediate.  Same calling convention as the plain entry points; `geom` describes the ORIGINAL 3x3
+ * layer (ks = 3, pad = 1, exactly one of up / pool set).  ganlab_conv_s2_supported() tells whether the
+ * shape qualifies (even sizes, low-res width >= 16 and a multiple of 4); otherwise compose the plain
+ * kernels.  pack: `up` selects the combination matrix, `transpose` = 1 packs for the operator that
+ * consumes the output gradient (dgrad). */
+int ganlab_conv_s2_supported(const ganlab_conv_geom* g);
+long long ganlab_conv_s2_pack_f32(const float* w, float* out, int Cout, int Cin, int up, int transpose,
+                                  float scale, void* stream);
+int ganlab_conv_s2_fwd_f32(const float* x, const float* wp, const float* bias, float* y,
+                           const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_s2_dgrad_f32(const float* gy, const float* wp, float* gx, const ganlab_conv_geom* g,
+                             void* stream);
+size_t ganlab_conv_s2_wgrad_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g,
+                             float scale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- depthwise / resampling (custom_layers.py:36-53; nn.Upsample / nn.AvgPool2d call sites) ---- */
 /* y = depthwise [1 2 1]x[1 2 1]/16 blur, zero padding (self-adjoint: also its own backward). */

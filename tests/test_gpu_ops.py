@@ -341,3 +341,85 @@ def test_instnorm_near_constant_planes(ops):
     c = torch.full((2, 3, 4, 4), 1.0)
     o = ops.instnorm_style(c.cuda(), None)
     assert o.abs().max().item() == 0.0
+
+
+S2_CASES = [
+    # N, Cin, H, W, Cout, kind   (kind: 'pool' = conv3x3 -> AvgPool2d(2) -> +bias -> lrelu ; 'up' = Upsample2x -> conv3x3)
+    (2, 16, 64, 64, 32, 'pool'),      # D top-layer shape (16 -> 32), thin S / thin T(dgrad) / W
+    (2, 32, 32, 32, 64, 'pool'),
+    (1, 64, 32, 32, 128, 'pool'),     # thick configs
+    (3, 16, 40, 48, 24, 'pool'),      # ragged tiles, nothing a power of two
+    (2, 128, 32, 32, 80, 'pool'),     # several K-chunks, ragged co tile
+    (2, 32, 32, 32, 16, 'up'),        # G top-layer shape (32 -> 16)
+    (2, 64, 16, 16, 32, 'up'),
+    (1, 128, 16, 16, 64, 'up'),
+    (1, 96, 20, 24, 48, 'up'),
+]
+
+
+@pytest.mark.parametrize('case', S2_CASES, ids=[str(c) for c in S2_CASES])
+def test_stride2_fused_layers(ops, case):
+    """conv+avgpool and upsample+conv as 4x4 stride-2 kernels (csrc/conv_s2.hip) vs the unfused torch ops."""
+    n, cin, h, w, cout, kind = case
+    gen = torch.Generator().manual_seed(abs(hash(case)) % 2 ** 31)
+    x = rnd(gen, n, cin, h, w).requires_grad_(True)
+    wt = rnd(gen, cout, cin, 3, 3).requires_grad_(True)
+    b = rnd(gen, cout).requires_grad_(True)
+    scale = 1.0 / np.sqrt(cin * 9)
+    if kind == 'pool':
+        y_ref = F.leaky_relu(F.avg_pool2d(F.conv2d(x * scale, wt, None, padding=1), 2) + b.view(1, -1, 1, 1), 0.2)
+    else:
+        y_ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest') * scale, wt, b, padding=1), 0.2)
+    cot = rnd(gen, *y_ref.shape)
+    (y_ref * cot).sum().backward()
+    xg, wg, bg = gpu(x).requires_grad_(True), gpu(wt).requires_grad_(True), gpu(b).requires_grad_(True)
+    g = ops.Geom(n, cin, h, w, cout, 3, 1, up=(kind == 'up'), pool=(kind == 'pool'))
+    assert g.s2, 'this shape must take the stride-2 fast path'
+    y = ops.conv2d(xg, wg, bg, scale=scale, padding=1, up=(kind == 'up'), pool=(kind == 'pool'), act='lrelu')
+    assert_close(y, y_ref, TOL, 'y')
+    (y * cot.cuda()).sum().backward()
+    assert_close(xg.grad, x.grad, TOL, 'dgrad')
+    assert_close(wg.grad, wt.grad, TOL, 'wgrad')
+    assert_close(bg.grad, b.grad, TOL, 'bias grad')
+
+
+def test_stride2_double_backward(ops):
+    """R1-shaped second order through a D down layer (conv -> pool -> bias -> lrelu) and a following conv."""
+    gen = torch.Generator().manual_seed(19)
+    x = rnd(gen, 2, 16, 32, 32).requires_grad_(True)
+    w1 = rnd(gen, 24, 16, 3, 3).requires_grad_(True)
+    b1 = rnd(gen, 24).requires_grad_(True)
+    w2 = rnd(gen, 8, 24, 3, 3).requires_grad_(True)
+    hmid = F.leaky_relu(F.avg_pool2d(F.conv2d(x * 0.1, w1, None, padding=1), 2) + b1.view(1, -1, 1, 1), 0.2)
+    out = F.conv2d(hmid * 0.2, w2, None, padding=1)
+    g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+    pen = (g ** 2).sum()
+    pen.backward()
+    xg = gpu(x).requires_grad_(True)
+    w1g, b1g, w2g = gpu(w1).requires_grad_(True), gpu(b1).requires_grad_(True), gpu(w2).requires_grad_(True)
+    hm = ops.conv2d(xg, w1g, b1g, scale=0.1, padding=1, pool=True, act='lrelu')
+    outg = ops.conv2d(hm, w2g, None, scale=0.2, padding=1)
+    gg, = torch.autograd.grad(ops.sum_all(outg), xg, create_graph=True)
+    assert_close(gg, g, TOL, 'first-order grad')
+    peng = ops.sumsq_all(gg)
+    assert_close(peng, pen, TOL, 'penalty')
+    peng.backward()
+    assert_close(w1g.grad, w1.grad, 5e-4, 'ggw1')
+    assert_close(w2g.grad, w2.grad, 5e-4, 'ggw2')
+
+
+def test_pool_fallback_small_shapes(ops):
+    """Shapes the stride-2 kernels do not cover (8x8 -> 4x4) compose the plain kernels - same result."""
+    gen = torch.Generator().manual_seed(23)
+    x = rnd(gen, 4, 32, 8, 8).requires_grad_(True)
+    wt = rnd(gen, 32, 32, 3, 3).requires_grad_(True)
+    b = rnd(gen, 32).requires_grad_(True)
+    y_ref = F.leaky_relu(F.avg_pool2d(F.conv2d(x * 0.05, wt, None, padding=1), 2) + b.view(1, -1, 1, 1), 0.2)
+    y_ref.sum().backward()
+    xg, wg, bg = gpu(x).requires_grad_(True), gpu(wt).requires_grad_(True), gpu(b).requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, scale=0.05, padding=1, pool=True, act='lrelu')
+    assert_close(y, y_ref, TOL)
+    ops.sum_all(y).backward()
+    assert_close(xg.grad, x.grad, TOL)
+    assert_close(wg.grad, wt.grad, TOL)
+    assert_close(bg.grad, b.grad, TOL)
