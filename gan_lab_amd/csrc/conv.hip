@@ -604,7 +604,17 @@ template <int KS>
 int dispatch_co(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 16) return dispatch_geom<KS, 1>(a, st);
   if (a.Cout <= 32) return dispatch_geom<KS, 2>(a, st);
-  return dispatch_geom<KS, 4>(a, st);
+  // Small spatial extents (4x4 / 8x8 / linear layers at 512 channels) give only a handful of pixel
+  // tiles: narrower channel tiles put more workgroups on the 256 CUs (the layer is latency-bound).
+  long long px_tiles;
+  if (a.Ho == 1 && a.Wo == 1) px_tiles = ceil_div(a.in.N, 64);
+  else if (a.Wo >= 32) px_tiles = (long long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, 8) * a.in.N;
+  else if (a.Wo >= 16) px_tiles = (long long)ceil_div(a.Wo, 16) * ceil_div(a.Ho, 16) * a.in.N;
+  else if (a.Wo >= 8) px_tiles = (long long)ceil_div(a.Wo, 8) * ceil_div(a.Ho, 8) * ceil_div(a.in.N, 4);
+  else px_tiles = (long long)ceil_div(a.Wo, 4) * ceil_div(a.Ho, 4) * ceil_div(a.in.N, 16);
+  if (px_tiles * ceil_div(a.Cout, 64) >= 256) return dispatch_geom<KS, 4>(a, st);
+  if (px_tiles * ceil_div(a.Cout, 32) >= 256) return dispatch_geom<KS, 2>(a, st);
+  return dispatch_geom<KS, 1>(a, st);
 }
 
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,

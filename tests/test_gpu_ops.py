@@ -1,5 +1,7 @@
 """GPU parity of every HIP op (through the C-ABI) against the CPU oracle, on seeded inputs.
 Tolerance: the north star allows 1e-3 relative fp32; we assert 2e-4 (fp32 re-association only)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -47,7 +49,7 @@ CONV_CASES = [
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(ops, case):
     n, cin, h, w, cout, ks, pad, up, has_b, act = case
-    gen = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))   # deterministic across processes
     x = rnd(gen, n, cin, h, w).requires_grad_(True)
     wt = rnd(gen, cout, cin, ks, ks).requires_grad_(True)
     b = (rnd(gen, cout) if has_b else None)
@@ -361,7 +363,7 @@ S2_CASES = [
 def test_stride2_fused_layers(ops, case):
     """conv+avgpool and upsample+conv as 4x4 stride-2 kernels (csrc/conv_s2.hip) vs the unfused torch ops."""
     n, cin, h, w, cout, kind = case
-    gen = torch.Generator().manual_seed(abs(hash(case)) % 2 ** 31)
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))   # deterministic across processes
     x = rnd(gen, n, cin, h, w).requires_grad_(True)
     wt = rnd(gen, cout, cin, 3, 3).requires_grad_(True)
     b = rnd(gen, cout).requires_grad_(True)
