@@ -61,6 +61,10 @@ SIGNATURES = {
                                                      _c_ll, _c_p]),
     'ganlab_pixelnorm_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
     'ganlab_pixelnorm_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_chan_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'ganlab_mul_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
+    'ganlab_tanh_fwd_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
+    'ganlab_tanh_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
     'ganlab_mbstd_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
     'ganlab_mbstd_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
     'ganlab_mbstd_bwdbwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),

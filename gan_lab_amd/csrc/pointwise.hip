@@ -531,6 +531,41 @@ __global__ __launch_bounds__(256) void mbstd_bwdbwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- //
+// per-channel affine y = x*scale[c] + shift[c] (BatchNorm / LayerNorm building block), product, tanh
+// ---------------------------------------------------------------------------------------------- //
+template <int VEC>
+__global__ void chan_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ y, int N, int C,
+                                   long long HW) {
+  const long long hwv = HW / VEC, total = (long long)N * C * hwv;
+  GRID_STRIDE(i, total) {
+    const int c = (int)((i / hwv) % C);
+    const float a = scale ? scale[c] : 1.f, b = shift ? shift[c] : 0.f;
+    if (VEC == 4) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+      reinterpret_cast<float4*>(y)[i] = v;
+    } else {
+      y[i] = x[i] * a + b;
+    }
+  }
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           long long n) {
+  GRID_STRIDE(i, n) out[i] = a[i] * b[i];
+}
+
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
+}
+
+__global__ void tanh_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                                long long n) {
+  GRID_STRIDE(i, n) gx[i] = gy[i] * (1.f - y[i] * y[i]);
+}
+
+// ---------------------------------------------------------------------------------------------- //
 // elementwise axpby, reductions, losses
 // ---------------------------------------------------------------------------------------------- //
 __global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
@@ -866,6 +901,36 @@ int ganlab_mbstd_bwdbwd_f32(const float* x, const float* gstat, const float* ggx
                             int G, int gs, long long F, float eps, void* stream) {
   if (!x || !gstat || !ggx || !g_gstat || !g_x || G <= 0 || gs <= 1 || F <= 0) return GANLAB_EINVAL;
   GL_LAUNCH(mbstd_bwdbwd_kernel, dim3(G), dim3(256), 0, ST, x, gstat, ggx, g_gstat, g_x, gs, F, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_chan_affine_f32(const float* x, const float* scale, const float* shift, float* y, int N, int C,
+                           long long HW, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  if ((HW & 3) == 0)
+    GL_LAUNCH(chan_affine_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST, x, scale, shift, y,
+              N, C, HW);
+  else
+    GL_LAUNCH(chan_affine_kernel<1>, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, ST, x, scale, shift, y, N,
+              C, HW);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void* stream) {
+  if (!a || !b || !out || n <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, a, b, out, n);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_tanh_fwd_f32(const float* x, float* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(tanh_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, x, y, n);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_tanh_bwd_f32(const float* gy, const float* y, float* gx, long long n, void* stream) {
+  if (!gy || !y || !gx || n <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(tanh_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, gy, y, gx, n);
   return GL_CHECK_LAUNCH();
 }
 

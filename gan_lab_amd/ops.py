@@ -635,6 +635,123 @@ class _PixelNorm(Function):
 
 
 # ---------------------------------------------------------------------------------------------- #
+# BatchNorm / LayerNorm building blocks (ResNet GAN path): every piece is closed under differentiation,
+# so torch.autograd composes first and second derivatives (WGAN-GP through LayerNorm) from HIP kernels.
+# ---------------------------------------------------------------------------------------------- #
+class _ChanAffine(Function):
+    """y[n,c,...] = x[n,c,...] * scale[c] + shift[c]  (scale / shift may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        x = _c(x)
+        n, c, hw = _nchw(x)
+        sc = _c(scale) if scale is not None else None
+        sh = _c(shift) if shift is not None else None
+        y = torch.empty_like(x)
+        check(_lib.lib().ganlab_chan_affine_f32(_p(x), _p(sc), _p(sh), _p(y), n, c, hw, _st()), 'chan_affine')
+        ctx.save_for_backward(x, sc)
+        ctx.has = (scale is not None, shift is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, sc = ctx.saved_tensors
+        gx = _ChanAffine.apply(g, sc, None) if ctx.needs_input_grad[0] else None
+        gs = _ChanSum.apply(_Mul.apply(g, x), None, 1.0) if (ctx.has[0] and ctx.needs_input_grad[1]) else None
+        gt = _ChanSum.apply(g, None, 1.0) if (ctx.has[1] and ctx.needs_input_grad[2]) else None
+        return gx, gs, gt
+
+
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
+        check(_lib.lib().ganlab_mul_f32(_p(a), _p(b), _p(out), a.numel(), _st()), 'mul')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (_Mul.apply(g, b) if ctx.needs_input_grad[0] else None,
+                _Mul.apply(g, a) if ctx.needs_input_grad[1] else None)
+
+
+class _Tanh(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(_lib.lib().ganlab_tanh_fwd_f32(_p(x), _p(y), x.numel(), _st()), 'tanh_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        g = _c(g)
+        gx = torch.empty_like(g)
+        check(_lib.lib().ganlab_tanh_bwd_f32(_p(g), _p(y), _p(gx), g.numel(), _st()), 'tanh_bwd')
+        return gx
+
+
+def chan_affine(x, scale=None, shift=None):
+    return _ChanAffine.apply(x, scale, shift)
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
+def channel_sum(x):
+    return _ChanSum.apply(x, None, 1.0)
+
+
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm2d semantics (biased variance for the normalisation, unbiased for the running
+    estimate) composed from channel sums / per-channel affines."""
+    n, c, hw = _nchw(x)
+    m = n * hw
+    if training:
+        mean = channel_sum(x) / m
+        xc = chan_affine(x, None, -mean)
+        var = channel_sum(mul(xc, xc)) / m
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.detach(), alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var.detach() * (m / max(m - 1, 1)), alpha=momentum)
+    else:
+        mean, var = running_mean, running_var
+        xc = chan_affine(x, None, -mean)
+    rstd = torch.rsqrt(var + eps)
+    return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm(normalized_shape = x.shape[1:]) semantics: per-sample statistics over all
+    features (biased variance), then the elementwise affine; rows are handled as 'channels' of a
+    (1, N, F) view, the elementwise affine as channels of an (N, F, 1) view."""
+    shape = x.shape
+    n = shape[0]
+    f = x.numel() // n
+    xr = x.reshape(1, n, f)
+    mean = channel_sum(xr) / f
+    xc = chan_affine(xr, None, -mean)
+    var = channel_sum(mul(xc, xc)) / f
+    y = chan_affine(xc, torch.rsqrt(var + eps), None)
+    if weight is not None:
+        y = chan_affine(y.reshape(n, f, 1), weight.reshape(f), bias.reshape(f) if bias is not None else None)
+    return y.reshape(shape)
+
+
+# ---------------------------------------------------------------------------------------------- #
 # minibatch stddev statistic with explicit second order (discriminator, R1 path)
 # ---------------------------------------------------------------------------------------------- #
 class _MbstdStat(Function):
@@ -804,6 +921,17 @@ def lerp(a, b, alpha):
 
 def scale(x, a):
     return _Scale.apply(x, float(a))
+
+
+def add(a, b):
+    """Residual sum a + b."""
+    return _Axpby.apply(a, b, 1.0, 1.0)
+
+
+def global_avg_pool(x):
+    """nn.AvgPool2d(kernel_size=H) on an (N,C,H,H) map -> (N,C,1,1): plane sums through the channel-sum kernel."""
+    n, c, h, w = x.shape
+    return (_ChanSum.apply(x.reshape(1, n * c, h * w), None, 1.0 / (h * w))).view(n, c, 1, 1)
 
 
 def instnorm_style(x, style=None, eps=1e-8):

@@ -161,6 +161,44 @@ class FusedAdam(torch.optim.Optimizer):
                     run['m'][no:no + n].copy_(r['m'][o:o + n])
                     run['v'][no:no + n].copy_(r['v'][o:o + n])
 
+    def export_moments(self, named_params):
+        """Plain-data Adam state for checkpoints: {'step', 'exp_avg': {name: tensor}, 'exp_avg_sq': {...}}."""
+        out = dict(step=0, exp_avg={}, exp_avg_sq={})
+        for group in self.param_groups:
+            cached = self.state.get('_fused', {}).get(id(group))
+            if cached is None:
+                continue
+            out['step'] = cached['step']
+            for name, p in named_params:
+                for r in cached['runs']:
+                    o = r['offs'].get(id(p))
+                    if o is not None:
+                        out['exp_avg'][name] = r['m'][o:o + p.numel()].view(p.shape).detach().cpu().clone()
+                        out['exp_avg_sq'][name] = r['v'][o:o + p.numel()].view(p.shape).detach().cpu().clone()
+        return out
+
+    @torch.no_grad()
+    def import_moments(self, named_params, saved):
+        """Inverse of export_moments (parameters must already have their arena-backed grads)."""
+        named_params = list(named_params)
+        for group in self.param_groups:
+            params = [p for p in group['params'] if p.grad is not None]
+            runs = self._build_runs(params)
+            for r in runs:
+                dev = r['params'][0].device
+                r['m'] = torch.zeros(r['n'], dtype=torch.float32, device=dev)
+                r['v'] = torch.zeros(r['n'], dtype=torch.float32, device=dev)
+            for name, p in named_params:
+                if name not in saved['exp_avg']:
+                    continue
+                for r in runs:
+                    o = r['offs'].get(id(p))
+                    if o is not None:
+                        r['m'][o:o + p.numel()].copy_(saved['exp_avg'][name].reshape(-1))
+                        r['v'][o:o + p.numel()].copy_(saved['exp_avg_sq'][name].reshape(-1))
+            self.state.setdefault('_fused', {})[id(group)] = dict(
+                sig=tuple((p.data_ptr(), p.grad.data_ptr()) for p in params), runs=runs, step=int(saved['step']))
+
     def zero_grad(self, set_to_none=False):
         # keep the arena-backed .grad views alive: zero in place
         for group in self.param_groups:

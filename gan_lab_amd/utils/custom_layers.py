@@ -88,6 +88,34 @@ class InstanceNorm2d(nn.Module):
         return ops.instnorm_style(x, None, self.eps)
 
 
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d parameter / buffer container (same state_dict keys) whose forward runs on the HIP
+    kernels (ops.batch_norm: channel sums + per-channel affines)."""
+
+    def forward(self, x):
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        use_batch = self.training or not self.track_running_stats
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, use_batch,
+                              momentum=self.momentum, eps=self.eps)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm([C, R, R]) parameter container whose forward (and first / second derivatives, for
+    WGAN-GP) runs on the HIP kernels (ops.layer_norm)."""
+
+    def forward(self, x):
+        assert tuple(x.shape[1:]) == tuple(self.normalized_shape), (x.shape, self.normalized_shape)
+        return ops.layer_norm(x, self.weight, self.bias, eps=self.eps)
+
+
+class Tanh(nn.Module):
+    """nn.Tanh stand-in (ResNet generators' output nonlinearity)."""
+
+    def forward(self, x):
+        return ops.tanh(x)
+
+
 class NormalizeLayer(nn.Module):
     """All normalisation methods in one place (custom_layers.py:88-111)."""
 
@@ -98,9 +126,13 @@ class NormalizeLayer(nn.Module):
             self.norm = PixelNorm2d()
         elif norm_type in ('instancenorm', 'instance norm',):
             self.norm = InstanceNorm2d(eps=1.e-8)
-        elif norm_type in ('batchnorm', 'batch norm', 'layernorm', 'layer norm',):
-            raise NotImplementedError(f'`norm_type` == "{norm_type}" is only used by the ResNet GAN path '
-                                      f'(out of the StyleGAN/ProGAN hot path) and has no HIP kernel yet.')
+        elif norm_type in ('batchnorm', 'batch norm',):
+            assert isinstance(ni, int)
+            self.norm = BatchNorm2d(ni)
+        elif norm_type in ('layernorm', 'layer norm',):
+            assert isinstance(ni, int)
+            assert isinstance(res, int)
+            self.norm = LayerNorm([ni, res, res])
         else:
             raise Exception(f'`norm_type` == "{norm_type}" not supported.')
 
@@ -282,12 +314,13 @@ def fused_sequential(mods, x):
         nxt = flat[i + 1] if i + 1 < n else None
         if isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
             kw = {}
-            if isinstance(m, Conv2dEx) and not up and m.conv2d.bias is None and isinstance(nxt, AvgPool2x):
-                # conv -> AvgPool2d(2) [-> Conv2dBias] [-> LeakyReLU]: one stride-2 kernel
+            if isinstance(m, Conv2dEx) and not up and isinstance(nxt, AvgPool2x):
+                # conv -> AvgPool2d(2) [-> Conv2dBias] [-> LeakyReLU]: one stride-2 kernel (a bias of
+                # the conv itself commutes with the pooling: pool(conv + b) = pool(conv) + b)
                 kw['pool'] = True
                 i += 1
                 nxt = flat[i + 1] if i + 1 < n else None
-                if isinstance(nxt, Conv2dBias):
+                if m.conv2d.bias is None and isinstance(nxt, Conv2dBias):
                     kw['bias_mod'] = nxt
                     i += 1
                     nxt = flat[i + 1] if i + 1 < n else None

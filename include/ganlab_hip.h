@@ -145,6 +145,16 @@ int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long H
 int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, int C, long long HW,
                              float eps, void* stream);
 
+/* building blocks of BatchNorm2d / LayerNorm (ResNet GAN path, custom_layers.py:100-107): the
+ * normalisations are composed from y = x*scale[c] + shift[c], elementwise products and channel sums,
+ * each closed under differentiation, so the WGAN-GP double backward works through LayerNorm */
+int ganlab_chan_affine_f32(const float* x, const float* scale, const float* shift, float* y, int N, int C,
+                           long long HW, void* stream);
+int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
+/* nn.Tanh of the ResNet generators (resnetgan/architectures.py:55, :93) */
+int ganlab_tanh_fwd_f32(const float* x, float* y, long long n, void* stream);
+int ganlab_tanh_bwd_f32(const float* gy, const float* y, float* gx, long long n, void* stream);
+
 /* ---- minibatch stddev statistic (custom_layers.py:117-140), contiguous groups of gs samples ---- */
 /* stat[g] = mean_f sqrt(var_unbiased_i(x[g,i,f]) + eps),  f over F = C*H*W features */
 int ganlab_mbstd_fwd_f32(const float* x, float* stat, int G, int gs, long long F, float eps, void* stream);

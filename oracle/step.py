@@ -28,7 +28,7 @@ def calc_gp(disc_fn, kind, fake, real, lda=10.0, gamma=1.0, eps_interp=None):
         raise ValueError(kind)
     xb.requires_grad_(True)
     outb = disc_fn(xb)
-    g = torch.autograd.grad(outb, xb, grad_outputs=torch.ones(outb.shape[0]),
+    g = torch.autograd.grad(outb, xb, grad_outputs=torch.ones_like(outb),
                             create_graph=True, retain_graph=True, only_inputs=True)[0]
     if kind == 'wgan-gp':
         if gamma != 1.0:

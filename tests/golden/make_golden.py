@@ -503,6 +503,118 @@ def golden_schedule():
          final_beta=np.float64(learner.beta))
 
 
+# ---------------------------------------------------------------------------------------------- #
+# ResNet GAN (BASELINE config #5): non-progressive 32 / 64 pixel nets, BatchNorm G, LayerNorm D, WGAN-GP
+# ---------------------------------------------------------------------------------------------- #
+RESNET_LATENT = 16
+
+
+def make_resnets(res, fmap_g, fmap_d):
+    import resnetgan.architectures as ra
+    if res == 64:
+        g = ra.Generator64PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g)
+        d = ra.Discriminator64PixResnet(fmap=fmap_d)
+    else:
+        g = ra.Generator32PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g)
+        d = ra.Discriminator32PixResnet(fmap=fmap_d)
+    return g, d
+
+
+def randomize_resnet(module, gen):
+    """Zero biases -> random; unit BatchNorm/LayerNorm gains -> random around 1."""
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            if k.endswith('bias'):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+            elif '.norm.weight' in k:
+                p.copy_(1. + torch.randn(p.shape, generator=gen) * 0.2)
+
+
+def golden_resnet(res, tag, fmap_g, fmap_d, b=4, lr=1e-3, n_iters=2, n_disc=2):
+    """Forward / gradient vectors plus `n_iters` main iterations of GANLearner.train's loop body
+    (resnetgan/learner.py:538-684: one G iteration with D frozen, then `n_disc` D iterations with
+    WGAN + WGAN-GP), torch.optim.Adam(betas=(0,.9)), every random draw explicit."""
+    torch.manual_seed(21 + res)
+    gen = torch.Generator().manual_seed(2100 + res)
+    g, d = make_resnets(res, fmap_g, fmap_d)
+    randomize_resnet(g, gen)
+    randomize_resnet(d, gen)
+    g.train()
+    d.train()
+    out = {}
+    out.update(sd_arrays('g0.', g))
+    out.update(sd_arrays('d0.', d))
+    # ---- net-level vectors (buffers restored afterwards so the step part starts from g0/d0) ----
+    sd_g0 = {k: v.clone() for k, v in g.state_dict().items()}
+    z = torch.randn(b, RESNET_LATENT, generator=gen)
+    real = torch.rand(b, 3, res, res, generator=gen) * 2 - 1
+    img = g(z)
+    out.update(z=T(z), real=T(real), img=T(img))
+    for p in d.parameters():
+        p.requires_grad_(False)
+    dout = d(img)
+    lg = -dout.mean()
+    g.zero_grad()
+    lg.backward()
+    out.update(d_of_img=T(dout), loss_g=T(lg))
+    out.update({'gg.' + k: T(p.grad) for k, p in g.named_parameters()})
+    out.update({'g_after_fwd.' + k: T(v) for k, v in g.state_dict().items() if 'running' in k})
+    for p in d.parameters():
+        p.requires_grad_(True)
+    fake = img.detach()
+    d.zero_grad()
+    d_fake, d_real = d(fake), d(real)
+    ld = (d_fake - d_real).mean()
+    torch.manual_seed(777)
+    gpv = ref_calc_gp(d, 'wgan-gp', fake, real)
+    torch.manual_seed(777)
+    out['eps_interp'] = T(torch.rand(b, 1, 1, 1))
+    out.update(d_fake=T(d_fake), d_real=T(d_real), loss_d_adv=T(ld), gp=T(gpv), loss_d=T(ld + gpv))
+    (ld + gpv).backward()
+    out.update({'gd.' + k: T(p.grad) for k, p in d.named_parameters()})
+    d.zero_grad()
+    torch.manual_seed(777)
+    ref_calc_gp(d, 'wgan-gp', fake, real).backward()
+    out.update({'ggp.' + k: T(p.grad) for k, p in d.named_parameters() if p.grad is not None})
+    g.load_state_dict(sd_g0)
+    g.zero_grad()
+    d.zero_grad()
+    # ---- training iterations ----
+    opt_g = torch.optim.Adam(g.parameters(), lr=lr, betas=(0., .9), eps=1e-8)
+    opt_d = torch.optim.Adam(d.parameters(), lr=lr, betas=(0., .9), eps=1e-8)
+    for it in range(n_iters):
+        for p in d.parameters():
+            p.requires_grad_(False)
+        g.zero_grad()
+        zg = torch.randn(b, RESNET_LATENT, generator=gen)
+        out[f'i{it}.zg'] = T(zg)
+        lg = -d(g(zg)).mean()
+        lg.backward()
+        opt_g.step()
+        out[f'i{it}.loss_g'] = T(lg)
+        for p in d.parameters():
+            p.requires_grad_(True)
+        for di in range(n_disc):
+            d.zero_grad()
+            zd = torch.randn(b, RESNET_LATENT, generator=gen)
+            real = torch.rand(b, 3, res, res, generator=gen) * 2 - 1
+            fake = g(zd).detach()
+            ld = (d(fake) - d(real)).mean()
+            torch.manual_seed(900 + 10 * it + di)
+            ld = ld + ref_calc_gp(d, 'wgan-gp', fake, real)
+            torch.manual_seed(900 + 10 * it + di)
+            eps_i = torch.rand(b, 1, 1, 1)
+            ld.backward()
+            opt_d.step()
+            out.update({f'i{it}.d{di}.zd': T(zd), f'i{it}.d{di}.real': T(real), f'i{it}.d{di}.eps_interp': T(eps_i),
+                        f'i{it}.d{di}.loss_d': T(ld)})
+    out.update(sd_arrays('g1.', g))
+    out.update(sd_arrays('d1.', d))
+    out.update(res=np.int64(res), lr=np.float64(lr), n_iters=np.int64(n_iters), n_disc=np.int64(n_disc),
+               fmap_g=np.int64(fmap_g), fmap_d=np.int64(fmap_d), len_latent=np.int64(RESNET_LATENT))
+    save(f'{tag}.npz', **out)
+
+
 if __name__ == '__main__':
     p = argparse.ArgumentParser()
     p.add_argument('--only', default=None)
@@ -523,6 +635,8 @@ if __name__ == '__main__':
                                             fade_in=True, alpha=0.25),
         'step_pg': lambda: golden_step('progan', 8, 'step_progan8', 'wgan', 'wgan-gp'),
         'schedule': golden_schedule,
+        'resnet64': lambda: golden_resnet(64, 'resnet64', fmap_g=2, fmap_d=2),
+        'resnet32': lambda: golden_resnet(32, 'resnet32', fmap_g=8, fmap_d=8),
     }
     for name, fn in jobs.items():
         if a.only is None or a.only == name:

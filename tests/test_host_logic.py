@@ -136,3 +136,20 @@ def test_ops_fail_loudly_without_gpu_tensors():
         ops.conv2d(torch.zeros(1, 3, 4, 4), torch.zeros(4, 3, 3, 3), padding=1)
     with pytest.raises(TypeError):
         ops.pixelnorm(torch.zeros(2, 8))
+
+
+@pytest.mark.parametrize('res', [32, 64])
+def test_resnet_state_dict_layout_matches_reference(res):
+    """Module tree / state_dict keys and shapes of the ResNet GAN nets against the reference's own
+    (captured in tests/golden/resnet{32,64}.npz); construction only, no kernels."""
+    import numpy as np
+    import os
+    from gan_lab_amd.resnetgan import architectures as A
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'resnet{res}.npz'))
+    gen_cls, disc_cls = (A.Generator64PixResnet, A.Discriminator64PixResnet) if res == 64 else \
+        (A.Generator32PixResnet, A.Discriminator32PixResnet)
+    g = gen_cls(len_latent=int(G['len_latent']), fmap=int(G['fmap_g']))
+    d = disc_cls(fmap=int(G['fmap_d']))
+    for pre, m in (('g0.', g), ('d0.', d)):
+        ref = [(k[3:], G[k].shape) for k in G.files if k.startswith(pre)]
+        assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == ref

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nets, ops, step
-from util import assert_close, load_golden, sub, t
+from util import assert_close, load_golden, resnet_zero_grad_key, sub, t
 
 TOL = 2e-5
 
@@ -227,3 +227,88 @@ def test_training_steps(name):
     for k, v in sub(g, 'lag.').items():
         m = ok['g.' + k] if 'g.' + k in ok else torch.ones_like(v, dtype=torch.bool)
         assert_close(gan.lagged[k][m], v[m], 1e-5, 'ewma ' + k)
+
+
+# ---------------------------------------------------------------------------------------------- #
+# ResNet GAN (config #5): BatchNorm generator, LayerNorm critic, WGAN + WGAN-GP
+# ---------------------------------------------------------------------------------------------- #
+def _grad_close(got, ref_by_key, tol, what):
+    """Per-parameter relative error.  The conv biases inside the generator's residual blocks all
+    feed a BatchNorm (directly, or through the residual sum), so their true gradient is zero and
+    both sides only hold rounding noise: those are judged against the largest gradient of the net."""
+    gmax = max(float(np.abs(v).max()) for v in ref_by_key.values())
+    for k, ref in ref_by_key.items():
+        a = got[k].grad.detach().double()
+        b = torch.from_numpy(ref).double()
+        den = gmax if resnet_zero_grad_key(k) else max(b.abs().max().item(), 1e-4 * gmax)
+        e = (a - b).abs().max().item() / den
+        assert e <= tol, f'{what} {k}: rel err {e:.3e} > {tol:.1e}'
+
+
+@pytest.mark.parametrize('res', [32, 64])
+def test_resnet_nets_forward_backward_gp(res):
+    from oracle import resnet
+    g = load_golden(f'resnet{res}.npz')
+    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']))
+    img = gan.gen(t(g['z']))
+    assert_close(img, g['img'], TOL, 'img')
+    for k, v in sub(g, 'g_after_fwd.').items():
+        assert_close(gan.g_buf[k], v, TOL, 'running stat ' + k)
+    dout = gan.disc(img, {k: v.detach() for k, v in gan.d.items()})
+    assert_close(dout, g['d_of_img'], TOL, 'D(G(z))')
+    (-dout.mean()).backward()
+    _grad_close(gan.g, {k[3:]: v for k, v in g.items() if k.startswith('gg.')}, 1e-4, 'G grad')
+    fake, real, eps = img.detach(), t(g['real']), t(g['eps_interp'])
+    gpv = step.calc_gp(gan.disc, 'wgan-gp', fake, real, 10.0, 1.0, eps)
+    assert_close(gpv, g['gp'], 1e-4, 'gp')
+    gpv.backward()
+    _grad_close(gan.d, {k[4:]: v for k, v in g.items() if k.startswith('ggp.')}, 2e-4, 'GP-only grad')
+    for p in gan.d.values():
+        p.grad = None
+    ld = gan.d_loss(fake, real, eps)
+    assert_close(ld, g['loss_d'], 1e-4, 'loss_d')
+    ld.backward()
+    _grad_close(gan.d, {k[3:]: v for k, v in g.items() if k.startswith('gd.')}, 2e-4, 'D grad')
+
+
+@pytest.mark.parametrize('res', [32, 64])
+def test_resnet_training_iterations(res):
+    from oracle import resnet
+    g = load_golden(f'resnet{res}.npz')
+    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']))
+    ok = {}
+
+    def note(tag, params):
+        for k, p in params.items():
+            if p.grad is not None:
+                m = p.grad.abs() > 1e-4 * p.grad.abs().max().clamp_min(1e-30)
+                ok[tag + k] = m if tag + k not in ok else (ok[tag + k] & m)
+
+    for it in range(int(g['n_iters'])):
+        lg = gan.g_step(t(g[f'i{it}.zg']))
+        note('g.', gan.g)
+        assert_close(lg, g[f'i{it}.loss_g'], 2e-4, f'loss_g {it}')
+        for di in range(int(g['n_disc'])):
+            p = f'i{it}.d{di}.'
+            ld = gan.d_step(t(g[p + 'zd']), t(g[p + 'real']), t(g[p + 'eps_interp']))
+            note('d.', gan.d)
+            assert_close(ld, g[p + 'loss_d'], 5e-4, f'loss_d {it}.{di}')
+    n_checked = 0
+    for pre, tag, cur, ref0 in (('g1.', 'g.', {**gan.g, **gan.g_buf}, sub(g, 'g0.')),
+                                ('d1.', 'd.', gan.d, sub(g, 'd0.'))):
+        for k, v in sub(g, pre).items():
+            if k.endswith('num_batches_tracked'):
+                assert int(cur[k]) == int(v), k
+                continue
+            if 'running' in k:
+                # the +-lr noise updates of the zero-gradient biases shift these means by O(lr)
+                assert_close(cur[k], v, 5e-3, pre + k)
+                continue
+            if tag == 'g.' and resnet_zero_grad_key(k):
+                continue        # Adam(beta1=0) turns the rounding-noise gradient into +-lr: not comparable
+            du_ref, du = v - ref0[k], cur[k].detach() - ref0[k]
+            m = ok[tag + k]
+            if m.float().mean() > 0.5:
+                assert_close(du[m], du_ref[m], 3e-2, 'update ' + pre + k)
+                n_checked += int(m.sum())
+    assert n_checked > 1000

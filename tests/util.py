@@ -38,3 +38,9 @@ def assert_close(a, b, tol, what=''):
     assert tuple(a_.shape) == tuple(b_.shape), f'{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}'
     e = rel_err(a_, b_)
     assert e <= tol, f'{what}: rel err {e:.3e} > {tol:.1e}'
+
+
+def resnet_zero_grad_key(k):
+    """Generator residual-block conv biases: a per-channel shift in front of a BatchNorm."""
+    return k.startswith('generator_model.') and k.endswith('conv2d.bias') and \
+        ('conv_layer' in k or 'skip_connection' in k)
