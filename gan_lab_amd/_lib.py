@@ -61,6 +61,14 @@ SIGNATURES = {
                                                      _c_ll, _c_p]),
     'ganlab_pixelnorm_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
     'ganlab_pixelnorm_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'ganlab_blur_fused_supported': (_c_int, [_c_int, _c_int]),
+    'ganlab_blur_fused_workspace': (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    'ganlab_blur_bias_act_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f,
+                                          _c_int, _c_f, _c_p]),
+    'ganlab_blur_act_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_f,
+                                         _c_p, _c_sz, _c_p]),
+    'ganlab_act_bwd_blur_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
+                                         _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_chan_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_mul_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
     'ganlab_tanh_fwd_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
@@ -119,7 +127,7 @@ def lib():
 
 
 _ERR = {-1: 'GANLAB_EINVAL (bad argument)', -2: 'GANLAB_EWORKSPACE (workspace too small)',
-        -3: 'GANLAB_ELAUNCH (kernel launch failed)'}
+        -3: 'GANLAB_ELAUNCH (kernel launch failed)', -4: 'GANLAB_EUNSUPPORTED (geometry not handled)'}
 
 
 def check(rc, what):

@@ -115,6 +115,135 @@ __global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y,
 }
 
 // ---------------------------------------------------------------------------------------------- //
+// blur fused with its pointwise neighbours (same 4x2-outputs-per-thread scheme; grid (chunks, C) so the
+// per-channel sums of the backward come out of the same pass):
+//   BF_FWD: out = act(blur(in) + noise_w[c]*noise[n,hw] + bias[c]*bias_scale)        G layer forward
+//   BF_A  : out = lrelu'(y) * blur(in);           sum0[c] = sum out                   D backward (blur^T, then act')
+//   BF_AT : out = blur(lrelu'(y) * in);           sum0[c] = sum lrelu'(y)*in, sum1[c] = sum lrelu'(y)*in*noise
+//           (adjoint of BF_A; the backward of BF_FWD)
+// ---------------------------------------------------------------------------------------------- //
+enum { BF_FWD = 0, BF_A = 1, BF_AT = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in, const float* __restrict__ y,
+                                                         const float* __restrict__ noise,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ noise_w, float* __restrict__ out,
+                                                         float* __restrict__ part, int N, int C, int H, int W,
+                                                         int chunks, float bias_scale, int act, float slope,
+                                                         int want_sums) {
+  __shared__ float red[4];
+  const int c = blockIdx.y, chunk = blockIdx.x;
+  const int w4 = W >> 2, h2 = H >> 1;
+  const long long per_n = (long long)h2 * w4, total = (long long)N * per_n, HW = (long long)H * W;
+  const float b = (MODE == BF_FWD && bias) ? bias[c] * bias_scale : 0.f;
+  const float nw = (MODE == BF_FWD && noise) ? noise_w[c] : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
+    const long long n = i / per_n, rem = i - n * per_n;
+    const int r2 = (int)(rem / w4), q = (int)(rem - (long long)r2 * w4);
+    const long long plane = (n * C + c) * HW;
+    const float* px = in + plane;
+    const int y0 = 2 * r2, x0 = 4 * q;
+    float h[4][4];
+    float cen[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 - 1 + k;
+      if ((unsigned)yy < (unsigned)H) {
+        const long long ro = (long long)yy * W;
+        float4 v = *reinterpret_cast<const float4*>(px + ro + x0);
+        float l = x0 > 0 ? px[ro + x0 - 1] : 0.f;
+        float r = x0 + 4 < W ? px[ro + x0 + 4] : 0.f;
+        if (MODE == BF_AT) {
+          const float* my = y + plane + ro;
+          const float4 m = *reinterpret_cast<const float4*>(my + x0);
+          const float ml = x0 > 0 ? my[x0 - 1] : 1.f;
+          const float mr = x0 + 4 < W ? my[x0 + 4] : 1.f;
+          v.x = m.x > 0.f ? v.x : v.x * slope;
+          v.y = m.y > 0.f ? v.y : v.y * slope;
+          v.z = m.z > 0.f ? v.z : v.z * slope;
+          v.w = m.w > 0.f ? v.w : v.w * slope;
+          l = ml > 0.f ? l : l * slope;
+          r = mr > 0.f ? r : r * slope;
+          if (k == 1 || k == 2) {
+            cen[k - 1][0] = v.x; cen[k - 1][1] = v.y; cen[k - 1][2] = v.z; cen[k - 1][3] = v.w;
+          }
+        }
+        h[k][0] = l + 2.f * v.x + v.y;
+        h[k][1] = v.x + 2.f * v.y + v.z;
+        h[k][2] = v.y + 2.f * v.z + v.w;
+        h[k][3] = v.z + 2.f * v.w + r;
+      } else {
+        h[k][0] = h[k][1] = h[k][2] = h[k][3] = 0.f;
+      }
+    }
+    float o[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[0][j] = (h[0][j] + 2.f * h[1][j] + h[2][j]) * 0.0625f;
+      o[1][j] = (h[1][j] + 2.f * h[2][j] + h[3][j]) * 0.0625f;
+    }
+    const long long co = (long long)y0 * W + x0;
+    if (MODE == BF_FWD) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noise) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + rr * W);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = o[rr][j] + b + nw * nz[j];
+          if (act == GANLAB_ACT_LRELU) t = gl_lrelu(t, slope);
+          o[rr][j] = t;
+        }
+      }
+    } else if (MODE == BF_A) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float m[4];
+        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(y + plane + co + rr * W);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[rr][j] = m[j] > 0.f ? o[rr][j] : o[rr][j] * slope;
+          s0 += o[rr][j];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noise && want_sums)
+          *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + rr * W);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0 += cen[rr][j];
+          s1 += cen[rr][j] * nz[j];
+        }
+      }
+    }
+    float* po = out + plane + co;
+    *reinterpret_cast<float4*>(po) = *reinterpret_cast<float4*>(o[0]);
+    *reinterpret_cast<float4*>(po + W) = *reinterpret_cast<float4*>(o[1]);
+  }
+  if (MODE != BF_FWD && want_sums) {
+    s0 = gl_block_sum_256(s0, red);
+    if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s0;
+    if (MODE == BF_AT) {
+      __syncthreads();
+      s1 = gl_block_sum_256(s1, red);
+      if (threadIdx.x == 0) part[((long long)C + c) * chunks + chunk] = s1;
+    }
+  }
+}
+
+inline int blur_fused_chunks(int N, int H, int W) {
+  long long c = ((long long)N * (H / 2) * (W / 4) + 256 * 4 - 1) / (256 * 4);
+  if (c < 1) c = 1;
+  if (c > 128) c = 128;
+  return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------------- //
 // y = act(x + noise_w[c]*noise[n,hw] + bias[c]*bias_scale)
 // ---------------------------------------------------------------------------------------------- //
 template <int VEC>
@@ -816,6 +945,54 @@ int ganlab_act_bwd_bias_f32(const float* gy, const float* y, float* gz, float* g
   GL_LAUNCH(act_bwd_bias_stage1, dim3(chunks, C), dim3(256), 0, ST, gy, y, gz, (float*)workspace, N, C, HW, chunks,
             slope);
   GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_blur_fused_supported(int H, int W) { return (H >= 2 && W >= 4 && (H & 1) == 0 && (W & 3) == 0) ? 1 : 0; }
+
+size_t ganlab_blur_fused_workspace(int N, int C, int H, int W) {
+  if (!ganlab_blur_fused_supported(H, W)) return 0;
+  return (size_t)2 * C * blur_fused_chunks(N, H, W) * sizeof(float);
+}
+
+int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                             int N, int C, int H, int W, float bias_scale, int act, float slope, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  const int chunks = blur_fused_chunks(N, H, W);
+  GL_LAUNCH(blur_fused_kernel<BF_FWD>, dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
+            noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* gb, int N, int C, int H, int W,
+                            float slope, float bias_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !y || !out || N <= 0 || C <= 0) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  const int chunks = blur_fused_chunks(N, H, W);
+  if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
+  GL_LAUNCH(blur_fused_kernel<BF_A>, dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
+            (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
+            gb ? 1 : 0);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, float* out, float* gb, float* gnw,
+                            int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!g || !y || !out || N <= 0 || C <= 0 || (gnw && !noise)) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  const int chunks = blur_fused_chunks(N, H, W);
+  const int sums = (gb || gnw) ? 1 : 0;
+  if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
+  GL_LAUNCH(blur_fused_kernel<BF_AT>, dim3(chunks, C), dim3(256), 0, ST, g, y, gnw ? noise : (const float*)nullptr,
+            (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
+            sums);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
+  if (gnw)
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace + (size_t)C * chunks, gnw, C,
+              chunks, 1.f);
   return GL_CHECK_LAUNCH();
 }
 

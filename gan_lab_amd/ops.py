@@ -220,6 +220,56 @@ def k_blur(x):
     return y
 
 
+def blur_fusable(x):
+    """Whether the fused blur kernels take this (N,C,H,W) map (H even, W a multiple of 4)."""
+    return x.dim() == 4 and bool(_lib.lib().ganlab_blur_fused_supported(int(x.shape[2]), int(x.shape[3])))
+
+
+def _blur_ws(x):
+    n, c, h, w = x.shape
+    nbytes = _lib.lib().ganlab_blur_fused_workspace(n, c, h, w)
+    return torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+
+
+def k_blur_bias_act(x, bias, noise, noise_w, bias_scale, act, slope):
+    x = _c(x)
+    n, c, h, w = x.shape
+    bias = _c(bias) if bias is not None else None
+    if noise is not None:
+        noise, noise_w = _c(noise), _c(noise_w)
+        assert noise.numel() == n * h * w and noise_w.numel() == c
+    y = torch.empty_like(x)
+    check(_lib.lib().ganlab_blur_bias_act_f32(_p(x), _p(bias), _p(noise), _p(noise_w), _p(y), n, c, h, w, bias_scale,
+                                              act, slope, _st()), 'blur_bias_act')
+    return y
+
+
+def k_blur_act_bwd(g, y, slope, bias_scale, want_gb):
+    g, y = _c(g), _c(y)
+    assert g.shape == y.shape
+    n, c, h, w = g.shape
+    out = torch.empty_like(g)
+    gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
+    ws = _blur_ws(g) if want_gb else None
+    check(_lib.lib().ganlab_blur_act_bwd_f32(_p(g), _p(y), _p(out), _p(gb), n, c, h, w, slope, bias_scale, _p(ws),
+                                             ws.numel() * 4 if ws is not None else 0, _st()), 'blur_act_bwd')
+    return out, gb
+
+
+def k_act_bwd_blur(g, y, noise, slope, bias_scale, want_gb, want_gnw):
+    g, y = _c(g), _c(y)
+    assert g.shape == y.shape
+    n, c, h, w = g.shape
+    out = torch.empty_like(g)
+    gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
+    gnw = torch.empty(c, dtype=torch.float32, device=g.device) if want_gnw else None
+    ws = _blur_ws(g) if (want_gb or want_gnw) else None
+    check(_lib.lib().ganlab_act_bwd_blur_f32(_p(g), _p(y), _p(_c(noise)) if want_gnw else None, _p(out), _p(gb),
+                                             _p(gnw), n, c, h, w, slope, bias_scale, _p(ws),
+                                             ws.numel() * 4 if ws is not None else 0, _st()), 'act_bwd_blur')
+    return out, gb, gnw
+
+
 def k_up2(x, scale=1.0):
     x = _c(x)
     n, c, h, w = x.shape
@@ -431,6 +481,77 @@ class _ActBwdBias(Function):
         return (_ActBwd.apply(g, y, ctx.slope) if g is not None else None), None, None, None
 
 
+class _BlurActBwd(Function):
+    """(out, gb) = (lrelu'(y) * blur(g), bias_scale * sum_{n,hw} out): the backward of  conv+bias+LeakyReLU
+    -> blur  in one pass.  Linear in g; its adjoint is _ActBwdBlur."""
+
+    @staticmethod
+    def forward(ctx, g, y, slope, bias_scale, want_gb):
+        ctx.save_for_backward(y)
+        ctx.set_materialize_grads(False)
+        ctx.slope, ctx.bias_scale = slope, bias_scale
+        return k_blur_act_bwd(g, y, slope, bias_scale, want_gb)
+
+    @staticmethod
+    def backward(ctx, gout, ggb):
+        y, = ctx.saved_tensors
+        g = gout
+        if ggb is not None:
+            shape = y.shape
+            b = _Scale.apply(ggb.view(1, shape[1], 1, 1).expand(shape), ctx.bias_scale)
+            g = b if g is None else _Axpby.apply(g, b, 1.0, 1.0)
+        if g is None:
+            return None, None, None, None, None
+        return _ActBwdBlur.apply(g, y, None, ctx.slope, 1.0, False, False)[0], None, None, None, None
+
+
+class _ActBwdBlur(Function):
+    """(out, gb, gnw) = (blur(z), bias_scale*sum z, sum z*noise) with z = lrelu'(y) * g: the backward of
+    blur -> noise/bias/LeakyReLU in one pass.  Linear in g; its adjoint is _BlurActBwd."""
+
+    @staticmethod
+    def forward(ctx, g, y, noise, slope, bias_scale, want_gb, want_gnw):
+        ctx.save_for_backward(y)
+        ctx.set_materialize_grads(False)
+        ctx.slope = slope
+        return k_act_bwd_blur(g, y, noise, slope, bias_scale, want_gb, want_gnw)
+
+    @staticmethod
+    def backward(ctx, gout, ggb, ggnw):
+        if ggb is not None or ggnw is not None:
+            raise NotImplementedError('double backward through the bias / noise-weight gradients of the fused blur')
+        y, = ctx.saved_tensors
+        if gout is None:
+            return (None,) * 7
+        return (_BlurActBwd.apply(gout, y, ctx.slope, 1.0, False)[0],) + (None,) * 6
+
+
+class _BlurBiasAct(Function):
+    """y = act(blur(x) + noise_w*noise + bias*bias_scale): the blur after a generator up-conv fused with
+    StyleAddNoise / Conv2dBias / LeakyReLU (stylegan/architectures.py:331-360 + :105-119)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope):
+        y = k_blur_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+        ctx.save_for_backward(y if act != ACT_NONE else None, noise)
+        ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, noise = ctx.saved_tensors
+        params = _want_param_grads()
+        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
+        want_nw = ctx.nw_shape is not None and ctx.needs_input_grad[3] and params
+        act = ctx.act != ACT_NONE
+        gx, gb, gnw = _ActBwdBlur.apply(gy, y if act else gy, noise if want_nw else None,
+                                        ctx.slope if act else 1.0, ctx.bias_scale, bool(want_b), bool(want_nw))
+        return (gx if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if want_b else None), None, \
+            (gnw.view(ctx.nw_shape) if want_nw else None), None, None, None
+
+
 class _ChanSum(Function):
     """(N,C,...) -> (C,) sum, optionally weighted by a (N,1,...) map (noise-weight gradient)."""
 
@@ -454,12 +575,14 @@ class _ConvBiasAct(Function):
     epilogue).  Reference: Conv2dEx.forward (+ nn.LeakyReLU) custom_layers.py:202-211."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope):
+    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False):
         y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
-        ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope = g, s, bias_scale, act, slope
+        ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
         ctx.bias_shape = bias.shape if bias is not None else None
-        return y
+        # blur=True: the D block's  conv -> bias -> LeakyReLU -> blur  (progan/architectures.py:280-293);
+        # forward is conv kernel + blur kernel, backward is ONE pass (blur^T, LeakyReLU', bias gradient)
+        return k_blur(y) if blur else y
 
     @staticmethod
     def backward(ctx, gy):
@@ -467,15 +590,21 @@ class _ConvBiasAct(Function):
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[2] and params
         gb = None
-        if ctx.act != ACT_NONE and want_b:
-            gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
+        if ctx.blur and ctx.act != ACT_NONE:
+            gz, gb = _BlurActBwd.apply(gy, y, ctx.slope, ctx.bias_scale, bool(want_b))
         else:
-            gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
-            if want_b:
-                gb = _ChanSum.apply(gz, None, ctx.bias_scale)
+            if ctx.blur:
+                gy = _Blur.apply(gy)
+            if ctx.act != ACT_NONE and want_b:
+                gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
+            else:
+                gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+                if want_b:
+                    gb = _ChanSum.apply(gz, None, ctx.bias_scale)
         gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
         gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and params) else None
-        return gx, gw, (gb.view(ctx.bias_shape) if gb is not None else None), None, None, None, None, None
+        return gx, gw, (gb.view(ctx.bias_shape) if want_b and gb is not None else None), None, None, None, None, \
+            None, None
 
 
 class _BiasAct(Function):
@@ -869,12 +998,24 @@ class _ChNormPenalty(Function):
 # ---------------------------------------------------------------------------------------------- #
 # functional API
 # ---------------------------------------------------------------------------------------------- #
-def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False):
-    """act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale) on the matrix cores.
+def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False,
+           blur=False):
+    """blur?(act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale)) on the matrix cores.
     ``pool``: the D down layer conv -> AvgPool2d(2) -> +bias -> LeakyReLU (progan/architectures.py:261-284)
-    as one stride-2 kernel when the shape qualifies, else composed from the plain kernels."""
+    as one stride-2 kernel when the shape qualifies, else composed from the plain kernels.
+    ``blur``: the binomial blur that follows conv+bias+LeakyReLU in a D block; its backward is fused with
+    the LeakyReLU / bias backward."""
     n, cin, h, w = x.shape
     cout, cin_w, ks, _ = weight.shape
+    if blur:
+        y = None
+        if not pool and not up and ks in (1, 3) and act == 'lrelu':
+            g = Geom(n, cin, h, w, cout, ks, padding, 0, 0)
+            if _lib.lib().ganlab_blur_fused_supported(g.Ho, g.Wo):
+                y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), ACT_LRELU, float(slope),
+                                       True)
+        return y if y is not None else _Blur.apply(conv2d(x, weight, bias, scale, padding, up, bias_scale, act, slope,
+                                                          pool))
     if pool and not (not up and pool_fusable(n, cin, h, w, cout, ks, padding)):
         y = avg_pool2(conv2d(x, weight, None, scale, padding, up))
         return bias_act(y, bias, bias_scale=bias_scale, act=act, slope=slope)
@@ -897,8 +1038,13 @@ def linear(x, weight, bias=None, scale=1.0, bias_scale=1.0, act=None, slope=0.2)
     return y.view(n, cout)
 
 
-def bias_act(x, bias=None, noise=None, noise_w=None, bias_scale=1.0, act=None, slope=0.2):
+def bias_act(x, bias=None, noise=None, noise_w=None, bias_scale=1.0, act=None, slope=0.2, blur=False):
+    """act(blur?(x) + noise_w*noise + bias*bias_scale); ``blur``: the binomial blur in front (one fused pass)."""
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    if blur:
+        if blur_fusable(x):
+            return _BlurBiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope))
+        x = _Blur.apply(x)
     return _BiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope))
 
 

@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import ops, rng
 from .._int import FMAP_SAMPLES, RES_INIT
-from ..utils.custom_layers import (Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer, Upsample2x,
+from ..utils.custom_layers import (Blur2d, Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer, Upsample2x,
                                    fused_sequential, get_blur_op)
 from ..utils.latent_utils import gen_rand_latent_vars
 from .base import StyleGAN
@@ -230,8 +230,11 @@ class StyleGenerator(StyleGAN):
     # -- forward -------------------------------------------------------------------------------------
     def _layer(self, n, layer, out, w, noise):
         """One gen_layers entry on fused kernels."""
+        blur = False
         if n:
-            out = fused_sequential([layer[0]], out)                    # (up+)conv MFMA kernel, blur kernel
+            head = list(layer[0]) if isinstance(layer[0], nn.Sequential) else [layer[0]]
+            blur = bool(head) and isinstance(head[-1], Blur2d)
+            out = fused_sequential(head[:-1] if blur else head, out)   # (up+)conv MFMA kernel
         mods = list(layer[2])
         bias = mods.pop(0) if mods and isinstance(mods[0], Conv2dBias) else None
         act = mods.pop(0) if mods and isinstance(mods[0], LeakyReLU) else None
@@ -239,7 +242,8 @@ class StyleGenerator(StyleGAN):
         out = ops.bias_act(out, bias.bias if bias is not None else None, nz,
                            layer[1].noise_weight if nz is not None else None,
                            act='lrelu' if act is not None else None,
-                           slope=act.negative_slope if act is not None else 0.2)
+                           slope=act.negative_slope if act is not None else 0.2,
+                           blur=blur)                                  # blur + noise + bias + LeakyReLU: one pass
         if self.use_pixelnorm:
             out = ops.pixelnorm(out)
         y = layer[3](w)                                                # (B, 2C) style

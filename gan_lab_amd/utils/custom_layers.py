@@ -208,7 +208,7 @@ class Conv2dEx(nn.Module):
         s = self.wscale if (self.equalized_lr and self.wscale is not None) else 1.0
         return s * (self.lrmul if self.use_lrmul else 1.0)
 
-    def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None):
+    def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None, blur=False):
         # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
         # pool / bias_mod: the D down layer  conv -> AvgPool2d -> Conv2dBias -> LeakyReLU  as one kernel
         bias, bias_scale = self.conv2d.bias, (self.lrmul if self.use_lrmul else 1.0)
@@ -216,7 +216,7 @@ class Conv2dEx(nn.Module):
             assert bias is None
             bias, bias_scale = bias_mod.bias, (bias_mod.lrmul if bias_mod.use_lrmul else 1.0)
         return ops.conv2d(x, self.conv2d.weight, bias, scale=self.scale, padding=self.padding, up=up,
-                          bias_scale=bias_scale, act=act, slope=slope, pool=pool)
+                          bias_scale=bias_scale, act=act, slope=slope, pool=pool, blur=blur)
 
 
 class Conv2dBias(nn.Module):
@@ -226,8 +226,9 @@ class Conv2dBias(nn.Module):
         self.lrmul = lrmul
         self.bias = nn.Parameter(torch.zeros(1, nf, 1, 1, device=device))
 
-    def forward(self, x, act=None, slope=0.2):
-        return ops.bias_act(x, self.bias, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope)
+    def forward(self, x, act=None, slope=0.2, blur=False):
+        return ops.bias_act(x, self.bias, bias_scale=self.lrmul if self.use_lrmul else 1.0, act=act, slope=slope,
+                            blur=blur)
 
 
 class LinearEx(nn.Module):
@@ -288,6 +289,8 @@ def fused_sequential(mods, x):
          Conv2dEx, AvgPool2x [, Conv2dBias] [, LeakyReLU] -> stride-2 kernel (pool + bias + act folded in)
          Conv2dEx / LinearEx [, LeakyReLU]         -> bias + LeakyReLU in the MFMA epilogue
          Conv2dBias / LinearBias [, LeakyReLU]     -> one bias+act pass
+         Conv2dEx, LeakyReLU, Blur2d               -> blur backward fused with LeakyReLU' + bias gradient
+         Blur2d, Conv2dBias [, LeakyReLU]          -> one blur+bias+act pass
        Everything else falls through to the module's own (HIP) forward.  nn.Sequential children are
        flattened first."""
     flat = []
@@ -312,7 +315,16 @@ def fused_sequential(mods, x):
             i += 1
             m = flat[i]
         nxt = flat[i + 1] if i + 1 < n else None
-        if isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
+        if isinstance(m, Blur2d) and isinstance(nxt, Conv2dBias):
+            kw = {'blur': True}
+            i += 1
+            m = nxt
+            nxt = flat[i + 1] if i + 1 < n else None
+            if isinstance(nxt, LeakyReLU):
+                kw.update(act='lrelu', slope=nxt.negative_slope)
+                i += 1
+            x = m(x, **kw)
+        elif isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
             kw = {}
             if isinstance(m, Conv2dEx) and not up and isinstance(nxt, AvgPool2x):
                 # conv -> AvgPool2d(2) [-> Conv2dBias] [-> LeakyReLU]: one stride-2 kernel (a bias of
@@ -327,6 +339,10 @@ def fused_sequential(mods, x):
             if isinstance(nxt, LeakyReLU):
                 kw.update(act='lrelu', slope=nxt.negative_slope)
                 i += 1
+                if isinstance(m, Conv2dEx) and not up and 'pool' not in kw and i + 1 < n and \
+                        isinstance(flat[i + 1], Blur2d):
+                    kw['blur'] = True
+                    i += 1
             if up:
                 kw['up'] = True
             x = m(x, **kw)

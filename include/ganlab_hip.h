@@ -29,6 +29,7 @@ extern "C" {
 #define GANLAB_EINVAL (-1)   /* bad argument (null pointer, non-positive dim, unsupported ks) */
 #define GANLAB_EWORKSPACE (-2) /* workspace too small */
 #define GANLAB_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch */
+#define GANLAB_EUNSUPPORTED (-4) /* geometry outside what the fused kernel handles (see *_supported) */
 
 #define GANLAB_ACT_NONE 0
 #define GANLAB_ACT_LRELU 1
@@ -118,6 +119,24 @@ int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, 
  * Conv2dBias + LeakyReLU, custom_layers.py:222-226); workspace as ganlab_channel_sum_workspace */
 int ganlab_act_bwd_bias_f32(const float* gy, const float* y, float* gz, float* gb, int N, int C, long long HW,
                             float slope, float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- blur fused with its pointwise neighbours (H even, W % 4 == 0: ganlab_blur_fused_supported) --------
+ * The binomial blur of a G layer sits between the up-conv and noise/bias/LeakyReLU
+ * (stylegan/architectures.py:331-360 -> :105-119, progan/architectures.py:95-107), that of a D block
+ * between LeakyReLU and the down-conv (progan/architectures.py:280-293): one pass instead of two.
+ *   blur_bias_act:  y   = act(blur(x) + noise_w[c]*noise[n,hw] + bias[c]*bias_scale)
+ *   blur_act_bwd:   out = lrelu'(y) * blur(g),  gb[c] = bias_scale * sum out        (gb nullable)
+ *   act_bwd_blur:   out = blur(lrelu'(y) * g),  gb[c] = bias_scale * sum lrelu'(y)*g,
+ *                   gnw[c] = sum lrelu'(y)*g*noise[n,hw]                             (gb, gnw nullable)
+ * blur_act_bwd and act_bwd_blur are adjoint: each is the other's backward (R1 double backward). */
+int ganlab_blur_fused_supported(int H, int W);
+size_t ganlab_blur_fused_workspace(int N, int C, int H, int W);
+int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                             int N, int C, int H, int W, float bias_scale, int act, float slope, void* stream);
+int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* gb, int N, int C, int H, int W,
+                            float slope, float bias_scale, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, float* out, float* gb, float* gnw,
+                            int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
+                            size_t workspace_bytes, void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);

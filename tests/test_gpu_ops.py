@@ -425,3 +425,79 @@ def test_pool_fallback_small_shapes(ops):
     assert_close(xg.grad, x.grad, TOL)
     assert_close(wg.grad, wt.grad, TOL)
     assert_close(bg.grad, b.grad, TOL)
+
+
+# ---------------------------------------------------------------------------------------------- #
+# blur fused with its pointwise neighbours
+# ---------------------------------------------------------------------------------------------- #
+def _blur_ref(x):
+    k = torch.tensor([1., 2., 1.], dtype=x.dtype)
+    k = (k[:, None] * k[None, :] / 16.).expand(x.shape[1], 1, 3, 3)
+    return F.conv2d(x, k, padding=1, groups=x.shape[1])
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 8, 12), (3, 16, 32, 32), (2, 4, 4, 4), (2, 3, 6, 10)])
+@pytest.mark.parametrize('with_noise', [True, False])
+def test_blur_bias_act_fused(ops, shape, with_noise):
+    """act(blur(x) + nw*noise + b*bs): forward, all first-order gradients, and the double backward of the
+    input gradient; (2,3,6,10) is not 4-column aligned and takes the composed path."""
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((shape, with_noise)).encode()))
+    n, c, h, w = shape
+    x, b = rnd(gen, *shape), rnd(gen, 1, c, 1, 1)
+    nz, nw = (rnd(gen, n, 1, h, w), rnd(gen, c)) if with_noise else (None, None)
+    cot, cot2 = rnd(gen, *shape), rnd(gen, *shape)
+
+    def run(dev):
+        to = (lambda v: gpu(v).requires_grad_(True)) if dev == 'gpu' else (lambda v: v.clone().requires_grad_(True))
+        xs, bs = to(x), to(b)
+        nws = to(nw) if with_noise else None
+        if dev == 'gpu':
+            y = ops.bias_act(xs, bs, gpu(nz) if with_noise else None, nws, bias_scale=0.7, act='lrelu', slope=0.2,
+                             blur=True)
+            c1, c2 = gpu(cot), gpu(cot2)
+        else:
+            pre = _blur_ref(xs) + bs * 0.7
+            if with_noise:
+                pre = pre + nws.view(1, c, 1, 1) * nz
+            y = F.leaky_relu(pre, 0.2)
+            c1, c2 = cot, cot2
+        ins = [xs, bs] + ([nws] if with_noise else [])
+        grads = torch.autograd.grad(y, ins, c1, create_graph=True)
+        # second order: d/dx of <gx, c2> is zero almost everywhere for a piecewise-linear map, so probe the
+        # linear operator instead: differentiate <gx, c2> w.r.t. the cotangent c1
+        c1v = c1.clone().requires_grad_(True)
+        gx2, = torch.autograd.grad(y, xs, c1v, create_graph=True)
+        gc, = torch.autograd.grad((gx2 * c2).sum(), c1v)
+        return [y] + list(grads) + [gc]
+
+    for a, r, name in zip(run('gpu'), run('cpu'), ['y', 'gx', 'gb', 'gnw' if with_noise else 'adj', 'adj']):
+        assert_close(a.detach().cpu(), r.detach(), TOL, name)
+
+
+@pytest.mark.parametrize('case', [(2, 8, 16, 16, 8, 3), (2, 16, 32, 32, 24, 3), (2, 3, 8, 8, 16, 1),
+                                  (2, 8, 6, 6, 8, 3)])
+def test_conv_act_blur_fused_backward(ops, case):
+    """blur(lrelu(conv(x) + b)) as the D block uses it: the fused backward (blur^T, LeakyReLU', bias gradient in
+    one pass) against torch, including the R1-style double backward."""
+    n, cin, hw, _, cout, ks = case
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+    x, w, b = rnd(gen, n, cin, hw, hw), rnd(gen, cout, cin, ks, ks) * 0.2, rnd(gen, cout) * 0.3
+    cot = rnd(gen, n, cout, hw, hw)
+
+    def run(dev):
+        to = (lambda v: gpu(v).requires_grad_(True)) if dev == 'gpu' else (lambda v: v.clone().requires_grad_(True))
+        xs, ws, bs = to(x), to(w), to(b)
+        if dev == 'gpu':
+            y = ops.conv2d(xs, ws, bs, scale=0.5, padding=ks // 2, act='lrelu', slope=0.2, blur=True)
+            c1 = gpu(cot)
+        else:
+            y = _blur_ref(F.leaky_relu(F.conv2d(xs * 0.5, ws, bs, padding=ks // 2), 0.2))
+            c1 = cot
+        out = (y * c1).sum(dim=(1, 2, 3))
+        gx, = torch.autograd.grad(out, xs, torch.ones_like(out), create_graph=True)
+        pen = (gx ** 2).sum() * 0.5 + out.sum()
+        gw, gb = torch.autograd.grad(pen, [ws, bs])
+        return y, gx, gw, gb
+
+    for a, r, name in zip(run('gpu'), run('cpu'), ['y', 'gx', 'd pen/dw', 'd pen/db']):
+        assert_close(a.detach().cpu(), r.detach(), TOL, name)
