@@ -43,48 +43,90 @@ __global__ void blur3x3_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
-// vectorised blur: one thread = 4 columns x 2 rows (W % 4 == 0, H % 2 == 0): 4 row segments are read
-// once (float4 + the two edge neighbours) and combined separably -> 12 loads per 8 outputs
-__global__ void blur3x3_vec_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H,
-                                   int W) {
-  const int w4 = W >> 2, h2 = H >> 1;
-  const long long total = planes * h2 * w4;
-  GRID_STRIDE(i, total) {
-    const int q = (int)(i % w4);
-    const long long t = i / w4;
-    const int r2 = (int)(t % h2);
-    const long long pl = t / h2;
+// One row segment (4 columns at x0) of the blur input with its two horizontal neighbours, [1 2 1]-filtered.
+// The neighbours come from the adjacent lanes (lane-1 holds columns x0-4..x0-1 of the same row whenever
+// q > 0) - only the first / last lane of a wave touches memory for them.  MASKED: the operand is
+// in * lrelu'(m) (the masked centre values are returned in cen).
+template <bool MASKED>
+__device__ __forceinline__ void blur_row(const float* __restrict__ in, const float* __restrict__ m, long long ro,
+                                         int x0, int q, int w4, bool valid, float slope, float (&hrow)[4],
+                                         float (&cen)[4]) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    v = *reinterpret_cast<const float4*>(in + ro + x0);
+    if (MASKED) {
+      const float4 mm = *reinterpret_cast<const float4*>(m + ro + x0);
+      v.x = mm.x > 0.f ? v.x : v.x * slope;
+      v.y = mm.y > 0.f ? v.y : v.y * slope;
+      v.z = mm.z > 0.f ? v.z : v.z * slope;
+      v.w = mm.w > 0.f ? v.w : v.w * slope;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  float l = __shfl_up(v.w, 1, 64);
+  float r = __shfl_down(v.x, 1, 64);
+  if (q == 0) {
+    l = 0.f;
+  } else if (lane == 0) {
+    l = 0.f;
+    if (valid) {
+      l = in[ro + x0 - 1];
+      if (MASKED) l = m[ro + x0 - 1] > 0.f ? l : l * slope;
+    }
+  }
+  if (q == w4 - 1) {
+    r = 0.f;
+  } else if (lane == 63) {
+    r = 0.f;
+    if (valid) {
+      r = in[ro + x0 + 4];
+      if (MASKED) r = m[ro + x0 + 4] > 0.f ? r : r * slope;
+    }
+  }
+  hrow[0] = l + 2.f * v.x + v.y;
+  hrow[1] = v.x + 2.f * v.y + v.z;
+  hrow[2] = v.y + 2.f * v.z + v.w;
+  hrow[3] = v.z + 2.f * v.w + r;
+  cen[0] = v.x; cen[1] = v.y; cen[2] = v.z; cen[3] = v.w;
+}
+
+// vectorised blur: one thread = 4 columns x R rows (W % 4 == 0, H % R == 0): R+2 row segments are read once
+// as float4 (edges by lane shuffle) and combined separably
+template <int R>
+__global__ __launch_bounds__(256) void blur3x3_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long long planes, int H, int W) {
+  const int w4 = W >> 2, hr = H / R;
+  const long long total = planes * hr * w4;
+  // all lanes of a wave run the same number of iterations (the shuffles need their neighbours alive)
+  const long long span = (long long)gridDim.x * blockDim.x;
+  for (long long base = blockIdx.x * (long long)blockDim.x; base < total; base += span) {
+    const long long i = base + threadIdx.x;
+    const bool live = i < total;
+    const long long ii = live ? i : total - 1;
+    const int q = (int)(ii % w4);
+    const long long t = ii / w4;
+    const int rr = (int)(t % hr);
+    const long long pl = t / hr;
     const float* px = x + pl * H * W;
-    const int y0 = 2 * r2, x0 = 4 * q;
-    float h[4][4];  // horizontal [1 2 1] sums of rows y0-1 .. y0+2
+    const int y0 = R * rr, x0 = 4 * q;
+    float h[R + 2][4], cen[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R + 2; ++k) {
       const int yy = y0 - 1 + k;
-      if ((unsigned)yy < (unsigned)H) {
-        const float* row = px + (long long)yy * W;
-        const float4 c = *reinterpret_cast<const float4*>(row + x0);
-        const float l = x0 > 0 ? row[x0 - 1] : 0.f;
-        const float r = x0 + 4 < W ? row[x0 + 4] : 0.f;
-        h[k][0] = l + 2.f * c.x + c.y;
-        h[k][1] = c.x + 2.f * c.y + c.z;
-        h[k][2] = c.y + 2.f * c.z + c.w;
-        h[k][3] = c.z + 2.f * c.w + r;
-      } else {
-        h[k][0] = h[k][1] = h[k][2] = h[k][3] = 0.f;
+      blur_row<false>(px, nullptr, (long long)yy * W, x0, q, w4, (unsigned)yy < (unsigned)H, 0.f, h[k], cen);
+    }
+    if (live) {
+      float* py = y + pl * H * W + (long long)y0 * W + x0;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        float4 o;
+        o.x = (h[k][0] + 2.f * h[k + 1][0] + h[k + 2][0]) * 0.0625f;
+        o.y = (h[k][1] + 2.f * h[k + 1][1] + h[k + 2][1]) * 0.0625f;
+        o.z = (h[k][2] + 2.f * h[k + 1][2] + h[k + 2][2]) * 0.0625f;
+        o.w = (h[k][3] + 2.f * h[k + 1][3] + h[k + 2][3]) * 0.0625f;
+        *reinterpret_cast<float4*>(py + (long long)k * W) = o;
       }
     }
-    float4 o0, o1;
-    o0.x = (h[0][0] + 2.f * h[1][0] + h[2][0]) * 0.0625f;
-    o0.y = (h[0][1] + 2.f * h[1][1] + h[2][1]) * 0.0625f;
-    o0.z = (h[0][2] + 2.f * h[1][2] + h[2][2]) * 0.0625f;
-    o0.w = (h[0][3] + 2.f * h[1][3] + h[2][3]) * 0.0625f;
-    o1.x = (h[1][0] + 2.f * h[2][0] + h[3][0]) * 0.0625f;
-    o1.y = (h[1][1] + 2.f * h[2][1] + h[3][1]) * 0.0625f;
-    o1.z = (h[1][2] + 2.f * h[2][2] + h[3][2]) * 0.0625f;
-    o1.w = (h[1][3] + 2.f * h[2][3] + h[3][3]) * 0.0625f;
-    float* py = y + pl * H * W + (long long)y0 * W + x0;
-    *reinterpret_cast<float4*>(py) = o0;
-    *reinterpret_cast<float4*>(py + W) = o1;
   }
 }
 
@@ -115,7 +157,7 @@ __global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y,
 }
 
 // ---------------------------------------------------------------------------------------------- //
-// blur fused with its pointwise neighbours (same 4x2-outputs-per-thread scheme; grid (chunks, C) so the
+// blur fused with its pointwise neighbours (same 4xR-outputs-per-thread scheme; grid (chunks, C) so the
 // per-channel sums of the backward come out of the same pass):
 //   BF_FWD: out = act(blur(in) + noise_w[c]*noise[n,hw] + bias[c]*bias_scale)        G layer forward
 //   BF_A  : out = lrelu'(y) * blur(in);           sum0[c] = sum out                   D backward (blur^T, then act')
@@ -124,7 +166,7 @@ __global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y,
 // ---------------------------------------------------------------------------------------------- //
 enum { BF_FWD = 0, BF_A = 1, BF_AT = 2 };
 
-template <int MODE>
+template <int MODE, int R>
 __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in, const float* __restrict__ y,
                                                          const float* __restrict__ noise,
                                                          const float* __restrict__ bias,
@@ -134,96 +176,62 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
                                                          int want_sums) {
   __shared__ float red[4];
   const int c = blockIdx.y, chunk = blockIdx.x;
-  const int w4 = W >> 2, h2 = H >> 1;
-  const long long per_n = (long long)h2 * w4, total = (long long)N * per_n, HW = (long long)H * W;
+  const int w4 = W >> 2, hr = H / R;
+  const long long per_n = (long long)hr * w4, total = (long long)N * per_n, HW = (long long)H * W;
   const float b = (MODE == BF_FWD && bias) ? bias[c] * bias_scale : 0.f;
   const float nw = (MODE == BF_FWD && noise) ? noise_w[c] : 0.f;
   float s0 = 0.f, s1 = 0.f;
-  for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
-    const long long n = i / per_n, rem = i - n * per_n;
-    const int r2 = (int)(rem / w4), q = (int)(rem - (long long)r2 * w4);
+  for (long long base = chunk * 256LL; base < total; base += (long long)chunks * 256) {
+    const long long i = base + threadIdx.x;
+    const bool live = i < total;
+    const long long ii = live ? i : total - 1;
+    const long long n = ii / per_n, rem = ii - n * per_n;
+    const int rr = (int)(rem / w4), q = (int)(rem - (long long)rr * w4);
     const long long plane = (n * C + c) * HW;
-    const float* px = in + plane;
-    const int y0 = 2 * r2, x0 = 4 * q;
-    float h[4][4];
-    float cen[2][4];
+    const int y0 = R * rr, x0 = 4 * q;
+    float h[R + 2][4], cen[R + 2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R + 2; ++k) {
       const int yy = y0 - 1 + k;
-      if ((unsigned)yy < (unsigned)H) {
-        const long long ro = (long long)yy * W;
-        float4 v = *reinterpret_cast<const float4*>(px + ro + x0);
-        float l = x0 > 0 ? px[ro + x0 - 1] : 0.f;
-        float r = x0 + 4 < W ? px[ro + x0 + 4] : 0.f;
-        if (MODE == BF_AT) {
-          const float* my = y + plane + ro;
-          const float4 m = *reinterpret_cast<const float4*>(my + x0);
-          const float ml = x0 > 0 ? my[x0 - 1] : 1.f;
-          const float mr = x0 + 4 < W ? my[x0 + 4] : 1.f;
-          v.x = m.x > 0.f ? v.x : v.x * slope;
-          v.y = m.y > 0.f ? v.y : v.y * slope;
-          v.z = m.z > 0.f ? v.z : v.z * slope;
-          v.w = m.w > 0.f ? v.w : v.w * slope;
-          l = ml > 0.f ? l : l * slope;
-          r = mr > 0.f ? r : r * slope;
-          if (k == 1 || k == 2) {
-            cen[k - 1][0] = v.x; cen[k - 1][1] = v.y; cen[k - 1][2] = v.z; cen[k - 1][3] = v.w;
-          }
-        }
-        h[k][0] = l + 2.f * v.x + v.y;
-        h[k][1] = v.x + 2.f * v.y + v.z;
-        h[k][2] = v.y + 2.f * v.z + v.w;
-        h[k][3] = v.z + 2.f * v.w + r;
-      } else {
-        h[k][0] = h[k][1] = h[k][2] = h[k][3] = 0.f;
-      }
+      blur_row<MODE == BF_AT>(in + plane, MODE == BF_AT ? y + plane : nullptr, (long long)yy * W, x0, q, w4,
+                              (unsigned)yy < (unsigned)H, slope, h[k], cen[k]);
     }
-    float o[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o[0][j] = (h[0][j] + 2.f * h[1][j] + h[2][j]) * 0.0625f;
-      o[1][j] = (h[1][j] + 2.f * h[2][j] + h[3][j]) * 0.0625f;
-    }
+    if (!live) continue;
     const long long co = (long long)y0 * W + x0;
-    if (MODE == BF_FWD) {
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
+    for (int k = 0; k < R; ++k) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (h[k][j] + 2.f * h[k + 1][j] + h[k + 2][j]) * 0.0625f;
+      if (MODE == BF_FWD) {
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (noise) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + rr * W);
+        if (noise) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + k * W);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float t = o[rr][j] + b + nw * nz[j];
+          float t = o[j] + b + nw * nz[j];
           if (act == GANLAB_ACT_LRELU) t = gl_lrelu(t, slope);
-          o[rr][j] = t;
+          o[j] = t;
         }
-      }
-    } else if (MODE == BF_A) {
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
+      } else if (MODE == BF_A) {
         float m[4];
-        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(y + plane + co + rr * W);
+        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(y + plane + co + k * W);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[rr][j] = m[j] > 0.f ? o[rr][j] : o[rr][j] * slope;
-          s0 += o[rr][j];
+          o[j] = m[j] > 0.f ? o[j] : o[j] * slope;
+          s0 += o[j];
         }
-      }
-    } else {
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
+      } else {
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
         if (noise && want_sums)
-          *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + rr * W);
+          *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + k * W);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          s0 += cen[rr][j];
-          s1 += cen[rr][j] * nz[j];
+          s0 += cen[k + 1][j];
+          s1 += cen[k + 1][j] * nz[j];
         }
       }
+      *reinterpret_cast<float4*>(out + plane + co + (long long)k * W) = *reinterpret_cast<float4*>(o);
     }
-    float* po = out + plane + co;
-    *reinterpret_cast<float4*>(po) = *reinterpret_cast<float4*>(o[0]);
-    *reinterpret_cast<float4*>(po + W) = *reinterpret_cast<float4*>(o[1]);
   }
   if (MODE != BF_FWD && want_sums) {
     s0 = gl_block_sum_256(s0, red);
@@ -236,8 +244,10 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
   }
 }
 
+inline int blur_rows(int H) { return (H & 3) == 0 ? 4 : 2; }
+
 inline int blur_fused_chunks(int N, int H, int W) {
-  long long c = ((long long)N * (H / 2) * (W / 4) + 256 * 4 - 1) / (256 * 4);
+  long long c = ((long long)N * (H / blur_rows(H)) * (W / 4) + 256 * 4 - 1) / (256 * 4);
   if (c < 1) c = 1;
   if (c > 128) c = 128;
   return (int)c;
@@ -885,7 +895,12 @@ int ganlab_abi_version(void) { return 1; }
 int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream) {
   if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
   if ((W & 3) == 0 && (H & 1) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
-    GL_LAUNCH(blur3x3_vec_kernel, dim3(ew_blocks(planes * (H / 2) * (W / 4))), dim3(256), 0, ST, x, y, planes, H, W);
+    if ((H & 3) == 0)
+      GL_LAUNCH(blur3x3_vec_kernel<4>, dim3(ew_blocks(planes * (H / 4) * (W / 4))), dim3(256), 0, ST, x, y, planes, H,
+                W);
+    else
+      GL_LAUNCH(blur3x3_vec_kernel<2>, dim3(ew_blocks(planes * (H / 2) * (W / 4))), dim3(256), 0, ST, x, y, planes, H,
+                W);
   else
     GL_LAUNCH(blur3x3_kernel, dim3(ew_blocks(planes * H * W)), dim3(256), 0, ST, x, y, planes, H, W);
   return GL_CHECK_LAUNCH();
@@ -960,8 +975,12 @@ int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noi
   if (!x || !y || N <= 0 || C <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
-  GL_LAUNCH(blur_fused_kernel<BF_FWD>, dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
-            noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
+  if (blur_rows(H) == 4)
+    GL_LAUNCH((blur_fused_kernel<BF_FWD, 4>), dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise,
+              bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
+  else
+    GL_LAUNCH((blur_fused_kernel<BF_FWD, 2>), dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise,
+              bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
   return GL_CHECK_LAUNCH();
 }
 
@@ -971,9 +990,14 @@ int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* g
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
   if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
-  GL_LAUNCH(blur_fused_kernel<BF_A>, dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
-            (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
-            gb ? 1 : 0);
+  if (blur_rows(H) == 4)
+    GL_LAUNCH((blur_fused_kernel<BF_A, 4>), dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
+              (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
+              gb ? 1 : 0);
+  else
+    GL_LAUNCH((blur_fused_kernel<BF_A, 2>), dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
+              (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
+              gb ? 1 : 0);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
   return GL_CHECK_LAUNCH();
 }
@@ -986,9 +1010,14 @@ int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, 
   const int chunks = blur_fused_chunks(N, H, W);
   const int sums = (gb || gnw) ? 1 : 0;
   if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
-  GL_LAUNCH(blur_fused_kernel<BF_AT>, dim3(chunks, C), dim3(256), 0, ST, g, y, gnw ? noise : (const float*)nullptr,
-            (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
-            sums);
+  if (blur_rows(H) == 4)
+    GL_LAUNCH((blur_fused_kernel<BF_AT, 4>), dim3(chunks, C), dim3(256), 0, ST, g, y,
+              gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
+              (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
+  else
+    GL_LAUNCH((blur_fused_kernel<BF_AT, 2>), dim3(chunks, C), dim3(256), 0, ST, g, y,
+              gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
+              (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
   if (gnw)
     GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace + (size_t)C * chunks, gnw, C,

@@ -220,6 +220,29 @@ def k_blur(x):
     return y
 
 
+def decode_u8(images_u8_nhwc, res, mean, std, flip=None):
+    """Real-image input path on the device: (N,Hs,Ws,C) uint8 -> box-downsample by the
+    power-of-two factor Hs/res (bit-exact with PIL's BOX resize) -> (N,C,res,res) fp32 ``(v/255 - mean)/std``
+    (data_config.py:307-341).  ``flip``: optional (N,) uint8/bool mask, horizontal mirror per image."""
+    x = images_u8_nhwc
+    if not x.is_cuda or x.dtype != torch.uint8 or x.dim() != 4:
+        raise TypeError('decode_u8 needs a (N,H,W,C) uint8 tensor on the GPU')
+    x = x.contiguous()
+    n, hs, ws, c = x.shape
+    if hs % res or ws % res or hs // res != ws // res:
+        raise ValueError(f'cannot box-resize {hs}x{ws} to {res}x{res}')
+    mean = torch.as_tensor(mean, dtype=torch.float32, device=x.device).contiguous()
+    std = torch.as_tensor(std, dtype=torch.float32, device=x.device).contiguous()
+    assert mean.numel() == c and std.numel() == c
+    if flip is not None:
+        flip = flip.to(device=x.device, dtype=torch.uint8).contiguous()
+        assert flip.numel() == n
+    out = torch.empty((n, c, res, res), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ganlab_u8_box_decode_f32(x.data_ptr(), _p(out), n, hs, ws, c, hs // res, _p(mean), _p(std),
+                                              flip.data_ptr() if flip is not None else None, _st()), 'u8_box_decode')
+    return out
+
+
 def blur_fusable(x):
     """Whether the fused blur kernels take this (N,C,H,W) map (H even, W a multiple of 4)."""
     return x.dim() == 4 and bool(_lib.lib().ganlab_blur_fused_supported(int(x.shape[2]), int(x.shape[3])))

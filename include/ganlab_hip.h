@@ -215,6 +215,15 @@ int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void
 /* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) for latents / per-layer noise */
 int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- real-image input path -----------------------------------------------------------
+ * uint8 NHWC dataset images -> 2^k box downsample -> fp32 NCHW ((v/255 - mean[c]) / std[c]); replaces the host
+ * chain PIL Image.resize(BOX) -> ToTensor -> Normalize (data_config.py:307-341, progan/learner.py:1099-1112).
+ * The uint8 stage is bit-exact with PIL's two-pass rounding for power-of-two factors; `flip` (nullable,
+ * one byte per image) mirrors the image horizontally (RandomHorizontalFlip, data_config.py:332-333).
+ * GANLAB_EUNSUPPORTED unless factor is a power of two dividing Hs and Ws. */
+int ganlab_u8_box_decode_f32(const unsigned char* in_nhwc, float* out_nchw, int N, int Hs, int Ws, int C, int factor,
+                             const float* mean, const float* stdv, const unsigned char* flip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

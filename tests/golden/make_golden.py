@@ -615,6 +615,31 @@ def golden_resnet(res, tag, fmap_g, fmap_d, b=4, lr=1e-3, n_iters=2, n_disc=2):
     save(f'{tag}.npz', **out)
 
 
+def golden_data():
+    """The host image chain of data_config.py:307-341 evaluated with the real PIL + torch arithmetic
+    (torchvision is absent here; its Resize / ToTensor / Normalize are thin wrappers over exactly these calls):
+    Image.resize(BOX) -> uint8 HWC -> float/255 -> (x - mean)/std."""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (6, 64, 64, 3), dtype=np.uint8)
+    imgs[0] = 255
+    imgs[1] = 0
+    imgs[2, ::2] = 255          # worst case for the double rounding
+    imgs[2, 1::2] = 0
+    mean, std = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]
+    mean2, std2 = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    out = dict(images=imgs, mean=np.float32(mean), std=np.float32(std), mean2=np.float32(mean2), std2=np.float32(std2))
+    for res in (64, 32, 16, 8, 4):
+        u8 = np.stack([np.asarray(Image.fromarray(im).resize((res, res), Image.BOX)) for im in imgs])
+        out[f'u8_{res}'] = u8
+        t_ = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+        out[f'x_{res}'] = T((t_ - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1))
+        out[f'x2_{res}'] = T((t_ - torch.tensor(mean2).view(1, 3, 1, 1)) / torch.tensor(std2).view(1, 3, 1, 1))
+    import PIL
+    out['pil_version'] = np.array(PIL.__version__)
+    save('data_box.npz', **out)
+
+
 if __name__ == '__main__':
     p = argparse.ArgumentParser()
     p.add_argument('--only', default=None)
@@ -635,6 +660,7 @@ if __name__ == '__main__':
                                             fade_in=True, alpha=0.25),
         'step_pg': lambda: golden_step('progan', 8, 'step_progan8', 'wgan', 'wgan-gp'),
         'schedule': golden_schedule,
+        'data': golden_data,
         'resnet64': lambda: golden_resnet(64, 'resnet64', fmap_g=2, fmap_d=2),
         'resnet32': lambda: golden_resnet(32, 'resnet32', fmap_g=8, fmap_d=8),
     }

@@ -312,3 +312,20 @@ def test_resnet_training_iterations(res):
                 assert_close(du[m], du_ref[m], 3e-2, 'update ' + pre + k)
                 n_checked += int(m.sum())
     assert n_checked > 1000
+
+
+# ---------------------------------------------------------------------------------------------- #
+# real-image input path: PIL BOX resize -> ToTensor -> Normalize
+# ---------------------------------------------------------------------------------------------- #
+def test_image_decode_oracle_matches_pil():
+    from oracle import data
+    g = load_golden('data_box.npz')
+    for res in (64, 32, 16, 8, 4):
+        assert np.array_equal(data.box_resize_u8(g['images'], res), g[f'u8_{res}']), res       # bit-exact
+        assert np.array_equal(data.decode(g['images'], res, g['mean'], g['std']), g[f'x_{res}']), res
+        assert np.array_equal(data.decode(g['images'], res, g['mean2'], g['std2']), g[f'x2_{res}']), res
+    flip = np.array([1, 0, 1, 0, 0, 1], dtype=bool)
+    x = data.decode(g['images'], 16, g['mean'], g['std'], flip)
+    ref = g['x_16'].copy()
+    ref[flip] = ref[flip][:, :, :, ::-1]
+    assert np.array_equal(x, ref)
