@@ -312,10 +312,18 @@ class ProGANLearner(GANLearner):
             self.train_dataiter = iter(train_dl)
             if parallel.rank() == 0:
                 print('STARTING FROM ITERATION 0:\n')
-        elif parallel.rank() == 0:
-            print('CONTINUING FROM WHERE YOU LEFT OFF:\n')
+        else:
+            if self.sched is None:      # checkpoint without phase bookkeeping: start the phases at this resolution
+                self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, c.bs_dict,
+                                           c.nimg_transition, num_disc_iters)
+            if self.pretrained_model and getattr(self, 'train_dataiter', None) is None:
+                self._bump_loader(train_dl)         # resume at the checkpoint's resolution / batch size
+                self._bump_loader(valid_dl)
+                self.train_dataiter = iter(train_dl)
+            if parallel.rank() == 0:
+                print('CONTINUING FROM WHERE YOU LEFT OFF:\n')
         if self.sched_bool:
-            if self.scheduler_gen is None:
+            if self.scheduler_gen is None and not self.pretrained_model:
                 self.sched_stop_step = 0
             self._set_scheduler()
         sched = self.sched
@@ -423,6 +431,13 @@ class ProGANLearner(GANLearner):
             'disc_model_state_dict': {k: v.detach().cpu() for k, v in self.disc_model.state_dict().items()},
             'gen_model_lagged_state_dict': None if lagged is None else
             {k: v.detach().cpu() for k, v in lagged.state_dict().items()},
+            'opt_gen_state_dict': self.opt_gen.export_moments(self.gen_model.named_parameters()),
+            'opt_disc_state_dict': self.opt_disc.export_moments(self.disc_model.named_parameters()),
+            'batch_size': self.batch_size, 'sched_stop_step': self.sched_stop_step,
+            'loss': self.loss, 'gradient_penalty': self.gradient_penalty,
+            'latent_distribution': self.latent_distribution,
+            'curr_dataset_batch_num': self.curr_dataset_batch_num, 'curr_epoch_num': self.curr_epoch_num,
+            'progressively_grow': self.progressively_grow,
             'curr_img_num': self.curr_img_num,
             'curr_phase_num': self.curr_phase_num,
             'nimg_transition_lst': list(self.sched.nimg_transition_lst) if self.sched else None,
@@ -430,9 +445,13 @@ class ProGANLearner(GANLearner):
         }, save_path)
 
     def load_model(self, load_path, dev_of_saved_model='cpu'):
-        """Restore networks by replaying ``increase_scale`` up to the saved resolution
-        (progan/learner.py:1348-1360); ``weights_only=False`` is required on torch >= 2.6."""
-        ck = torch.load(str(load_path), map_location=dev_of_saved_model, weights_only=False)
+        """Restore networks (replaying ``increase_scale`` up to the saved resolution, progan/learner.py:
+        1348-1360), EWMA shadow, Adam moments and the phase machine.  Reads this package's plain-data
+        checkpoints AND files written by the reference's own ``save_model`` (``checkpoint.py``)."""
+        from .. import checkpoint as ckpt
+        ck = ckpt.load_checkpoint(load_path, dev_of_saved_model)
+        ref = ckpt.is_reference_format(ck)
+        ckpt.check_architecture(ckpt.config_dict(ck), self.config)
         self._family.reset_state()
         self.gen_model, self.disc_model = self._build_networks()
         import numpy as np
@@ -441,16 +460,47 @@ class ProGANLearner(GANLearner):
             self.disc_model.increase_scale()
         self.gen_model.load_state_dict(ck['gen_model_state_dict'])
         self.disc_model.load_state_dict(ck['disc_model_state_dict'])
-        self.gen_model.fade_in_phase = ck['alpha'] != 1
-        self.gen_model.alpha = ck['alpha']
+        fade = ck['alpha'] != 1
+        self.gen_model.fade_in_phase = fade
+        self.gen_model.alpha = ck['alpha'] if fade else 1
         self.gen_model.to(self.config.dev)
         self.disc_model.to(self.config.dev)
-        self.batch_size = self.config.bs_dict[self.gen_model.curr_res]
+        self.batch_size = ck.get('batch_size', self.config.bs_dict[self.gen_model.curr_res])
         self._make_arenas(first=True)
-        if ck.get('gen_model_lagged_state_dict') is not None and self.lagged_params is not None:
+        lag = ck.get('lagged_params') if ref else None
+        if lag is None and ck.get('gen_model_lagged_state_dict') is not None:
+            lag = ck['gen_model_lagged_state_dict']
+        if lag is not None and self.lagged_params is not None:
             with torch.no_grad():
-                for k, v in ck['gen_model_lagged_state_dict'].items():
+                for k, v in lag.items():
                     if k in self.lagged_params:
                         self.lagged_params[k].copy_(v.to(self.config.dev))
+        for attr in ('loss', 'gradient_penalty'):
+            if ck.get(attr) is not None:
+                setattr(self, attr, ck[attr])
         self._set_optimizer()
+        g_names = [k for k, _ in self.gen_model.named_parameters() if fade or k not in _EXCL_G]
+        d_names = [k for k, _ in self.disc_model.named_parameters() if fade or k not in _EXCL_D]
+        mg, md = ck.get('opt_gen_state_dict'), ck.get('opt_disc_state_dict')
+        if ref:
+            mg, md = ckpt.moments_from_torch_adam(mg, g_names), ckpt.moments_from_torch_adam(md, d_names)
+        if mg is not None and mg.get('exp_avg'):
+            self.opt_gen.import_moments(self.gen_model.named_parameters(), mg)
+            self.opt_disc.import_moments(self.disc_model.named_parameters(), md)
+        for k in ('sched_stop_step', 'curr_dataset_batch_num', 'curr_epoch_num', 'tot_num_epochs', 'curr_img_num',
+                  'curr_phase_num', 'not_trained_yet', 'latent_distribution'):
+            if ck.get(k) is not None:
+                setattr(self, k, ck[k])
+        if ck.get('nimg_transition_lst') is not None:
+            self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, self.config.bs_dict,
+                                       self.config.nimg_transition, self.config.num_disc_iters)
+            self.sched.restore(self.gen_model.curr_res, ck['curr_img_num'], ck['curr_phase_num'],
+                               ck['nimg_transition_lst'], self.gen_model.alpha,
+                               ck.get('progressively_grow', True))
+            self.sched.batch_size = self.batch_size
+            self._progressively_grow = self.sched.progressively_grow
+        self.beta = None
+        if self.config.use_ewma_gen:
+            self.beta = self.get_smoothing_ewma_beta(half_life=EWMA_SMOOTHING_HALFLIFE) \
+                if COMPUTE_EWMA_VIA_HALFLIFE else EWMA_SMOOTHING_BETA
         self.pretrained_model = True

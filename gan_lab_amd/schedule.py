@@ -86,3 +86,19 @@ class PhaseSchedule(object):
                 self.alpha = 1
             else:
                 self.alpha = new_alpha
+
+    # -- checkpoint / resume ----------------------------------------------------------------------
+    def restore(self, curr_res, curr_img_num, curr_phase_num, nimg_transition_lst, alpha, progressively_grow=True):
+        """Put the machine into a saved state (the fields ``save_model`` keeps, progan/learner.py:1261-1297)."""
+        self.curr_res = int(curr_res)
+        self.batch_size = self.bs_dict[self.curr_res]
+        self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.batch_size)
+        self.nimg_transition_lst = [math.inf if (x is None or x < 0 or x == math.inf) else x
+                                    for x in nimg_transition_lst]
+        self.curr_img_num, self.curr_phase_num = int(curr_img_num), int(curr_phase_num)
+        self.progressively_grow = bool(progressively_grow)
+        self.fade_in_phase = alpha != 1
+        self.alpha = alpha if self.fade_in_phase else 1
+        self.delta_alpha = delta_alpha(self.batch_size, self.nimg_transition, self.num_disc_iters) \
+            if self.fade_in_phase else None
+        return self

@@ -28,6 +28,22 @@ class _Anything:
         return x
 
 
+class IndexedOrderedDict(OrderedDict):
+    """list-returning .values()/.keys() like the `indexed` package (progan/learner.py:228,472); lives at module
+    level under the package's own name so that the reference's save_model can pickle it as
+    ``indexed.IndexedOrderedDict`` exactly like a real installation would."""
+
+    def values(self):
+        return list(super().values())
+
+    def keys(self):
+        return list(super().keys())
+
+
+IndexedOrderedDict.__module__ = 'indexed'
+IndexedOrderedDict.__qualname__ = 'IndexedOrderedDict'
+
+
 def _mk(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -57,15 +73,6 @@ def install_stubs():
                 DatasetFolder=folder.DatasetFolder, ImageFolder=folder.ImageFolder)
     tv = _mk('torchvision', transforms=tfm, datasets=dsets, _ganlab_stub=True)
     tv.__path__ = []
-
-    class IndexedOrderedDict(OrderedDict):
-        """list-returning .values()/.keys() like the `indexed` package (progan/learner.py:228,472)."""
-
-        def values(self):
-            return list(super().values())
-
-        def keys(self):
-            return list(super().keys())
 
     _mk('indexed', IndexedOrderedDict=IndexedOrderedDict)
 

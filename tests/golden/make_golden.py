@@ -424,10 +424,8 @@ class _FakeDL:
             i += bs
 
 
-def golden_schedule():
-    """Host-logic trace of the REAL reference ProGANLearner.train over a 4 -> 8 -> 16 schedule
-    (BASELINE config #1 shape: 64 random images, batch 4): per main iteration the resolution, phase,
-    alpha, batch size and LR seen by the G-step, plus phase bookkeeping at the end."""
+def _ref_progan_setup(num_main_iters=40):
+    """Namespace + pickled config files the reference's ProGANLearner needs (temp HOME)."""
     import argparse as ap
     from pathlib import Path
     from PIL import Image
@@ -443,7 +441,7 @@ def golden_schedule():
         lr_fctr_dict={4: 1, 8: 1.25, 16: 1.5, 32: 1, 64: 1, 128: 1.5, 256: 2, 512: 3, 1024: 3},
         batch_size=bs, bs_dict={4: bs, 8: bs, 16: bs // 2, 32: bs, 64: bs, 128: bs, 256: bs, 512: bs // 2,
                                 1024: bs // 4},
-        nimg_transition=22, num_main_iters=40, res_samples=16, res_dataset=16, init_res=4,
+        nimg_transition=22, num_main_iters=num_main_iters, res_samples=16, res_dataset=16, init_res=4,
         model_upsample_type='nearest', model_downsample_type='average', align_corners=False,
         blur_type='binomial', bit_exact_resampling=False, nonlinearity='leaky relu', leakiness=.2,
         use_equalized_lr=True, normalize_z=True, len_latent=LEN_LATENT, latent_distribution='normal',
@@ -461,6 +459,73 @@ def golden_schedule():
         pickle.dump(cfg, f)
     with open(os.path.join(tmp, '.data_config.p'), 'wb') as f:
         pickle.dump(dcfg, f)
+    return cfg, bs
+
+
+def golden_checkpoint():
+    """A checkpoint file written by the REAL reference ``ProGANLearner.save_model`` (progan/learner.py:1238-1298)
+    after 9 main iterations of its own ``train`` (4x4 stabilised -> 8x8 mid fade-in), plus what a loader must
+    reproduce from it: generator / EWMA-generator / critic outputs on fixed inputs, and the critic parameters
+    after ONE more Adam step taken with the restored optimiser state."""
+    cfg, bs = _ref_progan_setup(num_main_iters=9)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    learner = ns.pl.ProGANLearner(cfg)
+    import torchvision.transforms as tvt
+    gen = torch.Generator().manual_seed(7)
+    dl = _FakeDL(64, bs, 4, tvt.Resize, gen)
+    learner.train(dl, num_main_iters=cfg.num_main_iters)
+    learner.valid_z = torch.zeros(16, LEN_LATENT)          # save_model() dereferences it (:1281)
+    path = os.path.join(HERE, 'ref_progan_ckpt.tar')
+    learner.save_model(path)
+    print(f'wrote ref_progan_ckpt.tar: {os.path.getsize(path) / 1024:.1f} KiB')
+    g, d = learner.gen_model, learner.disc_model
+    res = g.curr_res
+    z = torch.randn(4, LEN_LATENT, generator=gen)
+    real = torch.rand(4, 3, res, res, generator=gen) * 2 - 1
+    out = dict(z=T(z), real=T(real), curr_res=np.int64(res), alpha=np.float64(g.alpha),
+               fade_in=np.bool_(g.fade_in_phase), curr_img_num=np.int64(learner.curr_img_num),
+               curr_phase_num=np.int64(learner.curr_phase_num), batch_size=np.int64(learner.batch_size),
+               lr_gen=np.float64(learner.opt_gen.param_groups[0]['lr']),
+               nimg_transition_lst=np.array([x if np.isfinite(x) else -1 for x in learner.nimg_transition_lst],
+                                            dtype=np.float64))
+    g.eval()
+    with torch.no_grad():
+        out['img'] = T(g(z))
+        learner._update_gen_lagged()
+        learner.gen_model_lagged.eval()
+        out['img_lagged'] = T(learner.gen_model_lagged(z))
+    g.train()
+    with torch.no_grad():
+        fake = g(z)
+    out['fake_train'] = T(fake)
+    for p in d.parameters():
+        p.requires_grad_(True)
+    d.zero_grad()
+    if g.fade_in_phase:   # the D-step fades the reals in like the generator (progan/learner.py:771-779)
+        with torch.no_grad():
+            real = F.interpolate(F.avg_pool2d(real, kernel_size=2, stride=2), scale_factor=2, mode='nearest') * \
+                (1. - g.alpha) + real * g.alpha
+    d_fake, d_real = d(fake), d(real)
+    out.update(d_fake=T(d_fake), d_real=T(d_real))
+    torch.manual_seed(4321)
+    loss = (d_fake - d_real).mean() + ref_calc_gp(d, 'wgan-gp', fake, real) + (d_real ** 2).mean() * 0.001
+    torch.manual_seed(4321)
+    out['eps_interp'] = T(torch.rand(4, 1, 1, 1))
+    out['loss_d'] = T(loss)
+    before = {k: v.detach().clone() for k, v in d.named_parameters()}
+    loss.backward()
+    learner.opt_disc.step()
+    out.update({'dd.' + k: T(v.detach() - before[k]) for k, v in d.named_parameters()})
+    out.update({'gd.' + k: T(v.grad) for k, v in d.named_parameters() if v.grad is not None})
+    save('ref_progan_ckpt_expect.npz', **out)
+
+
+def golden_schedule():
+    """Host-logic trace of the REAL reference ProGANLearner.train over a 4 -> 8 -> 16 schedule
+    (BASELINE config #1 shape: 64 random images, batch 4): per main iteration the resolution, phase,
+    alpha, batch size and LR seen by the G-step, plus phase bookkeeping at the end."""
+    cfg, bs = _ref_progan_setup(num_main_iters=40)
     torch.manual_seed(0)
     np.random.seed(0)
     learner = ns.pl.ProGANLearner(cfg)
@@ -661,6 +726,7 @@ if __name__ == '__main__':
         'step_pg': lambda: golden_step('progan', 8, 'step_progan8', 'wgan', 'wgan-gp'),
         'schedule': golden_schedule,
         'data': golden_data,
+        'checkpoint': golden_checkpoint,
         'resnet64': lambda: golden_resnet(64, 'resnet64', fmap_g=2, fmap_d=2),
         'resnet32': lambda: golden_resnet(32, 'resnet32', fmap_g=8, fmap_d=8),
     }

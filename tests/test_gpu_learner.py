@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_close, load_golden, sub, t
+from util import assert_close, load_golden, rel_err, sub, t
 
 pytestmark = pytest.mark.gpu
 
@@ -120,3 +120,74 @@ def test_train_loop_grows_and_stays_finite(kind):
     assert keys == [k for k, _ in L.gen_model.named_parameters()]
     L.train(dl, num_main_iters=2)            # re-entrant: continues in the final phase
     assert L.gen_model.curr_res == 16
+
+
+def test_load_reference_written_checkpoint(tmp_path):
+    """tests/golden/ref_progan_ckpt.tar was written by the reference's own ProGANLearner.save_model after 9 main
+    iterations (4x4 -> 8x8, mid fade-in).  Loading it must reproduce the reference's generator / EWMA generator /
+    critic outputs, its next critic Adam step, and resume the phase machine where it stopped."""
+    import os
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.progan.learner import ProGANLearner
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    here = os.path.join(os.path.dirname(__file__), 'golden')
+    E = load_golden('ref_progan_ckpt_expect.npz')
+    bs = 4
+    cfg = make_config('progan', dev='cuda', pin_memory=False, res_samples=16, res_dataset=16, init_res=4, batch_size=bs,
+                      len_latent=16, nimg_transition=22, num_iters_save_model=10 ** 9, log_every=1,
+                      bs_dict={4: bs, 8: bs, 16: bs // 2, 32: bs, 64: bs, 128: bs, 256: bs, 512: bs // 2,
+                               1024: bs // 4})
+    cfg.lr_fctr_dict = {4: 1, 8: 1.25, 16: 1.5, 32: 1, 64: 1, 128: 1.5, 256: 2, 512: 3, 1024: 3}
+    L = ProGANLearner(cfg)
+    L.load_model(os.path.join(here, 'ref_progan_ckpt.tar'))
+    assert L.gen_model.curr_res == int(E['curr_res']) == 8 and L.gen_model.fade_in_phase
+    assert abs(L.gen_model.alpha - float(E['alpha'])) < 1e-12
+    assert L.curr_img_num == int(E['curr_img_num']) and L.curr_phase_num == int(E['curr_phase_num'])
+    assert L.batch_size == int(E['batch_size']) and L.pretrained_model and not L.not_trained_yet
+    z, real = t(E['z']).cuda(), t(E['real']).cuda()
+    L.gen_model.eval()
+    with torch.no_grad():
+        assert_close(L.gen_model(z).cpu(), E['img'], 1e-3, 'G(z) eval')
+        lag = L.materialize_lagged_generator().eval()
+        assert_close(lag(z).cpu(), E['img_lagged'], 1e-3, 'EWMA G(z) eval')
+    L.gen_model.train()
+    L.disc_model.train()
+    with torch.no_grad():
+        assert_close(L.gen_model(z).cpu(), E['fake_train'], 1e-3, 'G(z) train')
+    # the next critic step, on the reference's own latents, reals and interpolation draw
+    before = {k: v.detach().clone() for k, v in L.disc_model.named_parameters()}
+    L.set_requires_grad_disc(True)
+    ld = L.d_step(real, zb=z, eps_interp=t(E['eps_interp']).cuda())
+    assert_close(ld.cpu(), E['loss_d'], 2e-3, 'loss_d')
+    n = 0
+    for k, p in L.disc_model.named_parameters():
+        if 'gd.' + k not in E:
+            continue
+        gref = t(E['gd.' + k])
+        m = gref.abs() > 1e-3 * gref.abs().max()
+        du, dref = (p.detach() - before[k]).cpu(), t(E['dd.' + k])
+        bad = (du[m] - dref[m]).abs() > 3e-2 * dref.abs().max()
+        assert bad.float().mean() <= 5e-3, k
+        n += int(m.sum())
+    assert n > 1000
+    # resume: the phase machine continues into stabilisation and the 16x16 growth
+    dl = SyntheticImageLoader(4096, 4, 4)
+    L.train(dl, num_main_iters=14)
+    assert L.gen_model.curr_res == 16 and dl.served[0] == (4, 8) and dl.served[-1] == (2, 16)
+    assert np.isfinite(L.last_losses['loss_d'])
+    # and this package's own checkpoint round-trips (Adam moments included)
+    path = tmp_path / 'progan_model.tar'
+    L.save_model(path)
+    L2 = ProGANLearner(cfg)
+    L2.load_model(path)
+    assert L2.gen_model.curr_res == 16 and L2.curr_img_num == L.curr_img_num
+    for a, b in ((L.arena_g, L2.arena_g), (L.arena_d, L2.arena_d)):
+        assert torch.equal(a.flat, b.flat)
+    x = (torch.rand(2, 3, 16, 16) * 2 - 1).cuda()
+    z2, e2 = torch.randn(2, 16).cuda(), torch.rand(2, 1, 1, 1).cuda()
+    L2.opt_disc.param_groups[0]['lr'] = L.opt_disc.param_groups[0]['lr']    # train() would set it (LambdaLR)
+    for lr in (L, L2):
+        lr.disc_model.train()
+        lr.set_requires_grad_disc(True)
+        lr.d_step(x, zb=z2, eps_interp=e2)
+    assert rel_err(L2.arena_d.flat.cpu(), L.arena_d.flat.cpu()) < 1e-6

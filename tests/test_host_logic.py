@@ -153,3 +153,69 @@ def test_resnet_state_dict_layout_matches_reference(res):
     for pre, m in (('g0.', g), ('d0.', d)):
         ref = [(k[3:], G[k].shape) for k in G.files if k.startswith(pre)]
         assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == ref
+
+
+def test_reference_checkpoint_reads_without_the_reference():
+    """A file written by the reference's own save_model (tests/golden/ref_progan_ckpt.tar, made by
+    make_golden.py) unpickles with the two foreign classes mapped onto local stand-ins."""
+    import os
+    import sys
+    import torch
+    from gan_lab_amd import checkpoint as ckpt
+    assert not any('reference' in p for p in sys.path)
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'ref_progan_ckpt.tar')
+    ck = ckpt.load_checkpoint(path)
+    assert ckpt.is_reference_format(ck)
+    cfg = ckpt.config_dict(ck)
+    assert cfg['model'] == 'ProGAN' and cfg['res_samples'] == 16 and cfg['len_latent'] == 16
+    assert ck['curr_res'] == 8 and 0 < ck['alpha'] < 1
+    assert isinstance(ck['lagged_params'], dict) and isinstance(ck['lagged_params'].keys(), list)
+    g_names = list(ck['gen_model_state_dict'].keys())
+    assert list(ck['lagged_params'].keys()) == g_names
+    # the reference re-creates its optimisers right before every save (progan/learner.py:963, :992, :1018), so
+    # a reference checkpoint always carries a fresh Adam: all parameters listed (fade-in), no moments yet
+    m = ckpt.moments_from_torch_adam(ck['opt_gen_state_dict'], g_names)
+    assert m['step'] == 0 and not m['exp_avg']
+    assert isinstance(ck['nl'], torch.nn.LeakyReLU)
+    with pytest.raises(ValueError):
+        ckpt.moments_from_torch_adam(ck['opt_gen_state_dict'], g_names[:-2])
+    # the translation itself, on a torch Adam that has stepped
+    ps = {'a.weight': torch.nn.Parameter(torch.randn(3, 4)), 'b.bias': torch.nn.Parameter(torch.randn(5))}
+    opt = torch.optim.Adam(ps.values(), lr=1e-3, betas=(0., .99))
+    for _ in range(3):
+        opt.zero_grad()
+        (ps['a.weight'].sum() ** 2 + (ps['b.bias'] ** 2).sum()).backward()
+        opt.step()
+    m = ckpt.moments_from_torch_adam(opt.state_dict(), list(ps))
+    assert m['step'] == 3
+    for k, p in ps.items():
+        assert torch.equal(m['exp_avg'][k], opt.state[p]['exp_avg']) and \
+            torch.equal(m['exp_avg_sq'][k], opt.state[p]['exp_avg_sq'])
+    ns = type('C', (), dict(cfg))()
+    ckpt.check_architecture(cfg, ns)
+    ns.len_latent = 512
+    with pytest.raises(ValueError):
+        ckpt.check_architecture(cfg, ns)
+
+
+def test_phase_schedule_restore_continues_identically():
+    from gan_lab_amd.schedule import PhaseSchedule
+    bs = {4: 4, 8: 4, 16: 2, 32: 2}
+
+    def run(s, n, log):
+        for _ in range(n):
+            ev = s.begin_iter()
+            s.after_d_iter()
+            s.end_iter()
+            log.append((tuple(ev), s.curr_res, s.batch_size, s.fade_in_phase, round(float(s.alpha), 12), s.curr_img_num))
+
+    full, log_full = PhaseSchedule(4, 32, bs, 22), []
+    run(full, 60, log_full)
+    for k in (3, 9, 14, 27, 41):
+        a, la = PhaseSchedule(4, 32, bs, 22), []
+        run(a, k, la)
+        b = PhaseSchedule(4, 32, bs, 22).restore(a.curr_res, a.curr_img_num, a.curr_phase_num,
+                                                 list(a.nimg_transition_lst), a.alpha, a.progressively_grow)
+        lb = []
+        run(b, 60 - k, lb)
+        assert la + lb == log_full, k
