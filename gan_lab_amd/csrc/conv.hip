@@ -102,6 +102,46 @@ struct XStage {
       loff[i] = l;
     }
   }
+
+  // Strip variant (forward kernel walks several tiles along x): goff holds ci*plane + vy*Wi (or -1 when the
+  // item is padding in y / n / past the item count) and xq the item's column relative to the tile origin
+  // (in units of the source: low-res columns for XVECUP); the x coordinate and its bounds test are applied
+  // per tile in x_load_strip.
+  __device__ __forceinline__ void init_strip(const PatchArgs& p, int tid, int n0, int oy0) {
+    const int plane = p.Hi * p.Wi;
+    n0_ = n0; oy0_ = oy0; ox0_ = 0;
+    if (G::XMODE == XSCALAR) return;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int e = tid + i * 256;
+      int g = -1, l = 0;
+      if (G::XMODE == XVEC) {
+        const int q = e % G::ROW4;
+        int t = e / G::ROW4;
+        const int r = t % G::R, ci = t / G::R;
+        const int vy = oy0 + r - G::PADC;
+        l = (ci * PLANE + r * G::RP + 4 * q) | (ci << 20);
+        if (e < NITEMS && n0 < p.N && (unsigned)vy < (unsigned)p.Hi) g = ci * plane + vy * p.Wi;
+      } else {
+        const int q = e % G::LROW4;
+        int t = e / G::LROW4;
+        const int lr = t % G::LR, ci = t / G::LR;
+        const int ly = (oy0 >> 1) - 1 + lr;
+        l = (ci * PLANE + (2 * lr) * G::RP + 8 * q) | (ci << 20);
+        if (lr > 0) l |= (1 << 30);
+        if (2 * lr < G::R) l |= (1 << 31);
+        if (e < NITEMS && n0 < p.N && (unsigned)ly < (unsigned)p.Hi) g = ci * plane + ly * p.Wi;
+        else if (e >= NITEMS) l &= ~((1 << 30) | (1 << 31));
+      }
+      goff[i] = g;
+      loff[i] = l;
+    }
+  }
+  // column of item i relative to the tile origin, in source units (re-derived: cheaper than 7 live registers)
+  static __device__ __forceinline__ int xq_of(int tid, int i) {
+    const int e = tid + i * 256;
+    return G::XMODE == XVEC ? 4 * (e % G::ROW4) - G::LP : 4 * (e % G::LROW4) - G::LP / 2;
+  }
 };
 
 // registers holding one staged chunk of the activation patch
@@ -121,6 +161,23 @@ __device__ __forceinline__ void x_load(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r, 
     const int ci = (st.loff[i] >> 20) & 0x3ff;
     const bool ok = st.goff[i] >= 0 && ci0 + ci < Cin;
     r.v[i] = ok ? *reinterpret_cast<const float4*>(src + st.goff[i]) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// strip variant: `xbase` = tile origin column in source units (ox0, or ox0/2 for the folded upsample)
+template <class G, int CI_T, int PLANE>
+__device__ __forceinline__ void x_load_strip(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
+                                             const XStage<G, CI_T, PLANE>& st, const float* xb, int ci0, int Cin,
+                                             int plane, int xbase, int Wi, int tid) {
+  constexpr int PT = XStage<G, CI_T, PLANE>::PT;
+  if (G::XMODE == XSCALAR) return;
+  const float* src = xb + (long long)ci0 * plane;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int ci = (st.loff[i] >> 20) & 0x3ff;
+    const int vx = xbase + XStage<G, CI_T, PLANE>::xq_of(tid, i);
+    const bool ok = st.goff[i] >= 0 && ci0 + ci < Cin && (unsigned)vx < (unsigned)Wi;
+    r.v[i] = ok ? *reinterpret_cast<const float4*>(src + st.goff[i] + vx) : float4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -205,6 +262,7 @@ struct ConvArgs {
   int Cout, Ho, Wo;
   int Cin_p, Cout_p;   // packed-weight dims: wp[tap][Cin_p][Cout_p]
   int tiles_x, tiles_y, tiles_n, tiles_co;
+  int strip, strips_x;   // each workgroup walks `strip` consecutive tiles along x
   float bias_scale, slope;
   int act;
 };
@@ -222,9 +280,208 @@ struct FwdCfg {
   static constexpr int XS = CI_T * PLANE, WS = KK * CI_T * COP;
   static constexpr int NWI = KK * CI_T * CO_T / 4;  // float4 weight items per chunk
   static constexpr int WPT = ceil_div_c(NWI, 256);
+  static constexpr bool STRIP = MB_ == 1 && XMODE_ != XSCALAR;
   static_assert(NB >= 1, "pixel tile too small");
 };
 
+#ifdef GL_PHASES  // tools/phase_probe.py: per-workgroup phase timestamps (debug builds only)
+__device__ unsigned long long* gl_phase_buf;
+#define GL_T(i) \
+  if (threadIdx.x == 0) gl_phase_buf[(long long)blockIdx.x * 8 + (i)] = wall_clock64();
+// accumulated phase times over the tiles of a strip (slots 4..7)
+#define GL_ACC_DECL unsigned long long gl_t_prev = wall_clock64(), gl_acc[4] = {0, 0, 0, 0};
+#define GL_ACC(i)                                   \
+  {                                                 \
+    const unsigned long long gl_now = wall_clock64(); \
+    gl_acc[i] += gl_now - gl_t_prev;                \
+    gl_t_prev = gl_now;                             \
+  }
+#define GL_ACC_FLUSH \
+  if (threadIdx.x == 0)                            \
+    for (int gl_i = 0; gl_i < 4; ++gl_i) gl_phase_buf[(long long)blockIdx.x * 8 + 4 + gl_i] = gl_acc[gl_i];
+#else
+#define GL_T(i)
+#define GL_ACC_DECL
+#define GL_ACC(i)
+#define GL_ACC_FLUSH
+#endif
+
+template <class Cfg>
+__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_strip_kernel(ConvArgs p) {
+  GL_T(0)
+  // strips only where they pay and fit the register budget: thin layers (<= 32 output channels per workgroup)
+  constexpr bool STRIP = Cfg::STRIP;
+  using G = typename Cfg::G;
+  constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
+  constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
+  constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, WPT = Cfg::WPT, NWI = Cfg::NWI;
+  using XS_t = XStage<G, CI_T, PLANE>;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  float* Xs = smem;
+  float* Ws = smem + Cfg::XS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_t = bid % p.tiles_co;
+  bid /= p.tiles_co;
+  const int sxi = bid % p.strips_x;
+  bid /= p.strips_x;
+  const int tyi = bid % p.tiles_y;
+  const int tni = bid / p.tiles_y;
+  int txi = STRIP ? sxi * p.strip : sxi;                     // the strip: tiles txi .. tx_end-1 of this tile row
+  const int tx_end = STRIP ? min(txi + p.strip, p.tiles_x) : txi + 1;
+  const int co0 = co_t * CO_T, oy0 = tyi * TH, n0 = tni * NI;
+  int ox0 = txi * TW;
+  const int plane = p.in.Hi * p.in.Wi;
+  const float* xb = p.in.x + (long long)n0 * p.in.Cin * plane;
+
+  // ---- staging descriptors (independent of the K-chunk and of the tile within the strip) ----
+  XS_t xst;
+  xst.init_strip(p.in, tid, n0, oy0);
+  int wg[WPT], wl[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int c4 = e % (CO_T / 4);
+    const int t = e / (CO_T / 4);
+    const int ci = t % CI_T, tap = t / CI_T;
+    wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
+    wg[i] = e < NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
+  }
+  // ---- per-lane MFMA operand offsets ----
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    boff[nb] = ni * IMG + ty * RP + tx + G::XOFF + (lane >> 4) * PLANE;
+  }
+  const int aoff = (lane >> 4) * COP + (lane & 15);
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias of this lane's output channels: loaded once, ahead of the strip loop - a global load inside the
+  // epilogue would drain (vmcnt) the prefetched patch of the next tile on every tile
+  float bv[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+      bv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+    }
+  XRegs<G, XS_t::PT> xr;
+  float4 wr[WPT];
+  auto load_w = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+                         : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto xbase_of = [&](int ox) { return G::XMODE == XVECUP ? (ox >> 1) : ox; };
+  const bool one_chunk = p.Cin_p <= CI_T;   // the weight slab then stays in LDS for the whole strip
+  x_load_strip<G, CI_T, PLANE>(xr, xst, xb, 0, p.in.Cin, plane, xbase_of(ox0), p.in.Wi, tid);
+  load_w(0);
+  bool w_staged = false;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+
+  // Items = (tile of the strip, K-chunk).  While the MFMAs of one item run, the loads of the next one
+  // (next chunk of this tile, or the first chunk of the next tile) are already in flight into registers.
+  int ci0 = 0;
+  GL_ACC_DECL
+  while (true) {
+    __syncthreads();  // every wave is done reading the previous item
+    GL_ACC(0)
+    if (G::XMODE == XSCALAR) {
+      xst.ox0_ = ox0;
+      x_stage_scalar<G, CI_T, PLANE>(xst, p.in, xb, ci0, Xs, tid);
+    } else {
+      x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
+    }
+    if (!(one_chunk && w_staged)) {
+#pragma unroll
+      for (int i = 0; i < WPT; ++i)
+        if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
+      w_staged = true;
+    }
+    __syncthreads();
+    GL_T(1)
+    GL_ACC(1)
+    const bool last_chunk = ci0 + CI_T >= p.Cin_p;
+    const int nci0 = last_chunk ? 0 : ci0 + CI_T;
+    const int nox0 = last_chunk ? ox0 + TW : ox0;
+    if (!last_chunk || (STRIP && txi + 1 < tx_end)) {  // prefetch the next item
+      x_load_strip<G, CI_T, PLANE>(xr, xst, xb, nci0, p.in.Cin, plane, xbase_of(nox0), p.in.Wi, tid);
+      if (!one_chunk) load_w(nci0);
+    }
+    // K-steps = (ky, kx, 4-channel group), fully unrolled with immediate LDS offsets.  With one 16-channel
+    // output block per workgroup every MFMA needs 1.25 LDS reads, so the loop is bound by LDS latency unless
+    // the operand reads run well ahead: a ring of PD+1 register sets keeps PD steps of reads in flight.
+    {
+      constexpr int C4N = CI_T / 4, NSTEP = KK * C4N, PD = 3;
+      float ra[PD + 1][MB], rb[PD + 1][NB];
+      auto fetch = [&](int st, int slot) {
+        const int ky = st / (KS * C4N), kx = (st / C4N) % KS, c4 = st % C4N;
+        const float* wrow = Ws + ky * (KS * CI_T * COP) + aoff + (kx * CI_T + c4 * 4) * COP;
+        const float* xrow = Xs + ky * RP + c4 * 4 * PLANE + kx;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) ra[slot][mb] = wrow[mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) rb[slot][nb] = xrow[boff[nb]];
+      };
+#pragma unroll
+      for (int st = 0; st < PD && st < NSTEP; ++st) fetch(st, st % (PD + 1));
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + PD < NSTEP) fetch(st + PD, (st + PD) % (PD + 1));
+        const int slot = st % (PD + 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][mb], rb[slot][nb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep "reads PD steps ahead, then this step's MFMAs" as written
+      }
+    }
+    if (last_chunk) {
+      // ---- epilogue of this tile: + bias, activation, NCHW store; reset the accumulators ----
+      GL_T(2)
+      GL_ACC(2)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+        const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+        const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
+        const bool inb = n < p.in.N && oy < p.Ho && ox < p.Wo;
+        float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * out_plane + (long long)oy * p.Wo + ox;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
+            if (inb && co < p.Cout) {
+              float v = acc[mb][nb][r] + bv[mb][r];
+              if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+              dst[(long long)(mb * 16 + r) * out_plane] = v;
+            }
+          }
+          acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      GL_ACC(3)
+      if (++txi >= tx_end) break;
+    }
+    ci0 = nci0;
+    ox0 = nox0;
+  }
+  GL_ACC_FLUSH
+  GL_T(3)
+}
+
+// One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
+// has no room for the strip bookkeeping).
 template <class Cfg>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
@@ -576,9 +833,21 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
   a.tiles_y = ceil_div(a.Ho, G::TH);
   a.tiles_n = ceil_div(a.in.N, G::NI);
   a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
-  const long long grid = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+  // Strips: a workgroup walks `strip` consecutive tiles of one tile row, prefetching the next tile while the
+  // MFMAs of the current one run.  Only where there are plenty of tiles (thin, large layers): keep >= ~8
+  // rounds of 3 workgroups per CU in the grid, and split the row evenly.
+  const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+  int k = a.tiles_x;                         // strips per tile row (tiles_x: one tile per workgroup)
+  if (Cfg::STRIP) {
+    k = 1;
+    while (k < a.tiles_x && tiles / ceil_div(a.tiles_x, k) < 6144) ++k;
+  }
+  a.strip = ceil_div(a.tiles_x, k);
+  a.strips_x = ceil_div(a.tiles_x, a.strip);
+  const long long grid = (long long)a.strips_x * a.tiles_y * a.tiles_n * a.tiles_co;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if constexpr (Cfg::STRIP) GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -752,6 +1021,13 @@ bool geom_ok(const ganlab_conv_geom* g) {
 }
 
 }  // namespace
+
+#ifdef GL_PHASES
+extern "C" int ganlab_dbg_set_phase_buf(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gl_phase_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 
 extern "C" {
 
