@@ -181,6 +181,27 @@ __device__ __forceinline__ void x_load_strip(XRegs<G, XStage<G, CI_T, PLANE>::PT
   }
 }
 
+// Buffer-descriptor variant: `rsrc` spans the Cin*plane floats of this workgroup's image, so channel padding
+// (ci >= Cin) falls outside the descriptor and reads as 0 in hardware; rows / columns in the zero padding get an
+// out-of-range offset.  No exec-mask branches: ~6 instructions per float4 instead of ~20.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <class G, int CI_T, int PLANE>
+__device__ __forceinline__ void x_load_buf(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
+                                           const XStage<G, CI_T, PLANE>& st, __amdgpu_buffer_rsrc_t rsrc, int ci0,
+                                           int plane, int xbase, int Wi, int tid) {
+  constexpr int PT = XStage<G, CI_T, PLANE>::PT;
+  if (G::XMODE == XSCALAR) return;
+  const int soff = ci0 * plane * 4;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int vx = xbase + XStage<G, CI_T, PLANE>::xq_of(tid, i);
+    const bool ok = st.goff[i] >= 0 && (unsigned)vx < (unsigned)Wi;
+    const int off = ok ? (st.goff[i] + vx) * 4 : (int)0x80000000;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);
+    r.v[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  }
+}
+
 // Per-element staging for ragged / tiny shapes: global -> LDS in batches of 8 independent loads.
 template <class G, int CI_T, int PLANE>
 __device__ __forceinline__ void x_stage_scalar(const XStage<G, CI_T, PLANE>& st, const PatchArgs& p,
@@ -306,17 +327,23 @@ __device__ unsigned long long* gl_phase_buf;
 #define GL_ACC_FLUSH
 #endif
 
+// Strip kernel for thin layers (one 16-channel output block, ONE K-chunk: Cin_p == CI_T, full tiles - the host
+// checks): a workgroup walks `strip` tiles of one tile row.  Per tile and wave exactly PT buffer loads (the next
+// tile's patch, hardware zero-fill at the borders) and 4*NB buffer stores are issued, unconditionally, so the
+// compiler's vmcnt bookkeeping stays exact across the loop: the wait for the prefetched patch does not drain the
+// stores of the tile that was just written.  The weight slab is staged in LDS once per strip.
 template <class Cfg>
-__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_strip_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
   GL_T(0)
-  // strips only where they pay and fit the register budget: thin layers (<= 32 output channels per workgroup)
-  constexpr bool STRIP = Cfg::STRIP;
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
-  constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, WPT = Cfg::WPT, NWI = Cfg::NWI;
+  constexpr int TW = G::TW, TH = G::TH, CO_T = Cfg::CO_T, WPT = Cfg::WPT, NWI = Cfg::NWI;
+  static_assert(MB == 1 && G::NI == 1 && G::XMODE != XSCALAR, "strip kernel: thin vector-staged layers only");
   using XS_t = XStage<G, CI_T, PLANE>;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  // LDS is padded to > 160 KB / 4 so that at most 3 workgroups share a CU (a 4th only adds DRAM-page and L2 churn)
+  constexpr int SMEM = (Cfg::XS + Cfg::WS) > 10496 ? (Cfg::XS + Cfg::WS) : 10496;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* Xs = smem;
   float* Ws = smem + Cfg::XS;
 
@@ -327,107 +354,80 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
   const int sxi = bid % p.strips_x;
   bid /= p.strips_x;
   const int tyi = bid % p.tiles_y;
-  const int tni = bid / p.tiles_y;
-  int txi = STRIP ? sxi * p.strip : sxi;                     // the strip: tiles txi .. tx_end-1 of this tile row
-  const int tx_end = STRIP ? min(txi + p.strip, p.tiles_x) : txi + 1;
-  const int co0 = co_t * CO_T, oy0 = tyi * TH, n0 = tni * NI;
-  int ox0 = txi * TW;
+  const int n0 = bid / p.tiles_y;
+  const int tx0 = sxi * p.strip;
+  const int ntiles = min(p.strip, p.tiles_x - tx0);
+  const int co0 = co_t * CO_T, oy0 = tyi * TH;
   const int plane = p.in.Hi * p.in.Wi;
   const float* xb = p.in.x + (long long)n0 * p.in.Cin * plane;
 
-  // ---- staging descriptors (independent of the K-chunk and of the tile within the strip) ----
   XS_t xst;
   xst.init_strip(p.in, tid, n0, oy0);
-  int wg[WPT], wl[WPT];
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    boff[nb] = ty * RP + tx + G::XOFF + (lane >> 4) * PLANE;
+  }
+  const int aoff = (lane >> 4) * COP + (lane & 15);
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = co0 + (lane >> 4) * 4 + r;
+    bv[r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+  }
+  // weight slab -> LDS (once)
 #pragma unroll
   for (int i = 0; i < WPT; ++i) {
     const int e = tid + i * 256;
     const int c4 = e % (CO_T / 4);
     const int t = e / (CO_T / 4);
     const int ci = t % CI_T, tap = t / CI_T;
-    wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
-    wg[i] = e < NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
+    if (e < NWI)
+      *reinterpret_cast<float4*>(Ws + (tap * CI_T + ci) * COP + 4 * c4) =
+          *reinterpret_cast<const float4*>(p.wp + (long long)(tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4);
   }
-  // ---- per-lane MFMA operand offsets ----
-  int boff[NB];
+  // buffer descriptors (wave-uniform by construction: kernel arguments and blockIdx only)
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (long long)n0 * p.Cout * out_plane, 0, (unsigned)(p.Cout * out_plane * 4), 0x00020000);
+  int vo_lane[NB];   // byte offset of this lane's pixel (tile at x = 0) in channel co0 + 4*(lane>>4)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
-    const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
-    boff[nb] = ni * IMG + ty * RP + tx + G::XOFF + (lane >> 4) * PLANE;
+    const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    vo_lane[nb] = (int)(((long long)(co0 + (lane >> 4) * 4) * out_plane + (long long)(oy0 + ty) * p.Wo + tx) * 4);
   }
-  const int aoff = (lane >> 4) * COP + (lane & 15);
-  f32x4 acc[MB][NB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias of this lane's output channels: loaded once, ahead of the strip loop - a global load inside the
-  // epilogue would drain (vmcnt) the prefetched patch of the next tile on every tile
-  float bv[MB][4];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
-      bv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
-    }
-  XRegs<G, XS_t::PT> xr;
-  float4 wr[WPT];
-  auto load_w = [&](int ci0) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
-                         : float4{0.f, 0.f, 0.f, 0.f};
-  };
   auto xbase_of = [&](int ox) { return G::XMODE == XVECUP ? (ox >> 1) : ox; };
-  const bool one_chunk = p.Cin_p <= CI_T;   // the weight slab then stays in LDS for the whole strip
-  x_load_strip<G, CI_T, PLANE>(xr, xst, xb, 0, p.in.Cin, plane, xbase_of(ox0), p.in.Wi, tid);
-  load_w(0);
-  bool w_staged = false;
-  const long long out_plane = (long long)p.Ho * p.Wo;
 
-  // Items = (tile of the strip, K-chunk).  While the MFMAs of one item run, the loads of the next one
-  // (next chunk of this tile, or the first chunk of the next tile) are already in flight into registers.
-  int ci0 = 0;
+  XRegs<G, XS_t::PT> xr;
+  int ox0 = tx0 * TW;
+  x_load_buf<G, CI_T, PLANE>(xr, xst, rs_in, 0, plane, xbase_of(ox0), p.in.Wi, tid);
+  x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
   GL_ACC_DECL
-  while (true) {
-    __syncthreads();  // every wave is done reading the previous item
-    GL_ACC(0)
-    if (G::XMODE == XSCALAR) {
-      xst.ox0_ = ox0;
-      x_stage_scalar<G, CI_T, PLANE>(xst, p.in, xb, ci0, Xs, tid);
-    } else {
-      x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
-    }
-    if (!(one_chunk && w_staged)) {
-#pragma unroll
-      for (int i = 0; i < WPT; ++i)
-        if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
-      w_staged = true;
-    }
-    __syncthreads();
+  for (int t = 0; t < ntiles; ++t, ox0 += TW) {
+    __syncthreads();  // the patch of tile t (and, first time round, the weight slab) is in LDS
     GL_T(1)
     GL_ACC(1)
-    const bool last_chunk = ci0 + CI_T >= p.Cin_p;
-    const int nci0 = last_chunk ? 0 : ci0 + CI_T;
-    const int nox0 = last_chunk ? ox0 + TW : ox0;
-    if (!last_chunk || (STRIP && txi + 1 < tx_end)) {  // prefetch the next item
-      x_load_strip<G, CI_T, PLANE>(xr, xst, xb, nci0, p.in.Cin, plane, xbase_of(nox0), p.in.Wi, tid);
-      if (!one_chunk) load_w(nci0);
-    }
+    // next tile's patch (past the end of the strip / row the offsets fall outside the descriptor: zeros, unused)
+    x_load_buf<G, CI_T, PLANE>(xr, xst, rs_in, 0, plane, t + 1 < ntiles ? xbase_of(ox0 + TW) : (1 << 28), p.in.Wi,
+                               tid);
     // K-steps = (ky, kx, 4-channel group), fully unrolled with immediate LDS offsets.  With one 16-channel
     // output block per workgroup every MFMA needs 1.25 LDS reads, so the loop is bound by LDS latency unless
     // the operand reads run well ahead: a ring of PD+1 register sets keeps PD steps of reads in flight.
     {
       constexpr int C4N = CI_T / 4, NSTEP = KK * C4N, PD = 3;
-      float ra[PD + 1][MB], rb[PD + 1][NB];
+      float ra[PD + 1], rb[PD + 1][NB];
       auto fetch = [&](int st, int slot) {
         const int ky = st / (KS * C4N), kx = (st / C4N) % KS, c4 = st % C4N;
-        const float* wrow = Ws + ky * (KS * CI_T * COP) + aoff + (kx * CI_T + c4 * 4) * COP;
+        ra[slot] = Ws[ky * (KS * CI_T * COP) + aoff + (kx * CI_T + c4 * 4) * COP];
         const float* xrow = Xs + ky * RP + c4 * 4 * PLANE + kx;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) ra[slot][mb] = wrow[mb * 16];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) rb[slot][nb] = xrow[boff[nb]];
       };
@@ -438,43 +438,31 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
         if (st + PD < NSTEP) fetch(st + PD, (st + PD) % (PD + 1));
         const int slot = st % (PD + 1);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][mb], rb[slot][nb], acc[mb][nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot], rb[slot][nb], acc[nb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep "reads PD steps ahead, then this step's MFMAs" as written
       }
     }
-    if (last_chunk) {
-      // ---- epilogue of this tile: + bias, activation, NCHW store; reset the accumulators ----
-      GL_T(2)
-      GL_ACC(2)
+    GL_T(2)
+    GL_ACC(2)
+    // epilogue: + bias, activation; the per-lane part of the address is fixed for the strip, the rest is an SGPR
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
-        const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
-        const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
-        const bool inb = n < p.in.N && oy < p.Ho && ox < p.Wo;
-        float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * out_plane + (long long)oy * p.Wo + ox;
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
-            if (inb && co < p.Cout) {
-              float v = acc[mb][nb][r] + bv[mb][r];
-              if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
-              dst[(long long)(mb * 16 + r) * out_plane] = v;
-            }
-          }
-          acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nb][r] + bv[r];
+        if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+        const int soff = (int)(((long long)r * out_plane + ox0) * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, vo_lane[nb], soff, 0);
       }
-      GL_ACC(3)
-      if (++txi >= tx_end) break;
+      acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    ci0 = nci0;
-    ox0 = nox0;
+    GL_ACC(3)
+    __syncthreads();  // every wave is done reading tile t's patch
+    GL_ACC(0)
+    // registers -> LDS for tile t+1.  Loads and stores above sit in this same straight-line block, so the wait
+    // emitted here is vmcnt(#stores): the prefetched patch, not the stores that were just issued.
+    x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
   }
   GL_ACC_FLUSH
   GL_T(3)
@@ -837,17 +825,24 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
   // MFMAs of the current one run.  Only where there are plenty of tiles (thin, large layers): keep >= ~8
   // rounds of 3 workgroups per CU in the grid, and split the row evenly.
   const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
-  int k = a.tiles_x;                         // strips per tile row (tiles_x: one tile per workgroup)
-  if (Cfg::STRIP) {
-    k = 1;
-    while (k < a.tiles_x && tiles / ceil_div(a.tiles_x, k) < 6144) ++k;
+  if constexpr (Cfg::STRIP) {
+    // the strip kernel takes full tiles, one K-chunk, whole 16-channel blocks and 31-bit byte offsets
+    const bool ok = a.Cin_p == Cfg::CI_T && a.Wo % G::TW == 0 && a.Ho % G::TH == 0 && a.Cout % Cfg::CO_T == 0 &&
+                    (long long)a.in.Cin * a.in.Hi * a.in.Wi * 4 < 0x7fffffffLL &&
+                    (long long)a.Cout * a.Ho * a.Wo * 4 < 0x7fffffffLL;
+    if (ok) {
+      int k = 1;                               // strips per tile row
+      while (k < a.tiles_x && tiles / ceil_div(a.tiles_x, k) < 6144) ++k;
+      a.strip = ceil_div(a.tiles_x, k);
+      a.strips_x = ceil_div(a.tiles_x, a.strip);
+      const long long sgrid = (long long)a.strips_x * a.tiles_y * a.tiles_n * a.tiles_co;
+      if (sgrid <= 0 || sgrid > 0x7fffffffLL) return GANLAB_EINVAL;
+      GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
+      return GL_CHECK_LAUNCH();
+    }
   }
-  a.strip = ceil_div(a.tiles_x, k);
-  a.strips_x = ceil_div(a.tiles_x, a.strip);
-  const long long grid = (long long)a.strips_x * a.tiles_y * a.tiles_n * a.tiles_co;
-  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  if constexpr (Cfg::STRIP) GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+  GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)tiles), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
