@@ -46,6 +46,12 @@ SIGNATURES = {
     'ganlab_conv_s2_dgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
     'ganlab_conv_s2_wgrad_workspace': (_c_sz, [_GP]),
     'ganlab_conv_s2_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_bf16_supported': (_c_int, [_GP]),
+    'ganlab_conv_pack_bf16': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_conv_fwd_bf16': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_dgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_wgrad_bf16_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_wgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_blur3x3_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_p]),
     'ganlab_up2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_pool2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),

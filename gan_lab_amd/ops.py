@@ -46,11 +46,43 @@ def _new(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# ---- compute dtype of the dense 3x3 convolutions ---------------------------------------------------
+# 'f32' (default): exact fp32 MFMA, the reference's arithmetic.  'bf16': BASELINE config #2 "bf16 compute /
+# fp32 master" - eligible 3x3 layers multiply bf16-rounded operands on v_mfma_f32_16x16x32_bf16 with fp32
+# accumulation (csrc/conv_bf16.hip); tensors in HBM, parameters, optimiser state and every other kernel stay fp32.
+_COMPUTE = ['f32']
+
+
+def set_compute_dtype(name):
+    if name not in ('f32', 'bf16'):
+        raise ValueError("compute dtype must be 'f32' or 'bf16'")
+    _COMPUTE[0] = name
+
+
+def get_compute_dtype():
+    return _COMPUTE[0]
+
+
+class compute_dtype(object):
+    """with ops.compute_dtype('bf16'): ... - graphs BUILT inside keep their kernels for the backward."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self._prev = _COMPUTE[0]
+        set_compute_dtype(self.name)
+
+    def __exit__(self, *exc):
+        _COMPUTE[0] = self._prev
+        return False
+
+
 class Geom:
     """Static description of one convolution (mirrors ganlab_conv_geom) + derived output size.
     ``up``: nearest 2x upsample folded in front; ``pool``: 2x2 average pool folded behind (stride-2
     fused kernels, csrc/conv_s2.hip).  ``s2`` tells whether the stride-2 fast path applies."""
-    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c')
+    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c', 'bf')
 
     def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
         if ks not in (1, 3):
@@ -62,7 +94,15 @@ class Geom:
         if self.pool:
             self.Ho, self.Wo = self.Ho // 2, self.Wo // 2
         self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool)
-        self.s2 = bool((self.up or self.pool) and _lib.lib().ganlab_conv_s2_supported(ctypes.byref(self._c)))
+        # bf16 compute mode (decided HERE, so a backward that runs outside the `compute_dtype` block still uses the
+        # kernels its forward used): the bf16 kernels take the materialised (upsampled) input, no pool fusion
+        self.bf = None
+        if _COMPUTE[0] == 'bf16' and not self.pool:
+            v = ConvGeom(self.N, self.Cin, hv, wv, self.Cout, self.ks, self.pad, 0, 0)
+            if _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(v)):
+                self.bf = v
+        self.s2 = bool(self.bf is None and (self.up or self.pool) and
+                       _lib.lib().ganlab_conv_s2_supported(ctypes.byref(self._c)))
         if self.pool and not self.s2:
             raise ValueError('pool=1 geometry is not supported by the stride-2 kernels; compose conv + pool')
 
@@ -82,6 +122,10 @@ def pool_fusable(N, Cin, Hin, Win, Cout, ks, pad):
     """Whether conv(ks, pad) followed by AvgPool2d(2) can run as ONE stride-2 kernel."""
     if ks != 3 or pad != 1:
         return False
+    if _COMPUTE[0] == 'bf16':
+        v = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 0)
+        if _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(v)):
+            return False        # bf16 conv, then the pool as its own (HBM-bound) pass
     c = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 1)
     return bool(_lib.lib().ganlab_conv_s2_supported(ctypes.byref(c)))
 
@@ -133,6 +177,26 @@ def _packed(w, mode, scale, s2_up=None):
     return out
 
 
+def _packed_bf16(w, mode, scale):
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0], 'bf16')
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    if len(_PACK_CACHE) > 512:
+        _PACK_CACHE.clear()
+    cout, cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    n = L.ganlab_conv_pack_bf16(None, None, cout, cin, mode, scale, None)
+    if n <= 0:
+        raise _lib.GanlabLibraryError(f'conv_pack_bf16 size query failed ({n}) for weight {tuple(w.shape)}')
+    out = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    rc = L.ganlab_conv_pack_bf16(_p(w), out.data_ptr(), cout, cin, mode, scale, _st())
+    if rc != n:
+        raise _lib.GanlabLibraryError(f'conv_pack_bf16 failed ({rc})')
+    _PACK_CACHE[key] = (w.detach(), out)
+    return out
+
+
 # ---- "input gradient only" mode ---------------------------------------------------------------------
 # torch.autograd.grad(D(x), x, create_graph=True) (the gradient-penalty pass) only needs d/dx, but a
 # Python autograd.Function cannot see which of its outputs the engine will keep: without this flag
@@ -166,6 +230,12 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         bias = _c(bias, 'bias')
         assert bias.numel() == g.Cout
     y = _new(g.out_shape, x)
+    if g.bf is not None:   # bf16-compute layer (the nearest upsample, if any, is materialised first)
+        xin = k_up2(x, 1.0) if g.up else x
+        wp = _packed_bf16(w, PACK_FWD, scale)
+        check(_lib.lib().ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(g.bf), bias_scale,
+                                              act, slope, _st()), 'conv_fwd_bf16')
+        return y
     if g.s2:   # stride-2 fused layer: conv+avgpool (S kernel) or upsample+conv (T kernel)
         wp = _packed(w, PACK_FWD, scale, s2_up=g.up)
         check(_lib.lib().ganlab_conv_s2_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope,
@@ -180,6 +250,12 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
 def k_conv_dgrad(gy, w, g, scale):
     gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
     assert tuple(gy.shape) == g.out_shape, (tuple(gy.shape), g.out_shape)
+    if g.bf is not None:
+        wp = _packed_bf16(w, PACK_DGRAD, scale)
+        gxv = _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy)
+        check(_lib.lib().ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(gxv), ctypes.byref(g.bf), _st()),
+              'conv_dgrad_bf16')
+        return k_pool2(gxv, 1.0) if g.up else gxv
     if g.s2:
         wp = _packed(w, PACK_DGRAD, scale, s2_up=g.up)
         gx = _new(g.in_shape, gy)
@@ -199,6 +275,13 @@ def k_conv_wgrad(gy, x, g, scale):
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
+    if g.bf is not None:
+        xin = k_up2(x, 1.0) if g.up else x
+        nbytes = L.ganlab_conv_wgrad_bf16_workspace(ctypes.byref(g.bf))
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+        check(L.ganlab_conv_wgrad_bf16(_p(gy), _p(xin), _p(gw), ctypes.byref(g.bf), scale, _p(ws), ws.numel() * 4,
+                                       _st()), 'conv_wgrad_bf16')
+        return gw
     if g.s2:
         nbytes = L.ganlab_conv_s2_wgrad_workspace(g.ref())
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)

@@ -9,12 +9,18 @@ all-reduce per tensor.  ``start()`` launches them asynchronously on RCCL's own s
 forward pass (which does not depend on the gradients) overlaps the transfer; ``finish()`` is called
 right before the optimiser step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients must be exchanged.  GANLAB_DIST_WORLD1=1 keeps the RCCL code path on for a single rank
+    (a 1-GPU box can then exercise init / broadcast / async all-reduce / AVG exactly as an 8-GPU node runs them)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('GANLAB_DIST_WORLD1') == '1'
 
 
 def world_size():

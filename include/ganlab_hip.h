@@ -99,6 +99,23 @@ size_t ganlab_conv_s2_wgrad_workspace(const ganlab_conv_geom* g);
 int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g,
                              float scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- bf16-compute convolutions (csrc/conv_bf16.hip; BASELINE config #2 "bf16 compute / fp32 master") ---------
+ * Same math and call sites as the fp32 entry points above (custom_layers.py:202-211 and its autograd rules), but
+ * the operands are rounded to bf16 (RNE) on their way into LDS and multiplied on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation; every tensor in HBM stays fp32 (the reference's storage type, fp32 master weights).  The reference
+ * itself is fp32 only, so this path is an extension selected by the caller (gan_lab_amd.ops.compute_dtype).
+ * Supported: 3x3, pad 1, no up / pool, Cin % 64 == 0, Cout % 64 == 0, H % 8 == 0, W % 32 == 0
+ * (ganlab_conv_bf16_supported); everything else stays on the exact fp32 kernels.
+ * pack: returns the number of bf16 elements (9*Cout*Cin) when `out` is NULL; mode is GANLAB_PACK_*. */
+int ganlab_conv_bf16_supported(const ganlab_conv_geom* g);
+long long ganlab_conv_pack_bf16(const float* w, void* out, int Cout, int Cin, int mode, float scale, void* stream);
+int ganlab_conv_fwd_bf16(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                         float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- depthwise / resampling (custom_layers.py:36-53; nn.Upsample / nn.AvgPool2d call sites) ---- */
 /* y = depthwise [1 2 1]x[1 2 1]/16 blur, zero padding (self-adjoint: also its own backward). */
 int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream);

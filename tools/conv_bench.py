@@ -7,12 +7,17 @@ import torch
 from gan_lab_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+if len(sys.argv) > 2:          # tools/conv_bench.py 8 bf16 -> config #2 shapes on the bf16-compute kernels
+    ops.set_compute_dtype(sys.argv[2])
 SHAPES = [  # (Cin, Cout, Hin, up)
     (16, 16, 1024, 0), (32, 16, 512, 1), (16, 32, 1024, 0), (32, 32, 512, 0), (64, 32, 256, 1), (32, 64, 512, 0),
     (64, 64, 256, 0), (128, 64, 128, 1), (64, 128, 256, 0), (128, 128, 128, 0), (256, 128, 64, 1),
     (128, 256, 128, 0), (256, 256, 64, 0), (512, 256, 32, 1), (256, 512, 64, 0), (512, 512, 32, 0),
     (512, 512, 16, 0), (512, 512, 8, 0), (512, 512, 4, 0),
 ]
+if ops.get_compute_dtype() == 'bf16':      # StyleGAN-128 layer shapes
+    SHAPES = [(128, 128, 128, 0), (256, 128, 64, 1), (128, 256, 128, 0), (256, 256, 64, 0), (512, 256, 32, 1),
+              (256, 512, 64, 0), (512, 512, 32, 0)]
 
 
 def timeit(fn, reps=5):
