@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_IMAGE = {1024: 1.536, 128: 0.752}      # 4 G passes + 14 D passes
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2
+PEAK_BF16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF, no sparsity)
 
 
 def parse():
@@ -37,16 +38,18 @@ def parse():
     p.add_argument('--cpu-baseline-res', type=int, default=None)
     p.add_argument('--cpu-baseline-batch', type=int, default=1)
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                   help="compute dtype of the 3x3 convolutions; 'bf16' = BASELINE config #2 (use with --res 128 --batch 8)")
     return p.parse_args()
 
 
-def build_learner(res, batch, device):
+def build_learner(res, batch, device, dtype='f32'):
     from gan_lab_amd.config import make_config
     from gan_lab_amd.stylegan.learner import StyleGANLearner
     bs_dict = {r: batch for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
     cfg = make_config('stylegan', dev='cuda', pin_memory=False, loss='nonsaturating', gradient_penalty='r1',
                       lda=10., res_samples=res, res_dataset=res, init_res=res, batch_size=batch, bs_dict=bs_dict,
-                      num_iters_save_model=10 ** 9, log_every=0,
+                      num_iters_save_model=10 ** 9, log_every=0, compute_dtype=dtype,
                       cutoff_trunc_trick=4 if res >= 64 else None)
     import contextlib
     import io
@@ -66,13 +69,14 @@ def one_step(learner, real):
     return ld, lg
 
 
-def measure_dominant_kernel(torch, batch, res, reps=5):
+def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32'):
     """Average launch duration of the north-star conv kernel instance, device events on the launch stream."""
     from gan_lab_amd import ops
     c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
     x = torch.randn(batch, c, res, res, device='cuda')
     w = torch.randn(c, c, 3, 3, device='cuda')
     g = ops.Geom(batch, c, res, res, c, 3, 1, 0)
+    bf = g.bf is not None
     for _ in range(2):
         ops.k_conv_fwd(x, w, None, g, 0.05)
     torch.cuda.synchronize()
@@ -85,13 +89,15 @@ def measure_dominant_kernel(torch, batch, res, reps=5):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * 9 * c * c * res * res * batch
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4),
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
             # profiles/r01_northstar_conv_pmc.csv: equals the algorithmic 2 GiB in + 2 GiB out
-            'traffic': 4.2953e9 if (c == 16 and res == 1024 and batch == 32) else None,
-            'kernel': f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
-                      f'{c}->{c} @{res}^2 x{batch}',
+            'traffic': 4.2953e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
+            'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
+                       f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
+                       f'{c}->{c} @{res}^2 x{batch}'),
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
 
 
@@ -147,7 +153,7 @@ def main():
     rng.manual_seed(1234, rank)
     torch.manual_seed(1234 + rank)
 
-    learner = build_learner(a.res, a.batch, 'cuda')
+    learner = build_learner(a.res, a.batch, 'cuda', a.dtype)
     # synthetic FFHQ-shaped reals, resident in HBM before the timed region: U(-1,1) fp32 (B,3,R,R)
     real = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
 
@@ -178,21 +184,24 @@ def main():
                       f'images/sec (G+D step), StyleGAN {a.res}^2 bs{a.batch}/GPU',
             'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'StyleGAN res_samples={a.res} FFHQ-shaped synthetic, bs={a.batch}/GPU fp32, '
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'StyleGAN res_samples={a.res} FFHQ-shaped synthetic, bs={a.batch}/GPU '
+                                   f'{"fp32" if a.dtype == "f32" else "bf16 compute / fp32 storage+master"}, '
                                    f'nonsaturating + R1(lambda=10) + drift, stabilised phase, 1 D-iter + 1 G-iter',
                        'global_batch': world * a.batch, 'per_gpu_batch': a.batch,
                        'parallelism': f'dp{world}' if world > 1 else 'single'},
             'achieved_tflops_step': round(ips * TFLOP_PER_IMAGE.get(a.res, 0.0), 2) if a.res in TFLOP_PER_IMAGE
             else None,
-            'frac_of_f32_mfma_peak_step': round(ips * TFLOP_PER_IMAGE[a.res] / (PEAK_F32_MFMA_TFLOPS * world), 4)
+            'frac_of_mfma_peak_step': round(
+                ips * TFLOP_PER_IMAGE[a.res] /
+                ((PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS) * world), 4)
             if a.res in TFLOP_PER_IMAGE else None,
             'loss_d': ld, 'loss_g': lg, 'peak_mem_gib': round(peak_mem, 1),
         }
     del learner, real
     torch.cuda.empty_cache()
     if rank == 0:
-        out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res)
+        out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res, dtype=a.dtype)
         torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             cres = a.cpu_baseline_res or a.res

@@ -7,7 +7,8 @@ same way (:337-376: torch.device, seeding, ``bs_dict`` rebuilt from ``--batch_si
 bs//2 and 1024 -> bs//4) and pickles the Namespace to ``<this dir>/.config.p`` with the pointer file
 ``~/.configs_dir.txt`` (:408-412), which ``get_current_configuration('config')`` reads back.
 ``make_config(model, **overrides)`` builds the same Namespace in-process (tests, bench.py).
-New, optional fields (ignored by the reference): ``log_every``.
+New, optional fields (ignored by the reference): ``log_every``, ``compute_dtype`` ('f32' = the reference's
+arithmetic, 'bf16' = BASELINE config #2: bf16-compute 3x3 convolutions with fp32 storage / masters).
 """
 import argparse
 import os
@@ -43,7 +44,7 @@ def _spec(model_type):
         ('img_grid_sz', int, 4), ('img_grid_show_labels', bool, True),
         ('save_samples_dir', Path, Path(_HERE + '/samples/')), ('num_iters_save_model', int, 1000),
         ('save_model_dir', Path, Path(_HERE + '/models/')), ('num_workers', int, 0),
-        ('pin_memory', bool, dev == 'cuda'), ('log_every', int, 50),
+        ('pin_memory', bool, dev == 'cuda'), ('log_every', int, 50), ('compute_dtype', str.casefold, 'f32'),
     ]
     if model_type == 'ResNet GAN':
         rows += [('batch_size', int, BS), ('num_main_iters', int, 300000), ('num_disc_iters', int, 5),

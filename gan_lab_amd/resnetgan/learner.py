@@ -40,6 +40,8 @@ class GANLearner(object):
             raise RuntimeError(f"gan_lab_amd runs on the MI355X only (config.dev={config.dev!r}); there is no CPU "
                                f"path - use the reference or the test oracle for CPU runs")
         _lib.lib()  # fail now, loudly, if the kernel library is missing
+        from .. import ops
+        ops.set_compute_dtype(getattr(config, 'compute_dtype', 'f32'))   # 'bf16': BASELINE config #2
 
         self.curr_dataset_batch_num = 0
         self.curr_epoch_num = 1
