@@ -11,7 +11,9 @@ schedule; but
     gradient all-reduce overlaps the next G forward,
   * the fade-in of the real images (``up(down(x))*(1-a) + x*a``, :771-779) runs on the device,
   * losses are only synchronised to the host every ``log_every`` iterations.
-Validation metrics, image grids and plotting (:249-416, :1147-1234) are outside the hot path.
+Validation metrics and sample grids (:223-416, :1187-1234) are inference-only forwards of
+the same kernels: ``compute_metrics`` / ``make_image_grid`` below (numbers and a uint8 grid; the matplotlib
+figure of the reference is UI and stays out of scope).
 """
 import copy
 import os
@@ -60,6 +62,13 @@ class ProGANLearner(GANLearner):
         self.log_every = getattr(config, 'log_every', 50)
         self.share_gp_forward = True     # see d_step(): common-subexpression elimination of D(real)
         self.last_losses = {}
+        # validation bookkeeping (progan/learner.py:207-221)
+        self.gen_metrics_num = self.disc_metrics_num = 0
+        self.grid_inputs_constructed = False
+        self._img_grid_constructed = False
+        self.rand_idxs = None
+        self.valid_label = None
+        self.last_metrics = {}
         if self.model == 'ProGAN':
             self._init_progressive(config, self.__class__.__name__)
 
@@ -364,7 +373,14 @@ class ProGANLearner(GANLearner):
                     batch = next(self.train_dataiter)
                 xb = batch[0].to(c.dev, non_blocking=True).float()
                 last = disc_iter == num_disc_iters - 1
-                loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0)
+                valid_now = last and ((itr + 1) % c.num_iters_valid == 0 or itr == 0)
+                d_metrics = valid_now and z_valid_dl is not None and valid_dl is not None and bool(c.disc_metrics)
+                loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0 and not d_metrics)
+                if d_metrics:       # validation metrics of the just-updated discriminator (:822-832)
+                    vals = self.compute_metrics(metrics=c.disc_metrics, metrics_type='Discriminator',
+                                                z_valid_dl=z_valid_dl, valid_dl=valid_dl)
+                    if parallel.rank() == 0:
+                        print('|\n', 'Discriminator Validation Metrics:\n', *vals)
                 self.curr_dataset_batch_num += 1
                 sched.after_d_iter()
                 self.curr_img_num = sched.curr_img_num
@@ -374,6 +390,12 @@ class ProGANLearner(GANLearner):
             loss_g = None
             for gen_iter in range(num_gen_iters):
                 loss_g = self.g_step(d_update_pending=(gen_iter == 0))
+                if gen_iter == num_gen_iters - 1 and z_valid_dl is not None and c.gen_metrics and \
+                        ((itr + 1) % c.num_iters_valid == 0 or itr == 0):     # (:921-928)
+                    vals = self.compute_metrics(metrics=c.gen_metrics, metrics_type='Generator',
+                                                z_valid_dl=z_valid_dl, valid_dl=None)
+                    if parallel.rank() == 0:
+                        print('|\n', 'Generator Validation Metrics:\n', *vals)
             if num_gen_iters == 0:
                 self._finish_d_update()
 
@@ -403,6 +425,165 @@ class ProGANLearner(GANLearner):
             if (itr + 1) % c.num_iters_save_model == 0:
                 self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
         self.set_requires_grad_disc(True)
+
+    # ------------------------------------------------------------------------------------------------
+    # validation metrics and sample grids: inference-only forwards
+    # ------------------------------------------------------------------------------------------------
+    def _update_gen_lagged(self):
+        """progan/learner.py:234-242: refresh ``gen_model_lagged`` from the EWMA shadow (train mode, like upstream)."""
+        g = self.materialize_lagged_generator()
+        g.to(self.config.dev).train()
+        return g
+
+    @torch.no_grad()
+    def compute_metrics(self, metrics, metrics_type, z_valid_dl, valid_dl=None):
+        """Metric evaluation over the validation latents / images (progan/learner.py:249-416), same definitions:
+        every metric is ``sum over the (batch, n_batches) table / len(z_valid_dl.dataset)``, i.e. 'fake realness' /
+        'real realness' are mean logits and the two losses are batch-size-weighted means of per-batch losses
+        (the gradient penalty is not included, :393-395).  Networks run in eval mode on the training device
+        (``config.metrics_dev`` is ignored: there is no CPU path) and return to train mode.  Returns the
+        reference's list of formatted lines; the raw numbers are kept in ``self.last_metrics``."""
+        c = self.config
+        metrics_type = metrics_type.casefold()
+        if metrics_type not in ('generator', 'critic', 'discriminator',):
+            raise Exception('Invalid metrics_type. Only "generator", "critic", or "discriminator" are accepted.')
+        metrics = [m.casefold() for m in metrics]
+        want_grid = 'image grid' in metrics and metrics_type == 'generator'
+        if want_grid and (self.ds_mean is None or self.data_config is None):
+            self._update_data_config(raise_exception=True)
+        self.disc_model.eval()
+        if c.use_ewma_gen and metrics_type == 'generator':
+            self.gen_model.train()
+            self._update_gen_lagged()
+            self.gen_model_lagged.eval()
+        self.gen_model.eval()
+        try:
+            n_batches, n_z = len(z_valid_dl), len(z_valid_dl.dataset)
+            valid_iter = iter(valid_dl) if valid_dl is not None else None
+            if want_grid and not self.grid_inputs_constructed:
+                assert c.img_grid_sz ** 2 <= n_z
+                self.rand_idxs = torch.multinomial(torch.ones(n_z), num_samples=c.img_grid_sz ** 2,
+                                                   replacement=False)
+                self._grid_fill = 0
+            self._img_grid_constructed = False
+            table = {m: torch.zeros(self.batch_size, n_batches, device=c.dev) for m in metrics}
+            for n, zbatch in enumerate(z_valid_dl):
+                zb = zbatch[0].to(c.dev).float()
+                gen_labels = zbatch[1].cpu() if len(zbatch) > 1 else None
+                k = len(zb)
+                xgen = self.gen_model(zb)
+                y_fake = None
+                if 'fake realness' in metrics:
+                    y_fake = self.disc_model(xgen)
+                    table['fake realness'][:k, n] = y_fake
+                if metrics_type == 'generator':
+                    if 'generator loss' in metrics:
+                        if y_fake is None:
+                            y_fake = self.disc_model(xgen)
+                        table['generator loss'][:k, n] = self.loss_func_gen(y_fake)
+                    if want_grid:
+                        self._collect_grid_inputs(zb, gen_labels, n)
+                        if self.grid_inputs_constructed and not self._img_grid_constructed:
+                            self._save_metric_grids()
+                            self._img_grid_constructed = True
+                elif valid_iter is not None:
+                    xb = next(valid_iter)[0].to(c.dev).float()
+                    xb = self.fade_in_real(xb)          # reals follow the generator's fade-in (:361-371)
+                    y_real = None
+                    if 'real realness' in metrics:
+                        y_real = self.disc_model(xb)
+                        table['real realness'][:k, n] = y_real
+                    if 'discriminator loss' in metrics:
+                        if y_fake is None:
+                            y_fake = self.disc_model(xgen)
+                        if y_real is None:
+                            y_real = self.disc_model(xb)
+                        table['discriminator loss'][:k, n] = self.loss_func_disc(y_fake, y_real)
+            if metrics_type == 'generator':
+                self.gen_metrics_num += 1
+            else:
+                self.disc_metrics_num += 1
+            vals = {m: float(t.sum() / n_z) for m, t in table.items() if m != 'image grid'}
+        finally:
+            self.gen_model.train()
+            self.disc_model.train()
+        self.last_metrics[metrics_type] = vals
+        width = '%-' + str(max(len(m) for m in metrics) + 3) + 's'
+        return ['    ' + (width % (m + ':')) + '%.4g' % vals[m] + '\n' for m in metrics if m != 'image grid']
+
+    def _collect_grid_inputs(self, zb, gen_labels, n):
+        """Pick the img_grid_sz^2 randomly chosen validation latents (fixed across calls, :311-330)."""
+        c = self.config
+        if self.valid_z is None:
+            self.valid_z = torch.empty(c.img_grid_sz ** 2, zb.shape[1], device=c.dev)
+            if gen_labels is not None and c.img_grid_show_labels:
+                self.valid_label = torch.zeros(c.img_grid_sz ** 2, dtype=torch.long)
+        if self.grid_inputs_constructed:
+            return
+        chosen = set(self.rand_idxs.tolist())
+        for o in range(len(zb)):
+            if n * self.batch_size + o in chosen:
+                self.valid_z[self._grid_fill] = zb[o]
+                if self.valid_label is not None and gen_labels is not None:
+                    self.valid_label[self._grid_fill] = gen_labels[o]
+                self._grid_fill += 1
+        if self._grid_fill == c.img_grid_sz ** 2:
+            self.grid_inputs_constructed = True
+
+    def _save_metric_grids(self):
+        """samples/<model>/<dataset>/image_grid/{time_averaged,original}/<n>.png (:332-349)."""
+        c = self.config
+        root = c.save_samples_dir / self.model.casefold().replace(' ', '') / self.data_config.dataset / 'image_grid'
+        kinds = (('time_averaged', True),) if c.use_ewma_gen else ()
+        for sub, avg in kinds + (('original', False),):
+            (root / sub).mkdir(parents=True, exist_ok=True)
+            self.make_image_grid(zs=self.valid_z, labels=self.valid_label, time_average=avg,
+                                 save_path=str(root / sub / (str(self.gen_metrics_num) + '.png')))
+
+    def _check_sample_latents(self, zs):
+        if self.ds_mean is None or self.ds_std is None:
+            raise ValueError("This model does not hold any information about your dataset's mean and/or std.\n"
+                             "Please provide these (either from your current data configuration or from your "
+                             "pretrained model).")
+        want = self.config.len_latent + (self.num_classes_gen if self.cond_gen else 0)
+        if zs.shape[-1] != want:
+            raise IndexError(f'Input latent vector must be of size {want}.')
+
+    @torch.no_grad()
+    def generate(self, zs, time_average=True, **gen_kwargs):
+        """Samples in [0, 1] image space, (N, 3, R, R) on the device: ``G(z) * ds_std + ds_mean`` from the EWMA
+        generator (``time_average``) or the snapshot one - what plot_sample / make_image_grid display
+        (:1148-1234).  The networks' modes are left as the caller set them."""
+        self._check_sample_latents(zs)
+        if time_average and self.gen_model_lagged is None:
+            self._update_gen_lagged()
+            self.gen_model_lagged.eval()
+        gen = self.gen_model_lagged if time_average else self.gen_model
+        dev = self.config.dev
+        std, mean = self.ds_std.to(dev).view(1, -1, 1, 1), self.ds_mean.to(dev).view(1, -1, 1, 1)
+        out = [gen(zs[i:i + 16].to(dev).float(), **gen_kwargs) * std + mean for i in range(0, len(zs), 16)]
+        return torch.cat(out)
+
+    @torch.no_grad()
+    def make_image_grid(self, zs, labels=None, time_average=True, save_path=None):
+        """sqrt(len(zs)) x sqrt(len(zs)) grid of generated samples as a uint8 (H, W, 3) array, saved as a PNG
+        when ``save_path`` is given (progan/learner.py:1187-1234; the matplotlib figure of the reference is
+        replaced by the pixel grid itself, one generated pixel per grid pixel, labels are not drawn)."""
+        import numpy as np
+        if not zs.dim() == 2:
+            raise IndexError('Incorrect dimensions of input latent vector. Must be `dim == 2`.')
+        self._check_sample_latents(zs)
+        if np.sqrt(len(zs)) % 1 != 0:
+            raise ValueError('Argument `zs` must be a perfect square-length in order to make image grid.')
+        sz = int(np.sqrt(len(zs)))
+        x = self.generate(zs, time_average=time_average).clamp_(0., 1.)
+        r = x.shape[-1]
+        grid = (x.view(sz, sz, 3, r, r).permute(0, 3, 1, 4, 2).reshape(sz * r, sz * r, 3) * 255.).round()
+        grid = grid.to(torch.uint8).cpu().numpy()
+        if save_path is not None:
+            from PIL import Image
+            Image.fromarray(grid).save(save_path)
+        return grid
 
     # ------------------------------------------------------------------------------------------------
     def materialize_lagged_generator(self):
