@@ -63,6 +63,8 @@ class StyleAddNoise(nn.Module):
 
     def draw(self, x, noise=None):
         if noise is not None and (not self.training or StyleAddNoise.honour_noise_in_training):
+            if noise.shape[0] == 1 and x.shape[0] > 1:      # torch broadcasting of the reference's x + w * noise
+                noise = noise.expand(x.shape[0], -1, -1, -1)
             return noise
         return rng.randn((x.shape[0], 1, x.shape[2], x.shape[3]), x.device)
 

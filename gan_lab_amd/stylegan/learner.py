@@ -38,3 +38,56 @@ class StyleGANLearner(ProGANLearner):
                                   nl=self.nl, num_classes=self.num_classes_disc, equalized_lr=c.use_equalized_lr,
                                   mbstd_group_size=c.mbstd_group_size)
         return gen, disc
+
+    # -- style-mixing figure (stylegan/learner.py:306-431): the pixel content, without the matplotlib layout ------
+    STYLE_MIX_STAGES = (1, 4, 8)    # coarse / middle / fine: generator layer at which source B's w takes over
+
+    def make_stylemixing_grid(self, zs_sourceb, zs_coarse=(), zs_middle=(), zs_fine=(), labels=None,
+                              time_average=True, save_path=None, noise=None):
+        """Figure 3 of Karras et al. 2019 as a uint8 pixel grid: row 0 = source-B samples, column 0 = the
+        coarse / middle / fine source-A samples, cell (r, c) = ``G(z_A[r], x_mixing=z_B[c], style_mixing_stage)``
+        with stages 1 / 4 / 8 as upstream (:325-333).  Generators run in eval mode (truncation trick as
+        configured); ``noise`` pins the per-layer noise (tests).  Titles / axis labels of the reference's
+        matplotlib figure are not drawn; ``labels`` is accepted for signature compatibility."""
+        import numpy as np
+        import torch
+        groups = [g if isinstance(g, torch.Tensor) else torch.empty(0, self.config.len_latent)
+                  for g in (zs_coarse, zs_middle, zs_fine)]
+        groups = [g.unsqueeze(0) if g.dim() == 1 else g for g in groups]
+        zs_sourceb = zs_sourceb.unsqueeze(0) if zs_sourceb.dim() == 1 else zs_sourceb
+        assert any(len(g) for g in groups)
+        for g in [zs_sourceb] + groups:
+            if g.dim() > 2:
+                raise IndexError('Incorrect dimensions of input latent vector. Must be either `dim == 1` or `dim == 2`.')
+            if len(g):
+                self._check_sample_latents(g)
+        modes = (self.gen_model.training, None if self.gen_model_lagged is None else self.gen_model_lagged.training)
+        if time_average and self.gen_model_lagged is None:
+            self._update_gen_lagged()
+        gen = self.gen_model_lagged if time_average else self.gen_model
+        gen.eval()
+        try:
+            kw = {} if noise is None else {'noise': noise}
+            ncols = 1 + len(zs_sourceb)
+            r = self.gen_model.curr_res
+            rows = [[torch.ones(3, r, r, device=self.config.dev)] +
+                    list(self.generate(zs_sourceb, time_average=time_average, **kw))]
+            for stage, zs in zip(self.STYLE_MIX_STAGES, groups):
+                for z in zs:
+                    cells = [self.generate(z.unsqueeze(0), time_average=time_average, **kw)[0]]
+                    for zb in zs_sourceb:
+                        cells.append(self.generate(z.unsqueeze(0), time_average=time_average,
+                                                   x_mixing=zb.unsqueeze(0).to(self.config.dev),
+                                                   style_mixing_stage=stage, **kw)[0])
+                    rows.append(cells)
+        finally:
+            self.gen_model.train(modes[0])
+            if modes[1] is not None:
+                self.gen_model_lagged.train(modes[1])
+        x = torch.stack([torch.stack(c) for c in rows]).clamp_(0., 1.)           # (nrows, ncols, 3, r, r)
+        grid = (x.permute(0, 3, 1, 4, 2).reshape(len(rows) * r, ncols * r, 3) * 255.).round().to(torch.uint8)
+        grid = grid.cpu().numpy()
+        if save_path is not None:
+            from PIL import Image
+            Image.fromarray(grid).save(save_path)
+        return grid

@@ -146,3 +146,33 @@ def test_train_runs_validation_like_the_reference(capsys):
     assert L.gen_metrics_num == 3 and L.disc_metrics_num == 3
     assert all(np.isfinite(v) for m in L.last_metrics.values() for v in m.values())
     assert L.gen_model.training and L.disc_model.training
+
+
+def test_stylemixing_grid_cells_are_mixed_samples():
+    """make_stylemixing_grid (stylegan/learner.py:306-431, pixel content): cell (r, c) is the eval-mode generator
+    with source B's style taking over at stage 1 / 4 - compared with the oracle's style-mixing forward."""
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    from oracle import nets
+    from test_gpu_learner import make_learner
+    L = make_learner('stylegan', 32, init_res=32, batch=4, loss='nonsaturating', gradient_penalty='r1',
+                     use_ewma_gen=False)
+    L.train(SyntheticImageLoader(4096, 4, 32), num_main_iters=2)
+    L.ds_mean, L.ds_std = torch.full((3, 1, 1), 0.5), torch.full((3, 1, 1), 0.5)
+    gen = torch.Generator().manual_seed(4)
+    zb, za = torch.randn(2, 16, generator=gen), torch.randn(2, 16, generator=gen)
+    nl = len(L.gen_model.gen_layers)
+    noise = [torch.randn(1, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2), generator=gen) for n in range(nl)]
+    grid = L.make_stylemixing_grid(zb, zs_coarse=za[:1], zs_middle=za[1:], time_average=False,
+                                   noise=[n.cuda() for n in noise])
+    assert grid.shape == (3 * 32, 3 * 32, 3) and L.gen_model.training
+    sd = {k: v.detach().cpu().clone() for k, v in L.gen_model.state_dict().items()}
+    cfg = nets.make_cfg()
+
+    def cell(r, c):
+        return torch.from_numpy(grid[r * 32:(r + 1) * 32, c * 32:(c + 1) * 32].astype(np.float32)).permute(2, 0, 1)
+    with torch.no_grad():
+        for r, (z, stage) in enumerate(((za[:1], 1), (za[1:], 4)), start=1):
+            for c in (1, 2):
+                ref = nets.stylegen_forward(sd, z, noise, cfg, z_mix=zb[c - 1:c], cutoff_idx=stage)
+                ref = ((ref[0] * 0.5 + 0.5).clamp(0, 1) * 255).round()
+                assert (cell(r, c) - ref).abs().max() <= 1, (r, c)
