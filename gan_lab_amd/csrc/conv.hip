@@ -19,7 +19,8 @@
 // every staging access is 16 bytes wide where the shape allows:
 //   XMODE 1 (VEC)   : rows [ox0-4, ox0+TW+4) as aligned float4 (W % 4 == 0, stride-1 source)
 //   XMODE 2 (VECUP) : low-res rows as aligned float4, duplicated 2x2 while being written to LDS
-//   XMODE 0         : per-element path for ragged / tiny shapes (4x4, 8x8, linears, odd sizes)
+//   XMODE 0         : per-element path for ragged / tiny shapes (4x4, 8x8, linears, odd sizes), same register
+//                     prefetch (one float per item)
 // LDS strides are padded so the two k-halves of a 32-lane read group land on disjoint banks.
 #include "common.h"
 
@@ -64,20 +65,29 @@ struct PatchArgs {
 template <class G, int CI_T, int PLANE>
 struct XStage {
   static constexpr int NITEMS = CI_T * G::ITEMS_PER_CI;
-  static constexpr int PT = G::XMODE == XSCALAR ? 1 : ceil_div_c(NITEMS, 256);
+  static constexpr int PT = ceil_div_c(NITEMS, 256);
   int goff[PT];
   int loff[PT];  // LDS offset | (ci << 20); for XVECUP bit 30/31 = write row 2lr-1 / 2lr
-  int n0_, oy0_, ox0_;  // scalar mode: tile origin (items are re-derived while staging)
+  int n0_, oy0_, ox0_;  // scalar mode of the weight-gradient kernel: tile origin (items re-derived while staging)
 
   __device__ __forceinline__ void init(const PatchArgs& p, int tid, int n0, int oy0, int ox0) {
     const int plane = p.Hi * p.Wi;
     n0_ = n0; oy0_ = oy0; ox0_ = ox0;
-    if (G::XMODE == XSCALAR) return;
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int e = tid + i * 256;
       int g = -1, l = 0;
-      if (G::XMODE == XVEC) {
+      if (G::XMODE == XSCALAR) {   // one element per item: (ci, image, row, column) of the halo'd patch
+        const int c = e % G::RP;
+        int t = e / G::RP;
+        const int r = t % G::R;
+        t /= G::R;
+        const int ni = t % G::NI, ci = t / G::NI;
+        const int vy = oy0 + r - p.pad, vx = ox0 + c - p.pad;
+        l = (ci * PLANE + ni * G::IMG + r * G::RP + c) | (ci << 20);
+        if (e < NITEMS && n0 + ni < p.N && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv)
+          g = (ni * p.Cin + ci) * plane + (p.up ? (vy >> 1) : vy) * p.Wi + (p.up ? (vx >> 1) : vx);
+      } else if (G::XMODE == XVEC) {
         const int q = e % G::ROW4;
         int t = e / G::ROW4;
         const int r = t % G::R, ci = t / G::R;
@@ -145,22 +155,30 @@ struct XStage {
 };
 
 // registers holding one staged chunk of the activation patch
+template <int XMODE>
+struct XElem { typedef float4 type; };
+template <>
+struct XElem<XSCALAR> { typedef float type; };
 template <class G, int PT>
 struct XRegs {
-  float4 v[PT];
+  typename XElem<G::XMODE>::type v[PT];
 };
+__device__ __forceinline__ void x_zero(float4& v) { v = float4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void x_zero(float& v) { v = 0.f; }
+__device__ __forceinline__ void x_ld(float4& v, const float* p) { v = *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void x_ld(float& v, const float* p) { v = *p; }
 
 template <class G, int CI_T, int PLANE>
 __device__ __forceinline__ void x_load(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r, const XStage<G, CI_T, PLANE>& st,
                                        const float* xb, int ci0, int Cin, int plane) {
   constexpr int PT = XStage<G, CI_T, PLANE>::PT;
-  if (G::XMODE == XSCALAR) return;  // staged directly in x_store_scalar (no register prefetch)
   const float* src = xb + (long long)ci0 * plane;
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int ci = (st.loff[i] >> 20) & 0x3ff;
     const bool ok = st.goff[i] >= 0 && ci0 + ci < Cin;
-    r.v[i] = ok ? *reinterpret_cast<const float4*>(src + st.goff[i]) : float4{0.f, 0.f, 0.f, 0.f};
+    x_zero(r.v[i]);
+    if (ok) x_ld(r.v[i], src + st.goff[i]);
   }
 }
 
@@ -202,7 +220,8 @@ __device__ __forceinline__ void x_load_buf(XRegs<G, XStage<G, CI_T, PLANE>::PT>&
   }
 }
 
-// Per-element staging for ragged / tiny shapes: global -> LDS in batches of 8 independent loads.
+// Per-element staging WITHOUT register prefetch, global -> LDS in batches of 8 independent loads: the weight-gradient
+// kernel's ragged / tiny geometries (their 32-channel patches would not fit a register-prefetch copy).
 template <class G, int CI_T, int PLANE>
 __device__ __forceinline__ void x_stage_scalar(const XStage<G, CI_T, PLANE>& st, const PatchArgs& p,
                                                const float* xb, int ci0, float* Xs, int tid) {
@@ -253,9 +272,9 @@ __device__ __forceinline__ void x_store(const XRegs<G, XStage<G, CI_T, PLANE>::P
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int l = st.loff[i] & 0xfffff;
-    if (G::XMODE == XSCALAR) {
-      // nothing: see x_stage_scalar
-    } else if (G::XMODE == XVEC) {
+    if constexpr (G::XMODE == XSCALAR) {
+      if (tid + i * 256 < NITEMS) Xs[l] = r.v[i];
+    } else if constexpr (G::XMODE == XVEC) {
       if (tid + i * 256 < NITEMS) lds_store4<A16>(Xs + l, r.v[i]);
     } else {
       const float4 v = r.v[i];
@@ -295,7 +314,9 @@ struct FwdCfg {
   static constexpr int WN = 4;  // 4 waves side by side along the pixel dim
   static constexpr int NB = G::PX_T / (16 * WN);
   static constexpr int CO_T = 16 * MB_;
-  static constexpr int CI_T = (KS_ == 1) ? 32 : (MB_ <= 2 ? 16 : 8);
+  // scalar staging keeps 3 registers per patch element in flight (global offset, LDS offset, value): 8-channel
+  // chunks bound that at ~55 registers for the 4x4x16-image geometry
+  static constexpr int CI_T = (KS_ == 1) ? 32 : ((MB_ <= 2 && XMODE_ != XSCALAR) ? 16 : 8);
   static constexpr int PLANE = pad_mod32(G::NI * G::IMG, 16);
   static constexpr int COP = pad_mod32(CO_T, 16);
   static constexpr int XS = CI_T * PLANE, WS = KK * CI_T * COP;
@@ -329,7 +350,7 @@ __device__ unsigned long long* gl_phase_buf;
 
 // Strip kernel for thin layers (one 16-channel output block, ONE K-chunk: Cin_p == CI_T, full tiles - the host
 // checks): a workgroup walks `strip` tiles of one tile row.  Per tile and wave exactly PT buffer loads (the next
-// tile's patch, hardware zero-fill at the borders) and 4*NB buffer stores are issued, unconditionally, so the
+// tile's patch, hardware zero-fill at the borders) and NB 16-byte buffer stores are issued, unconditionally, so the
 // compiler's vmcnt bookkeeping stays exact across the loop: the wait for the prefetched patch does not drain the
 // stores of the tile that was just written.  The weight slab is staged in LDS once per strip.
 template <class Cfg>
@@ -374,12 +395,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
   f32x4 acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = co0 + (lane >> 4) * 4 + r;
-    bv[r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
-  }
+  // The MFMA below takes the activation patch as A and the weight slab as B, so D comes out [pixel][channel]: each
+  // lane ends up with 4 CONSECUTIVE PIXELS (rows 4(l>>4)+r of the 16-pixel block) of ONE output channel (l&15) and
+  // the epilogue is one 16-byte store per block instead of four 4-byte ones (store-issue bound otherwise).
+  const int co_lane = co0 + (lane & 15);
+  const float bv = (p.bias != nullptr && co_lane < p.Cout) ? p.bias[co_lane] * p.bias_scale : 0.f;
   // weight slab -> LDS (once)
 #pragma unroll
   for (int i = 0; i < WPT; ++i) {
@@ -397,12 +417,12 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
       p.y + (long long)n0 * p.Cout * out_plane, 0, (unsigned)(p.Cout * out_plane * 4), 0x00020000);
-  int vo_lane[NB];   // byte offset of this lane's pixel (tile at x = 0) in channel co0 + 4*(lane>>4)
+  int vo_lane[NB];   // byte offset of this lane's 4-pixel group (tile at x = 0) in channel co0 + (lane & 15)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int j = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
     const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
-    vo_lane[nb] = (int)(((long long)(co0 + (lane >> 4) * 4) * out_plane + (long long)(oy0 + ty) * p.Wo + tx) * 4);
+    vo_lane[nb] = (int)(((long long)co_lane * out_plane + (long long)(oy0 + ty) * p.Wo + tx) * 4);
   }
   auto xbase_of = [&](int ox) { return G::XMODE == XVECUP ? (ox >> 1) : ox; };
 
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
         const int slot = st % (PD + 1);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot], rb[slot][nb], acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot][nb], ra[slot], acc[nb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep "reads PD steps ahead, then this step's MFMAs" as written
       }
     }
@@ -448,13 +468,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
     // epilogue: + bias, activation; the per-lane part of the address is fixed for the strip, the rest is an SGPR
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+      u32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[nb][r] + bv[r];
+        float v = acc[nb][r] + bv;
         if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
-        const int soff = (int)(((long long)r * out_plane + ox0) * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, vo_lane[nb], soff, 0);
+        o[r] = __float_as_uint(v);
       }
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane[nb], ox0 * 4, 0);
       acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     GL_ACC(3)
@@ -534,8 +555,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
 
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
     __syncthreads();  // every wave is done reading the previous chunk
-    if (G::XMODE == XSCALAR) x_stage_scalar<G, CI_T, PLANE>(xst, p.in, xb, ci0, Xs, tid);
-    else x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
+    x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);   // every staging mode goes through the register prefetch
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
@@ -563,37 +583,49 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nb], a[mb], acc[mb][nb], 0, 0, 0);
         }
       }
     }
   }
   // ---- epilogue: + bias, activation, NCHW store ----
+  // The patch is the MFMA's A operand and the weights its B operand, so D is [pixel][channel]: a lane holds pixels
+  // 4(l>>4)+r (r = 0..3, consecutive along x in every tile geometry) of output channel l&15 -> one 16-byte store
+  // per accumulator tile when the row is 4-aligned (vector staging modes), four 4-byte ones for ragged shapes.
   const long long out_plane = (long long)p.Ho * p.Wo;
-  float bv[MB][4];
+  float bv[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
-      bv[mb][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
-    }
+  for (int mb = 0; mb < MB; ++mb) {
+    const int co = co0 + mb * 16 + (lane & 15);
+    bv[mb] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
-    const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
-    const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
-    if (n >= p.in.N || oy >= p.Ho || ox >= p.Wo) continue;
-    float* dst = p.y + ((long long)n * p.Cout + co0 + (lane >> 4) * 4) * out_plane + (long long)oy * p.Wo + ox;
+    const int j0 = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+      const int co = co0 + mb * 16 + (lane & 15);
+      if (co >= p.Cout) continue;
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + mb * 16 + (lane >> 4) * 4 + r;
-        if (co < p.Cout) {
-          float v = acc[mb][nb][r] + bv[mb][r];
-          if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
-          dst[(long long)(mb * 16 + r) * out_plane] = v;
+        v[r] = acc[mb][nb][r] + bv[mb];
+        if (p.act == GANLAB_ACT_LRELU) v[r] = gl_lrelu(v[r], p.slope);
+      }
+      if (G::XMODE != XSCALAR) {   // TW >= 8, Wo % 4 == 0, ox % 4 == 0: the 4 pixels share a row and are in range together
+        const int ty = (j0 >> G::TWL) & (TH - 1), tx = j0 & (TW - 1);
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (n0 < p.in.N && oy < p.Ho && ox < p.Wo)
+          *reinterpret_cast<float4*>(p.y + ((long long)n0 * p.Cout + co) * out_plane + (long long)oy * p.Wo + ox) =
+              float4{v[0], v[1], v[2], v[3]};
+      } else {                     // ragged / tiny geometries (down to 1x1 "pixels = samples"): element by element
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + r;
+          const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+          const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
+          if (n < p.in.N && oy < p.Ho && ox < p.Wo)
+            p.y[((long long)n * p.Cout + co) * out_plane + (long long)oy * p.Wo + ox] = v[r];
         }
       }
     }
@@ -705,7 +737,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int tyi = t2 % p.tiles_y, tni = t2 / p.tiles_y;
     const int ox0 = txi * TW, oy0 = tyi * TH, n0 = tni * NI;
     xst.init(p.in, tid, n0, oy0, ox0);
-    x_load<G, CI_T, PLANE>(xr, xst, p.in.x + (long long)n0 * p.in.Cin * plane, ci0, p.in.Cin, plane);
+    if constexpr (G::XMODE != XSCALAR)
+      x_load<G, CI_T, PLANE>(xr, xst, p.in.x + (long long)n0 * p.in.Cin * plane, ci0, p.in.Cin, plane);
     const float* gb = p.gy + (long long)n0 * p.Cout * oplane;
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
@@ -723,7 +756,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   if (tile < n_tiles) load_tile(tile);
   while (tile < n_tiles) {
     __syncthreads();
-    if (G::XMODE == XSCALAR)
+    if constexpr (G::XMODE == XSCALAR)
       x_stage_scalar<G, CI_T, PLANE>(xst, p.in, p.in.x + (long long)xst.n0_ * p.in.Cin * plane, ci0, Xs, tid);
     else
       x_store<G, CI_T, PLANE, false>(xr, xst, Xs, tid);
