@@ -22,6 +22,8 @@
 //   XMODE 0         : per-element path for ragged / tiny shapes (4x4, 8x8, linears, odd sizes), same register
 //                     prefetch (one float per item)
 // LDS strides are padded so the two k-halves of a 32-lane read group land on disjoint banks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -475,7 +477,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
         if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
         o[r] = __float_as_uint(v);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane[nb], ox0 * 4, 0);
+      // the x offset goes into the VGPR offset, not the SGPR soffset: with a register soffset the compiler's hazard
+      // recogniser assumes a >64-bit buffer store needs no wait state before its data VGPRs are rewritten, and on
+      // gfx950 the next block's epilogue then overwrites element 0 for the last lanes of each row (seen on MI355X)
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane[nb] + ox0 * 4, 0, 0);
       acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     GL_ACC(3)
@@ -487,6 +492,163 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
   }
   GL_ACC_FLUSH
   GL_T(3)
+}
+
+// Double-buffered VERTICAL strip kernel for the thinnest 3x3 layers (16 -> 16 channels: the whole weight set is 36
+// values per lane, ONE K-chunk).  Differences from conv_fwd_strip_kernel:
+//   * the weight slab lives in REGISTERS (lane l keeps W[tap][ci = 4 c4 + (l>>4)][co = l&15] for the 36 k-steps),
+//     so the loop issues one LDS read per MFMA instead of 1.25 and no LDS is spent on weights;
+//   * the patch is double-buffered in LDS (2 x 25.6 KB -> still 3 workgroups per CU): tile t+1 is written into the
+//     other buffer right after tile t's MFMA loop, so there is ONE barrier per tile;
+//   * a workgroup walks DOWN a column of tiles and neighbouring workgroups (consecutive block ids, same XCD) own
+//     neighbouring columns: at any time the workgroups in flight read and write the SAME image rows, i.e. whole
+//     4 KB rows of HBM pages, instead of 160-byte pieces of rows 4 KB apart.  Measured on the north-star conv
+//     (tools/strip_ablate.py): MFMA + LDS alone 1.16 ms, with the scattered reads and writes 1.77 ms.
+template <class Cfg>
+__global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
+  using G = typename Cfg::G;
+  constexpr int KS = Cfg::KS, NB = Cfg::NB, CI_T = Cfg::CI_T;
+  constexpr int RP = G::RP, PLANE = Cfg::PLANE, TW = G::TW, TH = G::TH, CO_T = Cfg::CO_T, XS = Cfg::XS;
+  constexpr int C4N = CI_T / 4, NSTEP = KS * KS * C4N, PD = 3;
+  constexpr int NITEMS = CI_T * G::R * G::ROW4, PT = ceil_div_c(NITEMS, 256);
+  static_assert(KS == 3 && Cfg::MB == 1 && G::NI == 1 && G::XMODE == XVEC && CI_T == 16, "16-channel 3x3 vector strips");
+  __shared__ __attribute__((aligned(16))) float smem[2 * XS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int co_t = bid % p.tiles_co;
+  bid /= p.tiles_co;
+  const int txi = bid % p.tiles_x;        // x fastest: neighbouring workgroups share image rows
+  bid /= p.tiles_x;
+  const int syi = bid % p.strips_x;       // (strips_x / strip count the strips along y here)
+  const int n0 = bid / p.strips_x;
+  const int ty0 = syi * p.strip;
+  const int ntiles = min(p.strip, p.tiles_y - ty0);
+  const int co0 = co_t * CO_T, ox0 = txi * TW, oy_first = ty0 * TH;
+  const int plane = p.in.Hi * p.in.Wi;
+  const float* xb = p.in.x + (long long)n0 * p.in.Cin * plane;
+
+  // staging items (ci, patch row r, float4 column q): byte offset without the row term (or the out-of-range marker
+  // when the column group lies in the zero padding / the item does not exist) and LDS offset | r << 20
+  int gbase[PT], lo[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % G::ROW4;
+    const int t = e / G::ROW4;
+    const int r = t % G::R, ci = t / G::R;
+    const int vx = ox0 - G::LP + 4 * q;
+    gbase[i] = (e < NITEMS && (unsigned)vx < (unsigned)p.in.Wi) ? (ci * plane + vx) * 4 : (int)0x80000000;
+    lo[i] = (ci * PLANE + r * RP + 4 * q) | (r << 20);
+  }
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane & 15);
+    const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    boff[nb] = ty * RP + tx + G::XOFF + (lane >> 4) * PLANE;
+  }
+  // weights -> registers (k-step st = tap * 4 + c4)
+  float wreg[NSTEP];
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st)
+    wreg[st] = p.wp[(long long)((st / C4N) * p.Cin_p + (st % C4N) * 4 + (lane >> 4)) * p.Cout_p + co0 + (lane & 15)];
+  const int co_lane = co0 + (lane & 15);
+  const float bv = (p.bias != nullptr && co_lane < p.Cout) ? p.bias[co_lane] * p.bias_scale : 0.f;
+
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (long long)n0 * p.Cout * out_plane, 0, (unsigned)(p.Cout * out_plane * 4), 0x00020000);
+  int vo_lane[NB];   // byte offset of this lane's 4-pixel group (tile row 0 of the image) in channel co0 + (lane & 15)
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int j = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
+    const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
+    vo_lane[nb] = (int)(((long long)co_lane * out_plane + (long long)ty * p.Wo + ox0 + tx) * 4);
+  }
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 xr[PT];
+  // patch of the tile whose first output row is `oy` (rows oy-1 .. oy+TH); oy >= Ho: every offset out of range
+  auto load_patch = [&](int oy) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int vy = oy - G::PADC + (lo[i] >> 20);
+      const bool ok = gbase[i] != (int)0x80000000 && (unsigned)vy < (unsigned)p.in.Hi;
+      const int off = ok ? gbase[i] + (int)((unsigned)vy * (unsigned)(p.in.Wi * 4)) : (int)0x80000000;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+  };
+  auto store_patch = [&](float* Xd) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+      if (tid + i * 256 < NITEMS) *reinterpret_cast<float4*>(Xd + (lo[i] & 0xfffff)) = xr[i];
+  };
+
+  int oy0 = oy_first;
+  load_patch(oy0);
+  store_patch(smem);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t, oy0 += TH) {
+    const float* Xb = smem + (t & 1) * XS;
+    // next tile's patch -> registers (past the end of the strip: out-of-range offsets, zeros, written but never read)
+#ifdef GL_ABL_NOLOAD   // tools/strip_ablate.py: every "next tile" load falls outside the descriptor (no HBM reads)
+    load_patch(1 << 28);
+#else
+    load_patch(t + 1 < ntiles ? oy0 + TH : (1 << 28));
+#endif
+#ifndef GL_ABL_NOMFMA
+    {
+      float rb[PD + 1][NB];
+      auto fetch = [&](int st, int slot) {
+        const int ky = st / (KS * C4N), kx = (st / C4N) % KS, c4 = st % C4N;
+        const float* xrow = Xb + ky * RP + c4 * 4 * PLANE + kx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) rb[slot][nb] = xrow[boff[nb]];
+      };
+#pragma unroll
+      for (int st = 0; st < PD; ++st) fetch(st, st % (PD + 1));
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + PD < NSTEP) fetch(st + PD, (st + PD) % (PD + 1));
+        const int slot = st % (PD + 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot][nb], wreg[st], acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+    // tile t+1 into the other buffer: its last readers (tile t-1) are behind the previous barrier
+    store_patch(smem + ((t + 1) & 1) * XS);
+    const int orow = oy0 * p.Wo * 4;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      u32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nb][r] + bv;
+        if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+        o[r] = __float_as_uint(v);
+      }
+      // the row offset goes into the VGPR offset, not the SGPR soffset: with a register soffset the compiler's
+      // hazard recogniser assumes a >64-bit buffer store needs no wait state before its data VGPRs are rewritten,
+      // and on gfx950 the next block's epilogue then overwrites element 0 for the last lanes of each row
+#ifdef GL_ABL_NOSTORE   // only the last tile of the strip is written; the accumulators run on so every MFMA stays live
+      if (t + 1 == ntiles)
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane[nb] + orow, 0, 0);
+#ifndef GL_ABL_NOSTORE
+      acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+    }
+    __syncthreads();   // everyone is done reading buffer t&1 and buffer (t+1)&1 is complete
+  }
 }
 
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
@@ -870,7 +1032,22 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
       a.strips_x = ceil_div(a.tiles_x, a.strip);
       const long long sgrid = (long long)a.strips_x * a.tiles_y * a.tiles_n * a.tiles_co;
       if (sgrid <= 0 || sgrid > 0x7fffffffLL) return GANLAB_EINVAL;
-      GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
+      if constexpr (Cfg::KS == 3 && G::XMODE == XVEC) {   // weights in registers, double-buffered patch
+        static const bool old_strip = getenv("GANLAB_STRIP_OLD") != nullptr;   // ablation knob (tools/)
+        if (old_strip) {
+          GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
+        } else {   // vertical strips: `strip` tiles down a column, `strips_x` strips per column
+          int ky = 1;
+          while (ky < a.tiles_y && tiles / ceil_div(a.tiles_y, ky) < 6144) ++ky;
+          a.strip = ceil_div(a.tiles_y, ky);
+          a.strips_x = ceil_div(a.tiles_y, a.strip);
+          const long long vgrid = (long long)a.tiles_x * a.strips_x * a.tiles_n * a.tiles_co;
+          if (vgrid <= 0 || vgrid > 0x7fffffffLL) return GANLAB_EINVAL;
+          GL_LAUNCH(conv_fwd_strip2_kernel<Cfg>, dim3((unsigned)vgrid), dim3(256), 0, st, a);
+        }
+      } else {
+        GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
+      }
       return GL_CHECK_LAUNCH();
     }
   }

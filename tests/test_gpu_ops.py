@@ -501,3 +501,25 @@ def test_conv_act_blur_fused_backward(ops, case):
 
     for a, r, name in zip(run('gpu'), run('cpu'), ['y', 'gx', 'd pen/dw', 'd pen/db']):
         assert_close(a.detach().cpu(), r.detach(), TOL, name)
+
+
+def test_thin_layer_multi_tile_strips(ops):
+    """The strip kernels (a workgroup walks several 32x8 tiles of one tile row, double-buffered patch, weights in
+    registers) only engage when a layer has >= 6144 strips: 12 x 16ch x 512^2 gives strips of 2 tiles.  Forward with
+    the fused bias + LeakyReLU epilogue and the input gradient (same kernel, dgrad-packed weights) against the
+    oracle's conv on the CPU; the edges of every strip (zero padding, last tile of a row) are in the comparison."""
+    gen = torch.Generator().manual_seed(2024)
+    n, c, r = 12, 16, 512
+    x = rnd(gen, n, c, r, r)
+    wt = rnd(gen, c, c, 3, 3)
+    b = rnd(gen, c)
+    scale = 1.0 / np.sqrt(c * 9)
+    xg = gpu(x).requires_grad_(True)
+    y = ops.conv2d(xg, gpu(wt), gpu(b), scale=scale, padding=1, act='lrelu', slope=0.2)
+    pre = F.conv2d(x * scale, wt, b, padding=1)
+    assert_close(y.detach().cpu(), F.leaky_relu(pre, 0.2), TOL, 'strip fwd')
+    gy = rnd(gen, n, c, r, r)
+    y.backward(gpu(gy))
+    gz = gy * torch.where(y.detach().cpu() > 0, 1.0, 0.2)    # the kernel's own sign pattern (|pre| ~ 1e-7 ties)
+    gx = F.conv_transpose2d(gz, wt * scale, padding=1)
+    assert_close(xg.grad.cpu(), gx, TOL, 'strip dgrad')
