@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
 //     (tools/strip_ablate.py): MFMA + LDS alone 1.16 ms, with the scattered reads and writes 1.77 ms.
 template <class Cfg>
 __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
+  GL_T(0)
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, PLANE = Cfg::PLANE, TW = G::TW, TH = G::TH, CO_T = Cfg::CO_T, XS = Cfg::XS;
@@ -594,6 +595,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
   load_patch(oy0);
   store_patch(smem);
   __syncthreads();
+  GL_T(1)
+  GL_T(2)
+  GL_ACC_DECL
   for (int t = 0; t < ntiles; ++t, oy0 += TH) {
     const float* Xb = smem + (t & 1) * XS;
     // next tile's patch -> registers (past the end of the strip: out-of-range offsets, zeros, written but never read)
@@ -624,8 +628,10 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
       }
     }
 #endif
+    GL_ACC(2)
     // tile t+1 into the other buffer: its last readers (tile t-1) are behind the previous barrier
     store_patch(smem + ((t + 1) & 1) * XS);
+    GL_ACC(1)
     const int orow = oy0 * p.Wo * 4;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -647,8 +653,12 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
       acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
     }
+    GL_ACC(3)
     __syncthreads();   // everyone is done reading buffer t&1 and buffer (t+1)&1 is complete
+    GL_ACC(0)
   }
+  GL_ACC_FLUSH
+  GL_T(3)
 }
 
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
