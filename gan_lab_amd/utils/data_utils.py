@@ -45,9 +45,13 @@ class SyntheticImageLoader(object):
         i = 0
         while i + self.batch_sampler.batch_size <= len(self.dataset):
             bs, res = self.batch_sampler.batch_size, self.res
-            xb = torch.rand(bs, self.channels, res, res, generator=self.gen) * 2 - 1
-            self.served.append((bs, res))
-            yield xb.to(self.device), torch.zeros(bs, dtype=torch.int64)
+            if str(self.device) != 'cpu':     # synthetic reals drawn on the device: no host RNG / PCIe in the loop
+                xb = torch.rand(bs, self.channels, res, res, device=self.device) * 2 - 1
+            else:
+                xb = torch.rand(bs, self.channels, res, res, generator=self.gen) * 2 - 1
+            if not self.served or self.served[-1] != (bs, res):
+                self.served.append((bs, res))
+            yield xb, torch.zeros(bs, dtype=torch.int64)
             i += bs
 
 
