@@ -92,9 +92,11 @@ def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32'):
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4),
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-            # profiles/r01_northstar_conv_pmc.csv: equals the algorithmic 2 GiB in + 2 GiB out
-            'traffic': 4.2953e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on this
+            # kernel, profiles/r01c_northstar_conv_pmc.csv: 2.42e9 read (1.12x the algorithmic 2 GiB: halo rows /
+            # columns that miss L2) + 2.17e9 written; same file: MFMA pipes busy 0.68-0.71 of the kernel's cycles
+            # at an effective clock of 1.75-2.1 GHz
+            'traffic': 4.5835e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
             'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
                        f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
                        f'{c}->{c} @{res}^2 x{batch}'),
