@@ -219,3 +219,38 @@ def test_phase_schedule_restore_continues_identically():
         lb = []
         run(b, 60 - k, lb)
         assert la + lb == log_full, k
+
+
+def test_bf16_compute_mode_host_side():
+    """Config #2 plumbing without a GPU: which geometries the bf16-compute kernels take (pure host query), the
+    packed-weight size query, the config field, and that a layer's kernel choice is frozen when its Geom is built."""
+    from gan_lab_amd import _lib, ops
+    from gan_lab_amd.config import make_config
+    L = _lib.lib()
+
+    def ok(n, cin, h, w, cout, ks=3, pad=1, up=0, pool=0):
+        return L.ganlab_conv_bf16_supported(ctypes.byref(_lib.ConvGeom(n, cin, h, w, cout, ks, pad, up, pool)))
+    assert ok(8, 128, 128, 128, 128) == 1 and ok(8, 512, 32, 32, 512) == 1 and ok(8, 256, 64, 64, 128) == 1
+    assert ok(8, 128, 16, 16, 128) == 0          # W < 32: stays on the exact fp32 kernels
+    assert ok(8, 16, 1024, 1024, 16) == 0        # thin layers
+    assert ok(8, 96, 32, 32, 128) == 0           # Cin not a multiple of 64
+    assert ok(8, 128, 32, 32, 128, ks=1, pad=0) == 0 and ok(8, 128, 32, 32, 128, up=1) == 0
+    assert ok(8, 128, 36, 32, 128) == 0          # H % 8
+    assert L.ganlab_conv_pack_bf16(None, None, 128, 256, 0, 1.0, None) == 9 * 128 * 256
+    assert L.ganlab_conv_pack_bf16(None, None, 100, 256, 0, 1.0, None) == -1
+    assert L.ganlab_conv_wgrad_bf16_workspace(ctypes.byref(_lib.ConvGeom(8, 128, 32, 32, 128, 3, 1, 0, 0))) > 0
+
+    assert make_config('stylegan', dev='cuda').compute_dtype == 'f32'
+    assert make_config('stylegan', dev='cuda', compute_dtype='bf16').compute_dtype == 'bf16'
+    with pytest.raises(ValueError):
+        ops.set_compute_dtype('fp8')
+    assert ops.get_compute_dtype() == 'f32'
+    with ops.compute_dtype('bf16'):
+        g_bf = ops.Geom(8, 128, 32, 32, 128, 3, 1)
+        g_up = ops.Geom(8, 256, 32, 32, 128, 3, 1, up=1)       # upsample materialised, then the bf16 conv at 64^2
+        g_thin = ops.Geom(8, 16, 64, 64, 16, 3, 1)
+        assert not ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)  # conv (bf16) then pool, no stride-2 fusion
+    assert g_bf.bf is not None and g_up.bf is not None and (g_up.bf.Hin, g_up.up, g_up.s2) == (64, 1, False)
+    assert g_thin.bf is None
+    assert ops.get_compute_dtype() == 'f32' and ops.Geom(8, 128, 32, 32, 128, 3, 1).bf is None
+    assert ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)
