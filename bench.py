@@ -98,6 +98,7 @@ def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32'):
             # at an effective clock of 1.75-2.1 GHz
             'traffic': 4.5835e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
             'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
+                       f'conv_fwd_strip2_kernel<KS=3,16co,32x8 vertical strips> {c}->{c} @{res}^2 x{batch}' if c <= 16 else
                        f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
                        f'{c}->{c} @{res}^2 x{batch}'),
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}

@@ -78,6 +78,11 @@ SIGNATURES = {
     'ganlab_u8_box_decode_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     'ganlab_chan_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_mul_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
+    'ganlab_ln_affine_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_colscale_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_coldot_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_rowdot_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_ln_bwdbwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_tanh_fwd_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
     'ganlab_tanh_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
     'ganlab_mbstd_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),

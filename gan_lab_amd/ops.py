@@ -969,10 +969,126 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.
     return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
 
 
+def _ln_project(g, x, mean, rstd, n, m):
+    """P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) per row, plus the two row sums (sum g, sum g*xhat):
+    the instance-norm backward kernels with rows as planes."""
+    L = _lib.lib()
+    s1, s2 = _new((n,), x), _new((n,), x)
+    check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(g), _p(x), _p(mean), _p(rstd), _p(s1), _p(s2), n, m, _st()),
+          'ln_bwd_reduce')
+    out = torch.empty_like(x)
+    check(L.ganlab_instnorm_style_bwd_apply_f32(_p(g), _p(x), _p(mean), _p(rstd), None, _p(s1), _p(s2), _p(out), n, 1,
+                                                m, _st()), 'ln_bwd_apply')
+    return out, s1, s2
+
+
+class _LayerNorm(Function):
+    """nn.LayerNorm(x.shape[1:]) with elementwise affine on fused kernels (csrc/norm.hip): 2 launches forward,
+    5 backward, 8 for the backward of the backward (WGAN-GP through the critic)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = _c(x)
+        n = x.shape[0]
+        m = x.numel() // n
+        w = _c(weight).reshape(m) if weight is not None else None
+        b = _c(bias).reshape(m) if bias is not None else None
+        L = _lib.lib()
+        mean, rstd = _new((n,), x), _new((n,), x)
+        check(L.ganlab_instnorm_stats_f32(_p(x), _p(mean), _p(rstd), n, m, eps, _st()), 'ln_stats')
+        y = torch.empty_like(x)
+        check(L.ganlab_ln_affine_fwd_f32(_p(x), _p(mean), _p(rstd), _p(w), _p(b), _p(y), n, m, _st()), 'ln_affine_fwd')
+        ctx.save_for_backward(x, weight, mean, rstd)   # the weight INPUT: the double backward reaches the parameter
+        ctx.wshape = weight.shape if weight is not None else None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        w = weight.reshape(-1) if weight is not None else None      # tracked under create_graph
+        want_p = _want_param_grads() and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        gx, gw, gb = _LayerNormBwd.apply(gy, x, w, mean, rstd, want_p)
+        if gw is not None and ctx.wshape is not None:
+            gw = gw.reshape(ctx.wshape)
+            gb = gb.reshape(ctx.wshape) if ctx.has_bias else None
+        else:
+            gw = gb = None
+        return gx, gw, gb if ctx.has_bias else None, None
+
+
+class _LayerNormBwd(Function):
+    """(gy, x, w) -> (gx, gw, gb); its own backward is the analytic double backward for a cotangent of gx (the
+    gradient-penalty pass never keeps gw / gb: ops.input_grad_only)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, w, mean, rstd, want_param_grads):
+        gy = _c(gy)
+        w = _c(w) if w is not None else None
+        n = x.shape[0]
+        m = x.numel() // n
+        L = _lib.lib()
+        if w is not None:
+            ghat = torch.empty_like(gy)
+            check(L.ganlab_colscale_f32(_p(gy), _p(w), _p(ghat), n, m, _st()), 'ln_colscale')
+        else:
+            ghat = gy
+        gx, s1, s2 = _ln_project(ghat, x, mean, rstd, n, m)
+        gw = gb = None
+        if want_param_grads and w is not None:
+            gw, gb = _new((m,), x), _new((m,), x)
+            check(L.ganlab_coldot_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(gw), _p(gb), n, m, _st()), 'ln_param_grad')
+        ctx.save_for_backward(gy, x, w, mean, rstd, gx, s1, s2)
+        ctx.set_materialize_grads(False)
+        return gx, gw, gb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, u, ggw, ggb):
+        gy, x, w, mean, rstd, gx, s1, s2 = ctx.saved_tensors
+        if ggw is not None or ggb is not None:
+            raise NotImplementedError('LayerNorm double backward through the parameter gradients is not needed by the '
+                                      'GAN losses (the penalty differentiates the INPUT gradient only)')
+        if u is None:
+            return None, None, None, None, None, None
+        u = _c(u)
+        n = x.shape[0]
+        m = x.numel() // n
+        L = _lib.lib()
+        pu, su1, su2 = _ln_project(u, x, mean, rstd, n, m)
+        g_gy = g_w = None
+        if w is not None:
+            g_gy = torch.empty_like(gy)
+            check(L.ganlab_colscale_f32(_p(pu), _p(w), _p(g_gy), n, m, _st()), 'ln_colscale')
+            if _want_param_grads() and ctx.needs_input_grad[2]:
+                g_w = _new((m,), x)
+                check(L.ganlab_coldot_f32(_p(gy), _p(pu), None, None, _p(g_w), None, n, m, _st()), 'ln_coldot')
+        else:
+            g_gy = pu
+        r = _new((n,), x)
+        check(L.ganlab_rowdot_f32(_p(u), _p(gy), _p(w), _p(r), n, m, _st()), 'ln_rowdot')      # sum_m u * ghat
+        # tiny per-row arithmetic on N-element vectors
+        inv = 1.0 / m
+        a, beta, ubar, pbar = s1 * inv, s2 * inv, su1 * inv, su2 * inv
+        mut = r * inv - a * ubar - beta * pbar
+        c1 = (-(rstd * rstd) * mut).contiguous()
+        c2 = (-rstd * beta).contiguous()
+        c3 = (-rstd * pbar).contiguous()
+        g_x = torch.empty_like(x)
+        check(L.ganlab_ln_bwdbwd_apply_f32(_p(x), _p(mean), _p(rstd), _p(pu), _p(gx), _p(c1), _p(c2), _p(c3), _p(g_x),
+                                           n, m, _st()), 'ln_bwdbwd_apply')
+        return g_gy, g_x, g_w, None, None, None
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
-    """nn.LayerNorm(normalized_shape = x.shape[1:]) semantics: per-sample statistics over all
-    features (biased variance), then the elementwise affine; rows are handled as 'channels' of a
-    (1, N, F) view, the elementwise affine as channels of an (N, F, 1) view."""
+    """nn.LayerNorm(normalized_shape = x.shape[1:]) semantics: per-sample statistics over all features (biased
+    variance), then the elementwise affine - fused kernels with an analytic double backward (csrc/norm.hip)."""
+    return _LayerNorm.apply(x, weight, bias, float(eps))
+
+
+def layer_norm_composed(x, weight, bias, eps=1e-5):
+    """The same operator composed from channel sums / per-channel affines / products (every piece closed under
+    differentiation, so autograd derives any order): the cross-check of the fused kernels in the tests."""
     shape = x.shape
     n = shape[0]
     f = x.numel() // n

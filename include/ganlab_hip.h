@@ -187,6 +187,25 @@ int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, 
 int ganlab_chan_affine_f32(const float* x, const float* scale, const float* shift, float* y, int N, int C,
                            long long HW, void* stream);
 int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
+/* ---- fused LayerNorm([C,R,R]) of the ResNet critics, first and second order (csrc/norm.hip) ----------------
+ * resnetgan/resblocks.py:15-121 -> NormalizeLayer('LayerNorm') = nn.LayerNorm (custom_layers.py:100-107).  A sample
+ * is a row of M = C*R*R elements; mean / rstd come from ganlab_instnorm_stats_f32(planes = N, HW = M) and the
+ * affine-free operator P_x(g) from ganlab_instnorm_style_bwd_{reduce,apply}_f32 with a NULL style.
+ *   ln_affine_fwd:   y = (x - mean[n]) * rstd[n] * w[m] + b[m]                          (w, b nullable)
+ *   colscale:        out[n,m] = a[n,m] * w[m]                                           (ghat = gy * w)
+ *   coldot:          o1[m] = sum_n a * f,  f = (x - mean[n]) * rstd[n] (mean given) or x;  o2[m] = sum_n a (nullable)
+ *                    -> gw, gb of the backward; d/dw of the double backward
+ *   rowdot:          out[n] = sum_m a * b * (w ? w[m] : 1)
+ *   ln_bwdbwd_apply: out = c1[n] * xhat + c2[n] * pu + c3[n] * gx    (d/dx of the double backward, csrc/norm.hip) */
+int ganlab_ln_affine_fwd_f32(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+                             float* y, int N, long long M, void* stream);
+int ganlab_colscale_f32(const float* a, const float* w, float* out, int N, long long M, void* stream);
+int ganlab_coldot_f32(const float* a, const float* x, const float* mean, const float* rstd, float* o1, float* o2,
+                      int N, long long M, void* stream);
+int ganlab_rowdot_f32(const float* a, const float* b, const float* w, float* out, int N, long long M, void* stream);
+int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
+                               const float* c1, const float* c2, const float* c3, float* out, int N, long long M,
+                               void* stream);
 /* nn.Tanh of the ResNet generators (resnetgan/architectures.py:55, :93) */
 int ganlab_tanh_fwd_f32(const float* x, float* y, long long n, void* stream);
 int ganlab_tanh_bwd_f32(const float* gy, const float* y, float* gx, long long n, void* stream);

@@ -16,7 +16,7 @@ OUT = os.path.join(ROOT, 'gpurun_out', 'libganlab_phases.so')
 
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ('conv.hip', 'conv_s2.hip', 'conv_bf16.hip', 'pointwise.hip', 'data.hip')]
+    srcs = [os.path.join(CSRC, f) for f in ('conv.hip', 'conv_s2.hip', 'conv_bf16.hip', 'pointwise.hip', 'norm.hip', 'data.hip')]
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-DGL_PHASES',
                            '-o', OUT] + srcs)
 

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gan_lab_amd', 'csrc')
-SRCS = [os.path.join(CSRC, f) for f in ('conv.hip', 'conv_s2.hip', 'conv_bf16.hip', 'pointwise.hip', 'data.hip')]
+SRCS = [os.path.join(CSRC, f) for f in ('conv.hip', 'conv_s2.hip', 'conv_bf16.hip', 'pointwise.hip', 'norm.hip', 'data.hip')]
 VARIANTS = {'full': [], 'noload': ['-DGL_ABL_NOLOAD'], 'nostore': ['-DGL_ABL_NOSTORE'], 'nomfma': ['-DGL_ABL_NOMFMA'],
             'noload+nostore': ['-DGL_ABL_NOLOAD', '-DGL_ABL_NOSTORE'],
             }
