@@ -2,8 +2,9 @@
 // utils/custom_layers.py:100-107 = nn.LayerNorm, elementwise affine), first AND second order: the WGAN-GP penalty
 // (resnetgan/learner.py:780-827) differentiates the critic's input gradient, so the backward of the backward is
 // needed.  A sample is one row of M = C*R*R elements; statistics come from ganlab_instnorm_stats_f32(planes = N,
-// HW = M) and the affine-free operator P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) from
-// ganlab_instnorm_style_bwd_{reduce,apply}_f32 with a NULL style.  With ghat = gy * w:
+// HW = M); the affine-free operator P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) is ln_rowsums (several
+// blocks per row: a critic has only `batch` rows) + ln_project, both with the elementwise weight folded in.
+// With ghat = gy * w:
 //   forward          y  = xhat * w + b
 //   backward         gx = P_x(ghat),  gw[m] = sum_n gy * xhat,  gb[m] = sum_n gy
 //   backward^2 (cotangent u of gx; P_x is self-adjoint):
@@ -11,7 +12,7 @@
 //       d/d w  = sum_n gy * P_x(u)
 //       d/d x  = -rstd^2 * mean(u * t) * xhat - rstd * beta * P_x(u) - rstd * p * gx
 //                with t = ghat - a - xhat * beta, a = mean(ghat), beta = mean(ghat * xhat), p = mean(u * xhat)
-// The kernels here are the pieces the instance-norm kernels do not provide.  All HBM-bound, one pass each.
+// All HBM-bound, one pass each; reductions are deterministic (fixed-order partial sums, fp64 partials).
 #include "common.h"
 
 namespace {
@@ -62,25 +63,72 @@ __global__ void coldot_kernel(const float* __restrict__ a, const float* __restri
   if (o2 != nullptr) o2[m] = s2;
 }
 
-// out[n] = sum_m a[n,m] * b[n,m] * (w ? w[m] : 1): one 256-thread block per row, fp64 partials (rows of up to 2^18
-// elements whose terms cancel)
-__global__ void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
-                              float* __restrict__ out, long long M) {
-  __shared__ double red[4];
-  const long long n = blockIdx.x;
-  const float* ar = a + n * M;
-  const float* br = b + n * M;
-  double s = 0.0;
-  for (long long m = threadIdx.x; m < M; m += 256) {
-    float t = ar[m] * br[m];
-    if (w != nullptr) t *= w[m];
-    s += (double)t;
+// Row sums with several blocks per row (a critic LayerNorm has only N = batch rows of up to 2^18 elements):
+//   t = a[n,m] * (wa ? wa[m] : 1);  s0 = sum t;  s1 = sum t * xhat;  s2 = sum a * b2 * (w2 ? w2[m] : 1)  (b2 nullable)
+// grid = (S, N): block (s, n) reduces the slice [s*len, (s+1)*len) of row n into part[(n*S + s)*3 ..] (fp64);
+// rowsums_finish adds the S partials of a row in a fixed order.
+constexpr int ROWSUM_MAX_SPLIT = 64;
+__global__ void ln_rowsums_kernel(const float* __restrict__ a, const float* __restrict__ wa,
+                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ b2,
+                                  const float* __restrict__ w2, double* __restrict__ part, long long M, long long len) {
+  __shared__ double red[3][4];
+  const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+  const long long lo = sidx * len, hi = (lo + len < M) ? lo + len : M;
+  const float mu = mean[n], rs = rstd[n];
+  const float* ar = a + (long long)n * M;
+  const float* xr = x + (long long)n * M;
+  const float* br = b2 != nullptr ? b2 + (long long)n * M : nullptr;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (long long m = lo + threadIdx.x; m < hi; m += 256) {
+    const float av = ar[m];
+    const float t = wa != nullptr ? av * wa[m] : av;
+    s0 += (double)t;
+    s1 += (double)(t * ((xr[m] - mu) * rs));
+    if (br != nullptr) s2 += (double)(av * br[m] * (w2 != nullptr ? w2[m] : 1.f));
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+    red[2][threadIdx.x >> 6] = s2;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) out[n] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    part[((long long)n * S + sidx) * 3 + k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  }
+}
+
+__global__ void ln_rowsums_finish_kernel(const double* __restrict__ part, float* __restrict__ out, int N, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, k)
+  if (i >= N * 3) return;
+  const int n = i / 3, k = i % 3;
+  double s = 0.0;
+  for (int j = 0; j < S; ++j) s += part[((long long)n * S + j) * 3 + k];
+  out[i] = (float)s;
+}
+
+// out[n,m] = (wo ? wo[m] : 1) * rstd[n] * (a*(wa ? wa[m] : 1) - s0[n]/M - xhat * s1[n]/M),  sums = [N][3]
+__global__ void ln_project_kernel(const float* __restrict__ a, const float* __restrict__ wa,
+                                  const float* __restrict__ x, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ sums,
+                                  const float* __restrict__ wo, float* __restrict__ out, long long total, long long M,
+                                  float inv_m) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / M, m = i - n * M;
+    const float rs = rstd[n];
+    const float xh = (x[i] - mean[n]) * rs;
+    const float t = wa != nullptr ? a[i] * wa[m] : a[i];
+    float v = rs * (t - sums[n * 3] * inv_m - xh * sums[n * 3 + 1] * inv_m);
+    if (wo != nullptr) v *= wo[m];
+    out[i] = v;
+  }
 }
 
 // out[n,m] = c1[n] * xhat[n,m] + c2[n] * pu[n,m] + c3[n] * gx[n,m]
@@ -123,9 +171,33 @@ int ganlab_coldot_f32(const float* a, const float* x, const float* mean, const f
   return GL_CHECK_LAUNCH();
 }
 
-int ganlab_rowdot_f32(const float* a, const float* b, const float* w, float* out, int N, long long M, void* stream) {
-  if (!a || !b || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
-  GL_LAUNCH(rowdot_kernel, dim3((unsigned)N), dim3(256), 0, ST, a, b, w, out, M);
+size_t ganlab_ln_rowsums_workspace(int N, long long M) {
+  if (N <= 0 || M <= 0) return 0;
+  return (size_t)N * ROWSUM_MAX_SPLIT * 3 * sizeof(double);
+}
+
+int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
+                          const float* b2, const float* w2, float* out, int N, long long M, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!a || !x || !mean || !rstd || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
+  if (!workspace || workspace_bytes < ganlab_ln_rowsums_workspace(N, M)) return GANLAB_EWORKSPACE;
+  int S = (int)((M + 4095) / 4096);
+  if (S > ROWSUM_MAX_SPLIT) S = ROWSUM_MAX_SPLIT;
+  if (S < 1) S = 1;
+  const long long len = ((M + S - 1) / S + 255) / 256 * 256;
+  S = (int)((M + len - 1) / len);
+  double* part = reinterpret_cast<double*>(workspace);
+  GL_LAUNCH(ln_rowsums_kernel, dim3((unsigned)S, (unsigned)N), dim3(256), 0, ST, a, wa, x, mean, rstd, b2, w2, part, M,
+            len);
+  GL_LAUNCH(ln_rowsums_finish_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, ST, part, out, N, S);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
+                          const float* sums, const float* wo, float* out, int N, long long M, void* stream) {
+  if (!a || !x || !mean || !rstd || !sums || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(ln_project_kernel, dim3(ew_blocks((long long)N * M)), dim3(256), 0, ST, a, wa, x, mean, rstd, sums, wo,
+            out, (long long)N * M, M, 1.0f / (float)M);
   return GL_CHECK_LAUNCH();
 }
 

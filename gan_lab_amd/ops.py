@@ -969,22 +969,28 @@ def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.
     return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
 
 
-def _ln_project(g, x, mean, rstd, n, m):
-    """P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) per row, plus the two row sums (sum g, sum g*xhat):
-    the instance-norm backward kernels with rows as planes."""
+def _ln_rowsums(a, wa, x, mean, rstd, n, m, b2=None, w2=None):
+    """[N][3] row sums (see ganlab_ln_rowsums_f32): sum a*wa, sum a*wa*xhat, sum a*b2*w2."""
     L = _lib.lib()
-    s1, s2 = _new((n,), x), _new((n,), x)
-    check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(g), _p(x), _p(mean), _p(rstd), _p(s1), _p(s2), n, m, _st()),
-          'ln_bwd_reduce')
+    nbytes = L.ganlab_ln_rowsums_workspace(n, m)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    out = _new((n, 3), x)
+    check(L.ganlab_ln_rowsums_f32(_p(a), _p(wa), _p(x), _p(mean), _p(rstd), _p(b2), _p(w2), _p(out), n, m,
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'ln_rowsums')
+    return out
+
+
+def _ln_project(a, wa, x, mean, rstd, sums, wo, n, m):
+    """wo * P_x(a * wa) with P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) per row."""
     out = torch.empty_like(x)
-    check(L.ganlab_instnorm_style_bwd_apply_f32(_p(g), _p(x), _p(mean), _p(rstd), None, _p(s1), _p(s2), _p(out), n, 1,
-                                                m, _st()), 'ln_bwd_apply')
-    return out, s1, s2
+    check(_lib.lib().ganlab_ln_project_f32(_p(a), _p(wa), _p(x), _p(mean), _p(rstd), _p(sums), _p(wo), _p(out), n, m,
+                                           _st()), 'ln_project')
+    return out
 
 
 class _LayerNorm(Function):
     """nn.LayerNorm(x.shape[1:]) with elementwise affine on fused kernels (csrc/norm.hip): 2 launches forward,
-    5 backward, 8 for the backward of the backward (WGAN-GP through the critic)."""
+    4 backward, 7 for the backward of the backward (WGAN-GP through the critic)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
@@ -1028,24 +1034,20 @@ class _LayerNormBwd(Function):
         n = x.shape[0]
         m = x.numel() // n
         L = _lib.lib()
-        if w is not None:
-            ghat = torch.empty_like(gy)
-            check(L.ganlab_colscale_f32(_p(gy), _p(w), _p(ghat), n, m, _st()), 'ln_colscale')
-        else:
-            ghat = gy
-        gx, s1, s2 = _ln_project(ghat, x, mean, rstd, n, m)
+        sums = _ln_rowsums(gy, w, x, mean, rstd, n, m)                 # a = mean(ghat), beta = mean(ghat * xhat)
+        gx = _ln_project(gy, w, x, mean, rstd, sums, None, n, m)       # P_x(gy * w)
         gw = gb = None
         if want_param_grads and w is not None:
             gw, gb = _new((m,), x), _new((m,), x)
             check(L.ganlab_coldot_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(gw), _p(gb), n, m, _st()), 'ln_param_grad')
-        ctx.save_for_backward(gy, x, w, mean, rstd, gx, s1, s2)
+        ctx.save_for_backward(gy, x, w, mean, rstd, gx, sums)
         ctx.set_materialize_grads(False)
         return gx, gw, gb
 
     @staticmethod
     @once_differentiable
     def backward(ctx, u, ggw, ggb):
-        gy, x, w, mean, rstd, gx, s1, s2 = ctx.saved_tensors
+        gy, x, w, mean, rstd, gx, sums = ctx.saved_tensors
         if ggw is not None or ggb is not None:
             raise NotImplementedError('LayerNorm double backward through the parameter gradients is not needed by the '
                                       'GAN losses (the penalty differentiates the INPUT gradient only)')
@@ -1055,8 +1057,9 @@ class _LayerNormBwd(Function):
         n = x.shape[0]
         m = x.numel() // n
         L = _lib.lib()
-        pu, su1, su2 = _ln_project(u, x, mean, rstd, n, m)
-        g_gy = g_w = None
+        usums = _ln_rowsums(u, None, x, mean, rstd, n, m, b2=gy, w2=w)   # sum u, sum u*xhat, sum u*ghat
+        pu = _ln_project(u, None, x, mean, rstd, usums, None, n, m)      # P_x(u)
+        g_w = None
         if w is not None:
             g_gy = torch.empty_like(gy)
             check(L.ganlab_colscale_f32(_p(pu), _p(w), _p(g_gy), n, m, _st()), 'ln_colscale')
@@ -1065,12 +1068,11 @@ class _LayerNormBwd(Function):
                 check(L.ganlab_coldot_f32(_p(gy), _p(pu), None, None, _p(g_w), None, n, m, _st()), 'ln_coldot')
         else:
             g_gy = pu
-        r = _new((n,), x)
-        check(L.ganlab_rowdot_f32(_p(u), _p(gy), _p(w), _p(r), n, m, _st()), 'ln_rowdot')      # sum_m u * ghat
         # tiny per-row arithmetic on N-element vectors
         inv = 1.0 / m
-        a, beta, ubar, pbar = s1 * inv, s2 * inv, su1 * inv, su2 * inv
-        mut = r * inv - a * ubar - beta * pbar
+        a, beta = sums[:, 0] * inv, sums[:, 1] * inv
+        ubar, pbar, r = usums[:, 0] * inv, usums[:, 1] * inv, usums[:, 2] * inv
+        mut = r - a * ubar - beta * pbar
         c1 = (-(rstd * rstd) * mut).contiguous()
         c2 = (-rstd * beta).contiguous()
         c3 = (-rstd * pbar).contiguous()

@@ -189,20 +189,27 @@ int ganlab_chan_affine_f32(const float* x, const float* scale, const float* shif
 int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void* stream);
 /* ---- fused LayerNorm([C,R,R]) of the ResNet critics, first and second order (csrc/norm.hip) ----------------
  * resnetgan/resblocks.py:15-121 -> NormalizeLayer('LayerNorm') = nn.LayerNorm (custom_layers.py:100-107).  A sample
- * is a row of M = C*R*R elements; mean / rstd come from ganlab_instnorm_stats_f32(planes = N, HW = M) and the
- * affine-free operator P_x(g) from ganlab_instnorm_style_bwd_{reduce,apply}_f32 with a NULL style.
+ * is a row of M = C*R*R elements; mean / rstd come from ganlab_instnorm_stats_f32(planes = N, HW = M);
+ * P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) per row.
  *   ln_affine_fwd:   y = (x - mean[n]) * rstd[n] * w[m] + b[m]                          (w, b nullable)
  *   colscale:        out[n,m] = a[n,m] * w[m]                                           (ghat = gy * w)
  *   coldot:          o1[m] = sum_n a * f,  f = (x - mean[n]) * rstd[n] (mean given) or x;  o2[m] = sum_n a (nullable)
  *                    -> gw, gb of the backward; d/dw of the double backward
- *   rowdot:          out[n] = sum_m a * b * (w ? w[m] : 1)
+ *   ln_rowsums:      per row n, several blocks per row + a fixed-order finish (deterministic), out = [N][3]:
+ *                    t = a*(wa ? wa[m] : 1):  s0 = sum t,  s1 = sum t*xhat,  s2 = sum a*b2*(w2 ? w2[m] : 1) (b2 nullable)
+ *   ln_project:      out = (wo ? wo[m] : 1) * rstd[n] * (a*(wa ? wa[m] : 1) - s0/M - xhat*s1/M)   (= wo * P_x(a*wa))
  *   ln_bwdbwd_apply: out = c1[n] * xhat + c2[n] * pu + c3[n] * gx    (d/dx of the double backward, csrc/norm.hip) */
 int ganlab_ln_affine_fwd_f32(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
                              float* y, int N, long long M, void* stream);
 int ganlab_colscale_f32(const float* a, const float* w, float* out, int N, long long M, void* stream);
 int ganlab_coldot_f32(const float* a, const float* x, const float* mean, const float* rstd, float* o1, float* o2,
                       int N, long long M, void* stream);
-int ganlab_rowdot_f32(const float* a, const float* b, const float* w, float* out, int N, long long M, void* stream);
+size_t ganlab_ln_rowsums_workspace(int N, long long M);
+int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
+                          const float* b2, const float* w2, float* out, int N, long long M, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
+                          const float* sums, const float* wo, float* out, int N, long long M, void* stream);
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
                                const float* c1, const float* c2, const float* c3, float* out, int N, long long M,
                                void* stream);
