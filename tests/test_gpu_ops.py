@@ -503,13 +503,14 @@ def test_conv_act_blur_fused_backward(ops, case):
         assert_close(a.detach().cpu(), r.detach(), TOL, name)
 
 
-def test_thin_layer_multi_tile_strips(ops):
+@pytest.mark.parametrize('n,r', [(12, 512), (8, 1024)], ids=['12x512^2-strips-of-2', '8x1024^2-strips-of-5-and-3'])
+def test_thin_layer_multi_tile_strips(ops, n, r):
     """The strip kernels (a workgroup walks several 32x8 tiles of one tile row, double-buffered patch, weights in
     registers) only engage when a layer has >= 6144 strips: 12 x 16ch x 512^2 gives strips of 2 tiles.  Forward with
     the fused bias + LeakyReLU epilogue and the input gradient (same kernel, dgrad-packed weights) against the
     oracle's conv on the CPU; the edges of every strip (zero padding, last tile of a row) are in the comparison."""
     gen = torch.Generator().manual_seed(2024)
-    n, c, r = 12, 16, 512
+    c = 16           # (8, 1024): the north-star layer at its real width, ragged last strip (128 tile rows = 25*5 + 3)
     x = rnd(gen, n, c, r, r)
     wt = rnd(gen, c, c, 3, 3)
     b = rnd(gen, c)
