@@ -40,7 +40,7 @@ def main():
             ('act_bwd_blur AT (2R1W)', 3, lambda: ops.k_act_bwd_blur(x, y, nz, 0.2, 1.0, True, True)),
             ('axpby (2R1W)', 3, lambda: ops.k_axpby(x, y, 0.5, 0.5)),
             ('pool2 (1R .25W)', 1.25, lambda: ops.k_pool2(x)),
-            ('instnorm stats (1R)', 1, lambda: ops._lib.lib() and ops._InstNormStyle.apply(x, None, 1e-8)),
+            ('instnorm stats+apply (2R1W)', 3, lambda: ops._InstNormStyle.apply(x, None, 1e-8)),
         ]
         print(f'--- {n}x{c}x{r}x{r}: {sz:.2f} GB per tensor')
         for name, units, fn in rows:
