@@ -22,8 +22,6 @@
 //   XMODE 0         : per-element path for ragged / tiny shapes (4x4, 8x8, linears, odd sizes), same register
 //                     prefetch (one float per item)
 // LDS strides are padded so the two k-halves of a 32-lane read group land on disjoint banks.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -1043,10 +1041,12 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
       const long long sgrid = (long long)a.strips_x * a.tiles_y * a.tiles_n * a.tiles_co;
       if (sgrid <= 0 || sgrid > 0x7fffffffLL) return GANLAB_EINVAL;
       if constexpr (Cfg::KS == 3 && G::XMODE == XVEC) {   // weights in registers, double-buffered patch
-        static const bool old_strip = getenv("GANLAB_STRIP_OLD") != nullptr;   // ablation knob (tools/)
-        if (old_strip) {
+#ifdef GL_ABL_OLDSTRIP   // ablation builds (tools/strip_ablate.py): horizontal strips, weights in LDS
+        if (true) {
           GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
-        } else {   // vertical strips: `strip` tiles down a column, `strips_x` strips per column
+        } else
+#endif
+        {   // vertical strips: `strip` tiles down a column, `strips_x` strips per column
           int ky = 1;
           while (ky < a.tiles_y && tiles / ceil_div(a.tiles_y, ky) < 6144) ++ky;
           a.strip = ceil_div(a.tiles_y, ky);

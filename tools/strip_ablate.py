@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'gan_lab_amd', 'csrc')
 SRCS = [os.path.join(CSRC, f) for f in ('conv.hip', 'conv_s2.hip', 'conv_bf16.hip', 'pointwise.hip', 'norm.hip', 'data.hip')]
-VARIANTS = {'full': [], 'noload': ['-DGL_ABL_NOLOAD'], 'nostore': ['-DGL_ABL_NOSTORE'], 'nomfma': ['-DGL_ABL_NOMFMA'],
+VARIANTS = {'full': [], 'old horizontal strip kernel': ['-DGL_ABL_OLDSTRIP'], 'noload': ['-DGL_ABL_NOLOAD'], 'nostore': ['-DGL_ABL_NOSTORE'], 'nomfma': ['-DGL_ABL_NOMFMA'],
             'noload+nostore': ['-DGL_ABL_NOLOAD', '-DGL_ABL_NOSTORE'],
             }
 
@@ -39,7 +39,7 @@ def main():
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     for name, flags in VARIANTS.items():
-        so = os.path.join(out, f'libganlab_abl_{name.replace("+", "_")}.so')
+        so = os.path.join(out, f'libganlab_abl_{name.replace("+", "_").replace(" ", "_")}.so')
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-o', so] +
                               flags + SRCS, stderr=subprocess.DEVNULL)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), so, name])
