@@ -69,10 +69,13 @@ def one_step(learner, real):
     return ld, lg
 
 
-def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32'):
-    """Average launch duration of the north-star conv kernel instance, device events on the launch stream."""
+def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32', c=None, r=None):
+    """Average launch duration of one 3x3 conv kernel instance (default: the north-star layer of the top resolution),
+    device events on the launch stream."""
     from gan_lab_amd import ops
-    c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
+    if c is None:
+        c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
+    res = r or res
     x = torch.randn(batch, c, res, res, device='cuda')
     w = torch.randn(c, c, 3, 3, device='cuda')
     g = ops.Geom(batch, c, res, res, c, 3, 1, 0)
@@ -206,6 +209,12 @@ def main():
     if rank == 0:
         out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res, dtype=a.dtype)
         torch.cuda.empty_cache()
+        if not a.no_roofline and a.res == 1024 and a.dtype == 'f32':
+            # the kernel with the largest share of the step (profiles/r01c_step_kernel_stats.csv: conv_fwd_kernel
+            # <KS=3,MB=4,32x8>, 15.6% of the step, the 64..512-channel stride-1 layers): its 256->256 @64^2 instance
+            out['roofline_top_kernel_by_time'] = measure_dominant_kernel(torch, a.batch, a.res, c=256, r=64)
+            out['roofline_top_kernel_by_time']['traffic'] = None
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             cres = a.cpu_baseline_res or a.res
             out['cpu_baseline'] = cpu_baseline(torch, cres, a.cpu_baseline_batch)

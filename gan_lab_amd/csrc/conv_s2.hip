@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2_up_kernel(S2Args p) {
 // ================================================================================================
 // W : 16-tap weight gradient.  gK4[tap][cl][ch] = sum_{n,Y,X} low[n,cl,Y,X] * high_pad[n,ch,2Y+a-1,2X+b-1]
 //   A = low tile [cl][px] (16 channels per workgroup), B = parity planes of the high patch
-//   [4 parities][16 ch][PL]; the 4 waves split the tile's 4-pixel K-steps; accumulators 16 taps x f32x4.
+//   [4 parities][16 ch][PL]; wave w owns the tap row a = w (4 taps x NBA accumulators = 32 registers) and walks ALL
+//   of the tile's 4-pixel K-steps, so the kernel needs ~130 VGPRs and 40 KB of LDS: 3-4 workgroups per CU cover each
+//   other's staging and barriers (with the K-steps split over the waves instead - 128 accumulator registers, 2
+//   workgroups per CU - the kernel ran at 55% of the MFMA peak), and a workgroup dumps ONE slot instead of four.
 //   Each workgroup walks tiles split, split+S, ... and dumps to its slot; reduce_s2_kernel sums the
 //   slots and folds K4 back to 3x3:  gw[ky][kx] = scale * sum_{a,b} M[a][ky] M[b][kx] gK4[a][b].
 // ================================================================================================
@@ -443,7 +446,9 @@ struct WCfg {
   static constexpr int NBA = NBA_, CL_T = 16 * NBA_;
   static constexpr int TW = 16, TH = 4, TWL = 4, PX_T = 64;
   static constexpr int RPL = TW + 4, RL = TH + 2;
-  static constexpr int PL = pad_mod32(RL * RPL, 2);
+  // plane pitch = 26 (mod 32): 16 channels land on 16 distinct even banks, the next pixel on the odd ones, and
+  // the workgroup stays under 40 KB of LDS (registers, 159 VGPRs, allow 3 per CU; forcing 128 VGPRs spills and is slower)
+  static constexpr int PL = pad_mod32(RL * RPL, 26);
   static constexpr int HROWS = 2 * RL, HROW4 = (2 * TW + 8) / 4;
   static constexpr int GP = pad_mod32(PX_T, 2);
   static constexpr int GS = CL_T * GP, XS = 4 * 16 * PL;
@@ -452,7 +457,7 @@ struct WCfg {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(256, 2) void conv_s2_wgrad_kernel(W2Args p) {
+__global__ __launch_bounds__(256, 3) void conv_s2_wgrad_kernel(W2Args p) {
   constexpr int NBA = Cfg::NBA;
   constexpr int PL = Cfg::PL, RPL = Cfg::RPL, GP = Cfg::GP, TW = Cfg::TW, TH = Cfg::TH, XPT = Cfg::XPT,
                 GPT = Cfg::GPT, PX_T = Cfg::PX_T;
@@ -468,11 +473,14 @@ __global__ __launch_bounds__(256, 2) void conv_s2_wgrad_kernel(W2Args p) {
   const int cl0 = cl_t * Cfg::CL_T, ch0 = ch_t * 16;
   const int H = 2 * p.Hl, W = 2 * p.Wl, hplane = H * W, lplane = p.Hl * p.Wl;
 
-  f32x4 acc[16][NBA];
+  f32x4 acc[4][NBA];
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int m = 0; m < NBA; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's tap row a = wk: parity plane and row offset of the high-resolution operand
+  const int a_py = (wk == 0 || wk == 2) ? 1 : 0, a_dy = wk == 0 ? -1 : (wk == 3 ? 1 : 0);
+  const int tap_base = (a_py * 2 * 16) * PL + a_dy * RPL;
 
   // tile-independent descriptor parts
   int xrel[XPT], xl[XPT];   // (hr, q) packed ; LDS offset | ch<<20
@@ -543,37 +551,34 @@ __global__ __launch_bounds__(256, 2) void conv_s2_wgrad_kernel(W2Args p) {
     __syncthreads();
     const int next = tile + p.S;
     if (next < n_tiles) load_tile(next);
-    for (int q = wk; q < PX_T / 4; q += 4) {
+#pragma unroll 4
+    for (int q = 0; q < PX_T / 4; ++q) {
       const int j = 4 * q + (lane >> 4);
       const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
-      const int poff = (ty + 1) * RPL + tx + 2 + (lane & 15) * PL;
+      const int poff = (ty + 1) * RPL + tx + 2 + (lane & 15) * PL + tap_base;
       float av[NBA];
 #pragma unroll
       for (int m = 0; m < NBA; ++m) av[m] = Gs[(m * 16 + (lane & 15)) * GP + j];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int b = 0; b < 4; ++b) {
+        const float bv = Xs[(cPY(b) * 16) * PL + poff + cDY(b)];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const float bv = Xs[((cPY(a) * 2 + cPY(b)) * 16) * PL + poff + cDY(a) * RPL + cDY(b)];
-#pragma unroll
-          for (int m = 0; m < NBA; ++m)
-            acc[a * 4 + b][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[a * 4 + b][m], 0, 0, 0);
-        }
+        for (int m = 0; m < NBA; ++m)
+          acc[b][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[b][m], 0, 0, 0);
       }
     }
     tile = next;
   }
-  // dump: D rows = cl (lane>>4)*4+r, col = ch (lane&15)
-  const int slot = split * 4 + wk;
-  float* dst = p.part + (long long)slot * 16 * p.Cl * p.Ch;
+  // dump: taps 4 wk + b of this workgroup's slot; D rows = cl (lane>>4)*4+r, col = ch (lane&15)
+  float* dst = p.part + (long long)split * 16 * p.Cl * p.Ch;
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int b = 0; b < 4; ++b)
 #pragma unroll
     for (int m = 0; m < NBA; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cl = cl0 + m * 16 + (lane >> 4) * 4 + r, ch = ch0 + (lane & 15);
-        if (cl < p.Cl && ch < p.Ch) dst[((long long)t * p.Cl + cl) * p.Ch + ch] = acc[t][m][r];
+        if (cl < p.Cl && ch < p.Ch) dst[((long long)(wk * 4 + b) * p.Cl + cl) * p.Ch + ch] = acc[b][m][r];
       }
 }
 
@@ -674,7 +679,7 @@ W2Plan plan_w2(int N, int Cl, int Ch, int Hl, int Wl) {
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
   pl.S = (int)S;
-  pl.slots = pl.S * 4;
+  pl.slots = pl.S;          // one slot per workgroup (its four waves own four different tap rows)
   return pl;
 }
 
