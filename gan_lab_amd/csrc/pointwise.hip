@@ -244,7 +244,22 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
   }
 }
 
+// rows per thread: R + 2 input rows are read for R output rows (the halo rows come from L1 / L2), so taller strips
+// mean less cache traffic: 8 rows for the large planes, 4 / 2 for the small ones
+// (measured, 32x16x1024^2 / 32x64x256^2: forward 1.13 -> 1.02 ms / 0.27 -> 0.28, blur-then-act' 1.41 -> 1.20 / 0.36 ->
+// 0.33, act'-then-blur 1.91 -> 2.26 / 0.36 -> 0.40 - its 134 registers cost occupancy - so 8 rows only where they won)
 inline int blur_rows(int H) { return (H & 3) == 0 ? 4 : 2; }
+inline int blur_rows_mode(int H, int mode) {
+  const int min8 = mode == BF_FWD ? 512 : (mode == BF_A ? 256 : (1 << 30));
+  return ((H & 7) == 0 && H >= min8) ? 8 : blur_rows(H);
+}
+#define BLUR_FUSED_LAUNCH(MODE, ...)                                                                   \
+  do {                                                                                                 \
+    const int rows_ = blur_rows_mode(H, MODE);                                                         \
+    if (rows_ == 8) GL_LAUNCH((blur_fused_kernel<MODE, 8>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);      \
+    else if (rows_ == 4) GL_LAUNCH((blur_fused_kernel<MODE, 4>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__); \
+    else GL_LAUNCH((blur_fused_kernel<MODE, 2>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);                \
+  } while (0)
 
 inline int blur_fused_chunks(int N, int H, int W) {
   long long c = ((long long)N * (H / blur_rows(H)) * (W / 4) + 256 * 4 - 1) / (256 * 4);
@@ -975,12 +990,8 @@ int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noi
   if (!x || !y || N <= 0 || C <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
-  if (blur_rows(H) == 4)
-    GL_LAUNCH((blur_fused_kernel<BF_FWD, 4>), dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise,
-              bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
-  else
-    GL_LAUNCH((blur_fused_kernel<BF_FWD, 2>), dim3(chunks, C), dim3(256), 0, ST, x, (const float*)nullptr, noise,
-              bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0);
+  BLUR_FUSED_LAUNCH(BF_FWD, x, (const float*)nullptr, noise, bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks,
+                    bias_scale, act, slope, 0);
   return GL_CHECK_LAUNCH();
 }
 
@@ -990,14 +1001,8 @@ int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* g
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
   if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
-  if (blur_rows(H) == 4)
-    GL_LAUNCH((blur_fused_kernel<BF_A, 4>), dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
-              (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
-              gb ? 1 : 0);
-  else
-    GL_LAUNCH((blur_fused_kernel<BF_A, 2>), dim3(chunks, C), dim3(256), 0, ST, g, y, (const float*)nullptr,
-              (const float*)nullptr, (const float*)nullptr, out, (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope,
-              gb ? 1 : 0);
+  BLUR_FUSED_LAUNCH(BF_A, g, y, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
+                    (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, gb ? 1 : 0);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
   return GL_CHECK_LAUNCH();
 }
@@ -1010,14 +1015,8 @@ int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, 
   const int chunks = blur_fused_chunks(N, H, W);
   const int sums = (gb || gnw) ? 1 : 0;
   if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
-  if (blur_rows(H) == 4)
-    GL_LAUNCH((blur_fused_kernel<BF_AT, 4>), dim3(chunks, C), dim3(256), 0, ST, g, y,
-              gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
-              (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
-  else
-    GL_LAUNCH((blur_fused_kernel<BF_AT, 2>), dim3(chunks, C), dim3(256), 0, ST, g, y,
-              gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
-              (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
+  BLUR_FUSED_LAUNCH(BF_AT, g, y, gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
+                    (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
   if (gnw)
     GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace + (size_t)C * chunks, gnw, C,
