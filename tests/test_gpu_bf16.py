@@ -218,3 +218,44 @@ def test_bf16_stylegan64_step_vs_fp32_oracle(ops, capsys):
     # measured on MI355X: img 6.0e-3, R1 3.4e-3, loss_d 7e-4, loss_g 1.4e-3, worst cosine 0.9936 (a noise weight)
     assert rep['img'] < 2e-2 and rep['loss_d'] < 1e-2 and rep['loss_g'] < 1e-2 and rep['gp'] < 2e-2, rep
     assert worst_cos > 0.98, rep
+
+
+def test_bf16_learner_trains_and_uses_the_bf16_kernels(ops, monkeypatch):
+    """config.compute_dtype='bf16' through the learner (BASELINE config #2's switch): a StyleGAN at 64 channels,
+    32^2, trains two iterations with finite losses, the eligible layers really run on the bf16 entry points, and a
+    later fp32 learner is back on the exact kernels."""
+    from gan_lab_amd import _lib, progressive as P
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.stylegan.learner import StyleGANLearner
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    calls = {'fwd': 0, 'dgrad': 0, 'wgrad': 0}
+    L_ = _lib.lib()
+    for name in ('fwd', 'dgrad', 'wgrad'):
+        orig = getattr(L_, f'ganlab_conv_{name}_bf16')
+
+        def counted(*a, _o=orig, _n=name):
+            calls[_n] += 1
+            return _o(*a)
+        monkeypatch.setattr(L_, f'ganlab_conv_{name}_bf16', counted, raising=False)
+    old = (P.FMAP_BASE, P.FMAP_MAX)
+    P.FMAP_BASE, P.FMAP_MAX = 1024, 64
+    try:
+        def cfg(dt):
+            return make_config('stylegan', dev='cuda', pin_memory=False, res_samples=32, res_dataset=32, init_res=32,
+                               batch_size=8, len_latent=64, len_dlatent=64, mapping_num_fcs=2, loss='nonsaturating',
+                               gradient_penalty='r1', cutoff_trunc_trick=None, num_iters_save_model=10 ** 9,
+                               log_every=1, compute_dtype=dt)
+        L = StyleGANLearner(cfg('bf16'))
+        assert ops.get_compute_dtype() == 'bf16'
+        L.train(SyntheticImageLoader(1024, 8, 32), num_main_iters=2)
+        import math
+        assert math.isfinite(L.last_losses['loss_d']) and math.isfinite(L.last_losses['loss_g'])
+        assert calls['fwd'] > 10 and calls['dgrad'] > 5 and calls['wgrad'] > 5, calls
+        n_bf16 = dict(calls)
+        L2 = StyleGANLearner(cfg('f32'))
+        assert ops.get_compute_dtype() == 'f32'
+        L2.train(SyntheticImageLoader(1024, 8, 32), num_main_iters=1)
+        assert calls == n_bf16
+    finally:
+        P.FMAP_BASE, P.FMAP_MAX = old
+        ops.set_compute_dtype('f32')
