@@ -338,92 +338,100 @@ class ProGANLearner(GANLearner):
         sched = self.sched
         self.nimg_transition_lst = sched.nimg_transition_lst
 
-        for itr in range(num_main_iters):
+        try:
+            for itr in range(num_main_iters):
+                self.set_requires_grad_disc(True)
+                for ev in sched.begin_iter():
+                    if ev == GROW:
+                        prev = self.gen_model.curr_res
+                        self._grow()
+                        self._bump_loader(train_dl)
+                        self._bump_loader(valid_dl)
+                        if z_valid_dl is not None:
+                            z_valid_dl.batch_sampler.batch_size = self.batch_size
+                        if parallel.rank() == 0:
+                            print(f'\n\n\nRESOLUTION INCREASED FROM {prev}x{prev} to {self.gen_model.curr_res}x'
+                                  f'{self.gen_model.curr_res}\n\nFADING IN {self.gen_model.curr_res}x'
+                                  f'{self.gen_model.curr_res} RESOLUTION...\n')
+                    elif ev == STABILISE:
+                        self._reset_opt_and_sched()
+                        if parallel.rank() == 0:
+                            print('\nSTABILIZING...\n')
+                    elif ev == FINAL:
+                        self._reset_opt_and_sched()
+                        self._progressively_grow = False
+                        if parallel.rank() == 0:
+                            print('\nSTABILIZING (FINAL)...\n')
+                self.curr_phase_num = sched.curr_phase_num
+                assert sched.curr_res == self.gen_model.curr_res and sched.batch_size == self.batch_size
+
+                # ------------------------- TRAIN DISCRIMINATOR -------------------------
+                for disc_iter in range(num_disc_iters):
+                    batch = next(self.train_dataiter, None)
+                    if batch is None:
+                        self.curr_epoch_num += 1
+                        self.train_dataiter = iter(train_dl)
+                        batch = next(self.train_dataiter)
+                    xb = batch[0].to(c.dev, non_blocking=True).float()
+                    last = disc_iter == num_disc_iters - 1
+                    valid_now = last and ((itr + 1) % c.num_iters_valid == 0 or itr == 0)
+                    d_metrics = valid_now and z_valid_dl is not None and valid_dl is not None and bool(c.disc_metrics)
+                    loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0 and not d_metrics)
+                    if d_metrics:       # validation metrics of the just-updated discriminator (:822-832)
+                        vals = self.compute_metrics(metrics=c.disc_metrics, metrics_type='Discriminator',
+                                                    z_valid_dl=z_valid_dl, valid_dl=valid_dl)
+                        if parallel.rank() == 0:
+                            print('|\n', 'Discriminator Validation Metrics:\n', *vals)
+                    self.curr_dataset_batch_num += 1
+                    sched.after_d_iter()
+                    self.curr_img_num = sched.curr_img_num
+
+                # --------------------------- TRAIN GENERATOR ---------------------------
+                self.set_requires_grad_disc(False)
+                loss_g = None
+                for gen_iter in range(num_gen_iters):
+                    loss_g = self.g_step(d_update_pending=(gen_iter == 0))
+                    if gen_iter == num_gen_iters - 1 and z_valid_dl is not None and c.gen_metrics and \
+                            ((itr + 1) % c.num_iters_valid == 0 or itr == 0):     # (:921-928)
+                        vals = self.compute_metrics(metrics=c.gen_metrics, metrics_type='Generator',
+                                                    z_valid_dl=z_valid_dl, valid_dl=None)
+                        if parallel.rank() == 0:
+                            print('|\n', 'Generator Validation Metrics:\n', *vals)
+                if num_gen_iters == 0:
+                    self._finish_d_update()
+
+                # alpha, LR schedule (progan/learner.py:951-956)
+                sched.end_iter()
+                if self.gen_model.fade_in_phase:
+                    if sched.fade_in_phase:
+                        self.gen_model.alpha = sched.alpha
+                    else:
+                        self.gen_model.alpha = 1      # snaps and leaves the fade-in phase for both networks
+                if self.sched_bool:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore')
+                        self.scheduler_gen.step()
+                        self.scheduler_disc.step()
+                self.not_trained_yet = False
+                if self.log_every and (itr % self.log_every == 0 or itr == num_main_iters - 1):
+                    self.last_losses = dict(itr=itr, loss_d=float(loss_d), loss_g=float(loss_g) if loss_g is not None
+                                            else None, res=self.gen_model.curr_res, alpha=float(self.gen_model.alpha),
+                                            fade_in=bool(self.gen_model.fade_in_phase), batch=self.batch_size)
+                    if parallel.rank() == 0:
+                        print(('%9s' * 6) % (f'{self.curr_epoch_num}', f'{self.gen_model.curr_res}X'
+                                             f'{self.gen_model.curr_res}',
+                                             'Fade In' if self.gen_model.fade_in_phase else 'Stab.',
+                                             '%.4g' % self.last_losses['loss_d'],
+                                             '%.4g' % (self.last_losses['loss_g'] or 0.), itr))
+                if (itr + 1) % c.num_iters_save_model == 0:
+                    self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+        except KeyboardInterrupt:
+            # progan/learner.py:986-1013: Ctrl-C saves the latest checkpoint before the run ends
             self.set_requires_grad_disc(True)
-            for ev in sched.begin_iter():
-                if ev == GROW:
-                    prev = self.gen_model.curr_res
-                    self._grow()
-                    self._bump_loader(train_dl)
-                    self._bump_loader(valid_dl)
-                    if z_valid_dl is not None:
-                        z_valid_dl.batch_sampler.batch_size = self.batch_size
-                    if parallel.rank() == 0:
-                        print(f'\n\n\nRESOLUTION INCREASED FROM {prev}x{prev} to {self.gen_model.curr_res}x'
-                              f'{self.gen_model.curr_res}\n\nFADING IN {self.gen_model.curr_res}x'
-                              f'{self.gen_model.curr_res} RESOLUTION...\n')
-                elif ev == STABILISE:
-                    self._reset_opt_and_sched()
-                    if parallel.rank() == 0:
-                        print('\nSTABILIZING...\n')
-                elif ev == FINAL:
-                    self._reset_opt_and_sched()
-                    self._progressively_grow = False
-                    if parallel.rank() == 0:
-                        print('\nSTABILIZING (FINAL)...\n')
-            self.curr_phase_num = sched.curr_phase_num
-            assert sched.curr_res == self.gen_model.curr_res and sched.batch_size == self.batch_size
-
-            # ------------------------- TRAIN DISCRIMINATOR -------------------------
-            for disc_iter in range(num_disc_iters):
-                batch = next(self.train_dataiter, None)
-                if batch is None:
-                    self.curr_epoch_num += 1
-                    self.train_dataiter = iter(train_dl)
-                    batch = next(self.train_dataiter)
-                xb = batch[0].to(c.dev, non_blocking=True).float()
-                last = disc_iter == num_disc_iters - 1
-                valid_now = last and ((itr + 1) % c.num_iters_valid == 0 or itr == 0)
-                d_metrics = valid_now and z_valid_dl is not None and valid_dl is not None and bool(c.disc_metrics)
-                loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0 and not d_metrics)
-                if d_metrics:       # validation metrics of the just-updated discriminator (:822-832)
-                    vals = self.compute_metrics(metrics=c.disc_metrics, metrics_type='Discriminator',
-                                                z_valid_dl=z_valid_dl, valid_dl=valid_dl)
-                    if parallel.rank() == 0:
-                        print('|\n', 'Discriminator Validation Metrics:\n', *vals)
-                self.curr_dataset_batch_num += 1
-                sched.after_d_iter()
-                self.curr_img_num = sched.curr_img_num
-
-            # --------------------------- TRAIN GENERATOR ---------------------------
-            self.set_requires_grad_disc(False)
-            loss_g = None
-            for gen_iter in range(num_gen_iters):
-                loss_g = self.g_step(d_update_pending=(gen_iter == 0))
-                if gen_iter == num_gen_iters - 1 and z_valid_dl is not None and c.gen_metrics and \
-                        ((itr + 1) % c.num_iters_valid == 0 or itr == 0):     # (:921-928)
-                    vals = self.compute_metrics(metrics=c.gen_metrics, metrics_type='Generator',
-                                                z_valid_dl=z_valid_dl, valid_dl=None)
-                    if parallel.rank() == 0:
-                        print('|\n', 'Generator Validation Metrics:\n', *vals)
-            if num_gen_iters == 0:
-                self._finish_d_update()
-
-            # alpha, LR schedule (progan/learner.py:951-956)
-            sched.end_iter()
-            if self.gen_model.fade_in_phase:
-                if sched.fade_in_phase:
-                    self.gen_model.alpha = sched.alpha
-                else:
-                    self.gen_model.alpha = 1      # snaps and leaves the fade-in phase for both networks
-            if self.sched_bool:
-                with warnings.catch_warnings():
-                    warnings.simplefilter('ignore')
-                    self.scheduler_gen.step()
-                    self.scheduler_disc.step()
-            self.not_trained_yet = False
-            if self.log_every and (itr % self.log_every == 0 or itr == num_main_iters - 1):
-                self.last_losses = dict(itr=itr, loss_d=float(loss_d), loss_g=float(loss_g) if loss_g is not None
-                                        else None, res=self.gen_model.curr_res, alpha=float(self.gen_model.alpha),
-                                        fade_in=bool(self.gen_model.fade_in_phase), batch=self.batch_size)
-                if parallel.rank() == 0:
-                    print(('%9s' * 6) % (f'{self.curr_epoch_num}', f'{self.gen_model.curr_res}X'
-                                         f'{self.gen_model.curr_res}',
-                                         'Fade In' if self.gen_model.fade_in_phase else 'Stab.',
-                                         '%.4g' % self.last_losses['loss_d'],
-                                         '%.4g' % (self.last_losses['loss_g'] or 0.), itr))
-            if (itr + 1) % c.num_iters_save_model == 0:
+            if not self.not_trained_yet and parallel.rank() == 0:
                 self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+                print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
+            raise
         self.set_requires_grad_disc(True)
 
     # ------------------------------------------------------------------------------------------------

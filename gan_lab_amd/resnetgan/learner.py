@@ -233,40 +233,48 @@ class GANLearner(object):
             per_epoch = max(self.dataset_sz // self.batch_size * self.batch_size, 1)
             self.tot_num_epochs = num_main_iters * self.batch_size * num_disc_iters // per_epoch + 1
         loss_d = loss_g = None
-        for itr in range(num_main_iters):
-            # ---------------------------- TRAIN GENERATOR ----------------------------
-            self.set_requires_grad_disc(False)
-            for _ in range(num_gen_iters):
-                loss_g = self.g_step()
-            # -------------------------- TRAIN DISCRIMINATOR --------------------------
+        try:
+            for itr in range(num_main_iters):
+                # ---------------------------- TRAIN GENERATOR ----------------------------
+                self.set_requires_grad_disc(False)
+                for _ in range(num_gen_iters):
+                    loss_g = self.g_step()
+                # -------------------------- TRAIN DISCRIMINATOR --------------------------
+                self.set_requires_grad_disc(True)
+                for _ in range(num_disc_iters):
+                    batch = next(self.train_dataiter, None)
+                    if batch is None:
+                        self.curr_epoch_num += 1
+                        self.train_dataiter = iter(train_dl)
+                        batch = next(self.train_dataiter)
+                    xb = batch[0].to(c.dev, non_blocking=True).float()
+                    loss_d = self.d_step(xb)
+                    self.curr_dataset_batch_num += 1
+                    self.curr_img_num += self.batch_size
+                if self.sched_bool:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore')
+                        self.scheduler_gen.step()
+                        self.scheduler_disc.step()
+                self.not_trained_yet = False
+                if self.log_every and (itr % self.log_every == 0 or itr == num_main_iters - 1):
+                    self.last_losses = dict(itr=itr, loss_d=float(loss_d) if loss_d is not None else None,
+                                            loss_g=float(loss_g) if loss_g is not None else None,
+                                            res=c.res_samples, batch=self.batch_size)
+                    if parallel.rank() == 0:
+                        print(('%9s' * 5) % (f'{self.curr_epoch_num}/{self.tot_num_epochs}',
+                                             f'{c.res_samples}X{c.res_samples}',
+                                             '%.4g' % (self.last_losses['loss_d'] or 0.),
+                                             '%.4g' % (self.last_losses['loss_g'] or 0.), itr))
+                if (itr + 1) % c.num_iters_save_model == 0:
+                    self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+        except KeyboardInterrupt:
+            # resnetgan/learner.py: Ctrl-C saves the latest checkpoint before the run ends
             self.set_requires_grad_disc(True)
-            for _ in range(num_disc_iters):
-                batch = next(self.train_dataiter, None)
-                if batch is None:
-                    self.curr_epoch_num += 1
-                    self.train_dataiter = iter(train_dl)
-                    batch = next(self.train_dataiter)
-                xb = batch[0].to(c.dev, non_blocking=True).float()
-                loss_d = self.d_step(xb)
-                self.curr_dataset_batch_num += 1
-                self.curr_img_num += self.batch_size
-            if self.sched_bool:
-                with warnings.catch_warnings():
-                    warnings.simplefilter('ignore')
-                    self.scheduler_gen.step()
-                    self.scheduler_disc.step()
-            self.not_trained_yet = False
-            if self.log_every and (itr % self.log_every == 0 or itr == num_main_iters - 1):
-                self.last_losses = dict(itr=itr, loss_d=float(loss_d) if loss_d is not None else None,
-                                        loss_g=float(loss_g) if loss_g is not None else None,
-                                        res=c.res_samples, batch=self.batch_size)
-                if parallel.rank() == 0:
-                    print(('%9s' * 5) % (f'{self.curr_epoch_num}/{self.tot_num_epochs}',
-                                         f'{c.res_samples}X{c.res_samples}',
-                                         '%.4g' % (self.last_losses['loss_d'] or 0.),
-                                         '%.4g' % (self.last_losses['loss_g'] or 0.), itr))
-            if (itr + 1) % c.num_iters_save_model == 0:
+            if not self.not_trained_yet and parallel.rank() == 0:
                 self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+                print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
+            raise
 
     def save_model(self, save_path):
         """Checkpoint as plain data (key names follow resnetgan/learner.py:1076-1140)."""

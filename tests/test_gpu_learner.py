@@ -191,3 +191,26 @@ def test_load_reference_written_checkpoint(tmp_path):
         lr.set_requires_grad_disc(True)
         lr.d_step(x, zb=z2, eps_interp=e2)
     assert rel_err(L2.arena_d.flat.cpu(), L.arena_d.flat.cpu()) < 1e-6
+
+
+def test_keyboard_interrupt_saves_a_checkpoint(tmp_path):
+    """Ctrl-C during train() saves the latest checkpoint before the exception propagates (progan/learner.py:986-1013)."""
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    L = make_learner('progan', 8, init_res=8, batch=4, save_model_dir=tmp_path)
+    dl = SyntheticImageLoader(4096, 4, 8)
+    orig, n = L.g_step, [0]
+
+    def g_step(*a, **k):
+        n[0] += 1
+        if n[0] == 3:
+            raise KeyboardInterrupt
+        return orig(*a, **k)
+    L.g_step = g_step
+    with pytest.raises(KeyboardInterrupt):
+        L.train(dl, num_main_iters=10)
+    ck = tmp_path / 'progan_model.tar'
+    assert ck.exists()
+    L2 = make_learner('progan', 8, init_res=8, batch=4)
+    L2.load_model(ck)
+    for (k, v), (_, v2) in zip(L.gen_model.state_dict().items(), L2.gen_model.state_dict().items()):
+        assert torch.equal(v.cpu(), v2.cpu()), k
