@@ -43,6 +43,9 @@ CONV_CASES = [
     (2, 32, 8, 8, 32, 3, 1, True, False, None),        # up at small res
     (1, 16, 128, 96, 16, 3, 1, False, False, None),    # non-square, 32x8 geometry with ragged tiles
     (5, 24, 20, 20, 40, 3, 1, False, True, None),      # nothing a power of two
+    (8, 16, 16, 16, 16, 3, 1, False, True, 'lrelu'),   # thin layer, 16x16-tile variant of the vertical strip kernel
+    (2, 12, 64, 16, 16, 3, 1, False, False, None),     # thin, channel padding (12 -> 16), tall narrow image
+    (2, 16, 24, 64, 16, 3, 1, False, True, None),      # thin, three tile rows of 8: strips with a top / bottom edge each
 ]
 
 
