@@ -558,10 +558,12 @@ class ProGANLearner(GANLearner):
             raise IndexError(f'Input latent vector must be of size {want}.')
 
     @torch.no_grad()
-    def generate(self, zs, time_average=True, **gen_kwargs):
+    def generate(self, zs, time_average=True, graph=False, **gen_kwargs):
         """Samples in [0, 1] image space, (N, 3, R, R) on the device: ``G(z) * ds_std + ds_mean`` from the EWMA
         generator (``time_average``) or the snapshot one - what plot_sample / make_image_grid display
-        (:1148-1234).  The networks' modes are left as the caller set them."""
+        (:1148-1234).  The networks' modes are left as the caller set them.  ``graph=True`` (eval-mode generator,
+        at most 16 latents, no extra forward arguments) replays a captured hipGraph of the forward
+        (gan_lab_amd/graphs.py): the latency-bound serving path."""
         self._check_sample_latents(zs)
         if time_average and self.gen_model_lagged is None:
             self._update_gen_lagged()
@@ -569,6 +571,14 @@ class ProGANLearner(GANLearner):
         gen = self.gen_model_lagged if time_average else self.gen_model
         dev = self.config.dev
         std, mean = self.ds_std.to(dev).view(1, -1, 1, 1), self.ds_mean.to(dev).view(1, -1, 1, 1)
+        if graph and not gen_kwargs and not gen.training and len(zs) <= 16:
+            from ..graphs import GraphedGenerator
+            key = (id(gen), len(zs), gen.curr_res, bool(gen.fade_in_phase))
+            cache = self.__dict__.setdefault('_graphed_generators', {})
+            if key not in cache:
+                cache.clear()                    # one live capture: a grown / re-materialised generator replaces it
+                cache[key] = GraphedGenerator(gen, len(zs), len_z=zs.shape[-1])
+            return cache[key](zs.to(dev).float()) * std + mean
         out = [gen(zs[i:i + 16].to(dev).float(), **gen_kwargs) * std + mean for i in range(0, len(zs), 16)]
         return torch.cat(out)
 

@@ -176,3 +176,51 @@ def test_stylemixing_grid_cells_are_mixed_samples():
                 ref = nets.stylegen_forward(sd, z, noise, cfg, z_mix=zb[c - 1:c], cutoff_idx=stage)
                 ref = ((ref[0] * 0.5 + 0.5).clamp(0, 1) * 255).round()
                 assert (cell(r, c) - ref).abs().max() <= 1, (r, c)
+
+
+@pytest.mark.parametrize('kind', ['stylegan', 'progan'])
+def test_graphed_generator_matches_eager(kind, capsys):
+    """HIP-graph replay of the eval-mode generator (gan_lab_amd/graphs.py): bit-identical to the eager forward for
+    the same latents / noise, follows in-place weight updates, and is faster per call at batch 1."""
+    import time
+    from gan_lab_amd.graphs import GraphedGenerator
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    from test_gpu_learner import make_learner
+    kw = dict(loss='nonsaturating', gradient_penalty='r1') if kind == 'stylegan' else {}
+    L = make_learner(kind, 32, init_res=32, batch=4, **kw)
+    dl = SyntheticImageLoader(4096, 4, 32)
+    L.train(dl, num_main_iters=2)
+    g = L.gen_model
+    g.eval()
+    gg = GraphedGenerator(g, batch=1)
+    gen = torch.Generator().manual_seed(0)
+    for it in range(3):
+        z = torch.randn(1, 16, generator=gen).cuda()
+        noise = None
+        if gg.noise is not None:
+            noise = [torch.randn(1, 1, *b.shape[2:], generator=gen).cuda() for b in gg.noise]
+        out = gg(z, noise=noise).clone()
+        with torch.no_grad():
+            ref = g(z, noise=noise) if noise is not None else g(z)
+        assert torch.equal(out, ref), (kind, it, (out - ref).abs().max().item())
+        if it == 0:                       # one more training iteration rewrites the weights in place
+            g.train()
+            L.train(dl, num_main_iters=1)
+            g.eval()
+
+    def per_call(fn, n=30):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    z = torch.randn(1, 16).cuda()
+    t_graph = per_call(lambda: gg(z, redraw_noise=False))
+    with torch.no_grad():
+        t_eager = per_call(lambda: g(z, noise=gg.noise) if gg.noise is not None else g(z))
+    with capsys.disabled():
+        print(f'\n{kind} 32^2 batch-1 sample: eager {t_eager:.3f} ms, hipGraph replay {t_graph:.3f} ms')
+    assert t_graph < t_eager
+    g.train()
