@@ -36,6 +36,32 @@ __global__ void ln_affine_fwd_kernel(const float* __restrict__ x, const float* _
   }
 }
 
+// BatchNorm apply in the CENTRED form y = (x - mean[c]) * scale[c] + shift[c]: the folded x*scale + (shift - mean*scale)
+// has an absolute rounding error of eps*|x*scale| instead of eps*|y|, i.e. ~10x more activations land on the wrong
+// side of the ReLU that follows (seen in the float64-judged ResNet step test)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                float* __restrict__ y, long long total4, int C, long long hw4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / hw4) % C);
+    const float mu = mean[c], sc = scale[c], sh = shift != nullptr ? shift[c] : 0.f;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = (v.x - mu) * sc + sh;
+    v.y = (v.y - mu) * sc + sh;
+    v.z = (v.z - mu) * sc + sh;
+    v.w = (v.w - mu) * sc + sh;
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+__global__ void bn_apply1_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                 float* __restrict__ y, long long total, int C, long long HW) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    y[i] = (x[i] - mean[c]) * scale[c] + (shift != nullptr ? shift[c] : 0.f);
+  }
+}
+
 // out[n,m] = a[n,m] * w[m]
 __global__ void colscale_kernel(const float* __restrict__ a, const float* __restrict__ w, float* __restrict__ out,
                                 long long total, long long M) {
@@ -68,24 +94,32 @@ __global__ void coldot_kernel(const float* __restrict__ a, const float* __restri
 // grid = (S, N): block (s, n) reduces the slice [s*len, (s+1)*len) of row n into part[(n*S + s)*3 ..] (fp64);
 // rowsums_finish adds the S partials of a row in a fixed order.
 constexpr int ROWSUM_MAX_SPLIT = 64;
+// A "row" is LayerNorm's sample (one contiguous segment of M elements) or BatchNorm's channel (N segments of HW
+// elements, C*HW apart): element j of row r lives at r*row_stride + (j / seg_len)*seg_stride + (j % seg_len).
+struct RowGeom {
+  long long L, seg_len, seg_stride, row_stride;   // L = elements per row
+};
+__device__ __forceinline__ long long row_addr(const RowGeom& g, int r, long long j) {
+  const long long seg = j / g.seg_len;
+  return (long long)r * g.row_stride + seg * g.seg_stride + (j - seg * g.seg_len);
+}
+
 __global__ void ln_rowsums_kernel(const float* __restrict__ a, const float* __restrict__ wa,
                                   const float* __restrict__ x, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ b2,
-                                  const float* __restrict__ w2, double* __restrict__ part, long long M, long long len) {
+                                  const float* __restrict__ w2, double* __restrict__ part, RowGeom g, long long len) {
   __shared__ double red[3][4];
   const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
-  const long long lo = sidx * len, hi = (lo + len < M) ? lo + len : M;
-  const float mu = mean[n], rs = rstd[n];
-  const float* ar = a + (long long)n * M;
-  const float* xr = x + (long long)n * M;
-  const float* br = b2 != nullptr ? b2 + (long long)n * M : nullptr;
+  const long long lo = sidx * len, hi = (lo + len < g.L) ? lo + len : g.L;
+  const float mu = mean != nullptr ? mean[n] : 0.f, rs = rstd != nullptr ? rstd[n] : 1.f;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (long long m = lo + threadIdx.x; m < hi; m += 256) {
-    const float av = ar[m];
+    const long long i = row_addr(g, n, m);
+    const float av = a[i];
     const float t = wa != nullptr ? av * wa[m] : av;
     s0 += (double)t;
-    s1 += (double)(t * ((xr[m] - mu) * rs));
-    if (br != nullptr) s2 += (double)(av * br[m] * (w2 != nullptr ? w2[m] : 1.f));
+    s1 += (double)t * (double)((x[i] - mu) * rs);
+    if (b2 != nullptr) s2 += (double)(av * b2[i] * (w2 != nullptr ? w2[m] : 1.f));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -105,27 +139,42 @@ __global__ void ln_rowsums_kernel(const float* __restrict__ a, const float* __re
   }
 }
 
-__global__ void ln_rowsums_finish_kernel(const double* __restrict__ part, float* __restrict__ out, int N, int S) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, k)
-  if (i >= N * 3) return;
-  const int n = i / 3, k = i % 3;
-  double s = 0.0;
-  for (int j = 0; j < S; ++j) s += part[((long long)n * S + j) * 3 + k];
-  out[i] = (float)s;
+// moments = 0: out[n][k] = sum_k.  moments = 1 (called with a = x, mean = rstd = NULL, so s0 = sum x, s1 = sum x^2):
+// out[n] = {mean, biased variance, 0} evaluated in fp64.
+__global__ void ln_rowsums_finish_kernel(const double* __restrict__ part, float* __restrict__ out, int N, int S,
+                                         int moments, double inv_len) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int j = 0; j < S; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] += part[((long long)n * S + j) * 3 + k];
+  if (moments) {
+    const double mu = s[0] * inv_len;
+    double var = s[1] * inv_len - mu * mu;
+    out[n * 3] = (float)mu;
+    out[n * 3 + 1] = (float)(var > 0.0 ? var : 0.0);
+    out[n * 3 + 2] = 0.f;
+  } else {
+    out[n * 3] = (float)s[0];
+    out[n * 3 + 1] = (float)s[1];
+    out[n * 3 + 2] = (float)s[2];
+  }
 }
 
-// out[n,m] = (wo ? wo[m] : 1) * rstd[n] * (a*(wa ? wa[m] : 1) - s0[n]/M - xhat * s1[n]/M),  sums = [N][3]
+// out = (wo ? wo[m] : 1) * (pre ? pre[n] : rstd[n]) * (a*(wa ? wa[m] : 1) - s0[n]/L - xhat * s1[n]/L),  sums = [N][3]
 __global__ void ln_project_kernel(const float* __restrict__ a, const float* __restrict__ wa,
                                   const float* __restrict__ x, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ sums,
-                                  const float* __restrict__ wo, float* __restrict__ out, long long total, long long M,
-                                  float inv_m) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / M, m = i - n * M;
+                                  const float* __restrict__ wo, const float* __restrict__ pre, float* __restrict__ out,
+                                  long long total, RowGeom g, float inv_len) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long n = e / g.L, m = e - n * g.L;
+    const long long i = row_addr(g, (int)n, m);
     const float rs = rstd[n];
     const float xh = (x[i] - mean[n]) * rs;
     const float t = wa != nullptr ? a[i] * wa[m] : a[i];
-    float v = rs * (t - sums[n * 3] * inv_m - xh * sums[n * 3 + 1] * inv_m);
+    float v = (pre != nullptr ? pre[n] : rs) * (t - sums[n * 3] * inv_len - xh * sums[n * 3 + 1] * inv_len);
     if (wo != nullptr) v *= wo[m];
     out[i] = v;
   }
@@ -176,28 +225,75 @@ size_t ganlab_ln_rowsums_workspace(int N, long long M) {
   return (size_t)N * ROWSUM_MAX_SPLIT * 3 * sizeof(double);
 }
 
+static int rowsums_launch(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
+                          const float* b2, const float* w2, float* out, int rows, RowGeom g, int moments,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a || !x || !out || rows <= 0 || g.L <= 0) return GANLAB_EINVAL;
+  if (!workspace || workspace_bytes < ganlab_ln_rowsums_workspace(rows, g.L)) return GANLAB_EWORKSPACE;
+  int S = (int)((g.L + 4095) / 4096);
+  if (S > ROWSUM_MAX_SPLIT) S = ROWSUM_MAX_SPLIT;
+  if (S < 1) S = 1;
+  const long long len = ((g.L + S - 1) / S + 255) / 256 * 256;
+  S = (int)((g.L + len - 1) / len);
+  double* part = reinterpret_cast<double*>(workspace);
+  GL_LAUNCH(ln_rowsums_kernel, dim3((unsigned)S, (unsigned)rows), dim3(256), 0, ST, a, wa, x, mean, rstd, b2, w2, part,
+            g, len);
+  GL_LAUNCH(ln_rowsums_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ST, part, out, rows, S,
+            moments, 1.0 / (double)g.L);
+  return GL_CHECK_LAUNCH();
+}
+
 int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* b2, const float* w2, float* out, int N, long long M, void* workspace,
                           size_t workspace_bytes, void* stream) {
-  if (!a || !x || !mean || !rstd || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
-  if (!workspace || workspace_bytes < ganlab_ln_rowsums_workspace(N, M)) return GANLAB_EWORKSPACE;
-  int S = (int)((M + 4095) / 4096);
-  if (S > ROWSUM_MAX_SPLIT) S = ROWSUM_MAX_SPLIT;
-  if (S < 1) S = 1;
-  const long long len = ((M + S - 1) / S + 255) / 256 * 256;
-  S = (int)((M + len - 1) / len);
-  double* part = reinterpret_cast<double*>(workspace);
-  GL_LAUNCH(ln_rowsums_kernel, dim3((unsigned)S, (unsigned)N), dim3(256), 0, ST, a, wa, x, mean, rstd, b2, w2, part, M,
-            len);
-  GL_LAUNCH(ln_rowsums_finish_kernel, dim3((unsigned)((N * 3 + 255) / 256)), dim3(256), 0, ST, part, out, N, S);
-  return GL_CHECK_LAUNCH();
+  if (!mean || !rstd) return GANLAB_EINVAL;
+  return rowsums_launch(a, wa, x, mean, rstd, b2, w2, out, N, RowGeom{M, M, 0, M}, 0, workspace, workspace_bytes,
+                        stream);
 }
 
 int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* sums, const float* wo, float* out, int N, long long M, void* stream) {
   if (!a || !x || !mean || !rstd || !sums || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
   GL_LAUNCH(ln_project_kernel, dim3(ew_blocks((long long)N * M)), dim3(256), 0, ST, a, wa, x, mean, rstd, sums, wo,
-            out, (long long)N * M, M, 1.0f / (float)M);
+            (const float*)nullptr, out, (long long)N * M, RowGeom{M, M, 0, M}, 1.0f / (float)M);
+  return GL_CHECK_LAUNCH();
+}
+
+// ---- BatchNorm2d (training mode, first order) of the ResNet generators on the same kernels: a row is a channel ---
+// (N segments of HW elements).  stats: out[c] = {batch mean, biased batch variance, 0};  bwd_sums: out[c] = {sum gy =
+// d/d bias, sum gy * xhat = d/d weight, 0};  bwd_apply: gx = pre[c] * (gy - s0/L - xhat * s1/L) with pre = rstd * w.
+int ganlab_bn_stats_f32(const float* x, float* out, int N, int C, long long HW, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  return rowsums_launch(x, nullptr, x, nullptr, nullptr, nullptr, nullptr, out, C, RowGeom{(long long)N * HW, HW, C * HW, HW},
+                        1, workspace, workspace_bytes, stream);
+}
+
+int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,
+                        int C, long long HW, void* stream) {
+  if (!x || !mean || !scale || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  const long long total = (long long)N * C * HW;
+  if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+    GL_LAUNCH(bn_apply_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, ST, x, mean, scale, shift, y, total / 4, C,
+              HW / 4);
+  else
+    GL_LAUNCH(bn_apply1_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST, x, mean, scale, shift, y, total, C, HW);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_bn_bwd_sums_f32(const float* gy, const float* x, const float* mean, const float* rstd, float* out, int N,
+                           int C, long long HW, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  return rowsums_launch(gy, nullptr, x, mean, rstd, nullptr, nullptr, out, C, RowGeom{(long long)N * HW, HW, C * HW, HW},
+                        0, workspace, workspace_bytes, stream);
+}
+
+int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd, const float* sums,
+                            const float* pre, float* gx, int N, int C, long long HW, void* stream) {
+  if (!gy || !x || !mean || !rstd || !sums || !pre || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
+  const long long L = (long long)N * HW;
+  GL_LAUNCH(ln_project_kernel, dim3(ew_blocks(L * C)), dim3(256), 0, ST, gy, (const float*)nullptr, x, mean, rstd, sums,
+            (const float*)nullptr, pre, gx, L * C, RowGeom{L, HW, C * HW, HW}, 1.0f / (float)L);
   return GL_CHECK_LAUNCH();
 }
 

@@ -949,22 +949,84 @@ def channel_sum(x):
     return _ChanSum.apply(x, None, 1.0)
 
 
+def _row_workspace(rows, length, device):
+    nbytes = _lib.lib().ganlab_ln_rowsums_workspace(rows, length)
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+
+
+class _BatchNormTrain(Function):
+    """nn.BatchNorm2d in training mode on fused kernels (csrc/norm.hip): batch statistics (2 launches), normalise +
+    affine (1), backward sums = the parameter gradients (2) and the input gradient (1).  First order only - the
+    generator is never inside a gradient penalty.  Returns (y, batch mean, biased batch variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = _c(x)
+        n, c, hw = _nchw(x)
+        L = _lib.lib()
+        ws = _row_workspace(c, n * hw, x.device)
+        mom = _new((c, 3), x)
+        check(L.ganlab_bn_stats_f32(_p(x), _p(mom), n, c, hw, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()),
+              'bn_stats')
+        mean, var = mom[:, 0].contiguous(), mom[:, 1].contiguous()
+        rstd = torch.rsqrt(var + eps)                       # C-element vectors
+        scale = (rstd * weight if weight is not None else rstd).contiguous()
+        y = torch.empty_like(x)
+        check(L.ganlab_bn_apply_f32(_p(x), _p(mean), _p(scale), _p(_c(bias)) if bias is not None else None, _p(y), n, c,
+                                    hw, _st()), 'bn_apply')
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gm, _gv):
+        x, weight, mean, rstd = ctx.saved_tensors
+        gy = _c(gy)
+        n, c, hw = _nchw(x)
+        L = _lib.lib()
+        ws = _row_workspace(c, n * hw, x.device)
+        sums = _new((c, 3), x)
+        check(L.ganlab_bn_bwd_sums_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(sums), n, c, hw,
+                                       ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'bn_bwd_sums')
+        gx = None
+        if ctx.needs_input_grad[0]:
+            pre = (rstd * weight if weight is not None else rstd).contiguous()
+            gx = torch.empty_like(x)
+            check(L.ganlab_bn_bwd_apply_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(sums), _p(pre), _p(gx), n, c, hw,
+                                            _st()), 'bn_bwd_apply')
+        want_p = _want_param_grads()
+        gw = sums[:, 1].contiguous() if (weight is not None and want_p and ctx.needs_input_grad[1]) else None
+        gb = sums[:, 0].contiguous() if (ctx.has_bias and want_p and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
 def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
-    """nn.BatchNorm2d semantics (biased variance for the normalisation, unbiased for the running
-    estimate) composed from channel sums / per-channel affines."""
+    """nn.BatchNorm2d semantics (biased variance for the normalisation, unbiased for the running estimate): fused
+    kernels in training mode, one per-channel affine with the running statistics in eval mode."""
     n, c, hw = _nchw(x)
     m = n * hw
     if training:
-        mean = channel_sum(x) / m
-        xc = chan_affine(x, None, -mean)
-        var = channel_sum(mul(xc, xc)) / m
+        y, mean, var = _BatchNormTrain.apply(x, weight, bias, float(eps))
         if running_mean is not None:
             with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean.detach(), alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var.detach() * (m / max(m - 1, 1)), alpha=momentum)
-    else:
-        mean, var = running_mean, running_var
-        xc = chan_affine(x, None, -mean)
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (m / max(m - 1, 1)), alpha=momentum)
+        return y
+    xc = chan_affine(x, None, -running_mean)          # centred, like the training path
+    rstd = torch.rsqrt(running_var + eps)
+    return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
+
+
+def batch_norm_composed(x, weight, bias, eps=1e-5):
+    """Training-mode BatchNorm composed from channel sums / per-channel affines / products (any order of
+    differentiation through autograd): the cross-check of the fused kernels in the tests."""
+    n, c, hw = _nchw(x)
+    m = n * hw
+    mean = channel_sum(x) / m
+    xc = chan_affine(x, None, -mean)
+    var = channel_sum(mul(xc, xc)) / m
     rstd = torch.rsqrt(var + eps)
     return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
 

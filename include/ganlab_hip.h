@@ -213,6 +213,21 @@ int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
                                const float* c1, const float* c2, const float* c3, float* out, int N, long long M,
                                void* stream);
+/* ---- fused BatchNorm2d (training mode, first order) of the ResNet generators (csrc/norm.hip) --------------------
+ * resnetgan/resblocks.py:15-121 -> NormalizeLayer('BatchNorm') = nn.BatchNorm2d (custom_layers.py:100-107).  A row is
+ * a channel (N segments of HW elements); workspace as ganlab_ln_rowsums_workspace(C, N*HW).
+ *   bn_stats:     out[c] = {batch mean, biased batch variance, 0}    (fp64 partial sums, evaluated in fp64)
+ *   bn_bwd_sums:  out[c] = {sum gy (= d/d bias), sum gy * xhat (= d/d weight), 0}
+ *   bn_bwd_apply: gx = pre[c] * (gy - s0/L - xhat * s1/L), pre = rstd * weight, L = N*HW
+ *   bn_apply:     y = (x - mean[c]) * scale[c] + shift[c]  (centred form: keeps the rounding error at eps*|y|) */
+int ganlab_bn_stats_f32(const float* x, float* out, int N, int C, long long HW, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,
+                        int C, long long HW, void* stream);
+int ganlab_bn_bwd_sums_f32(const float* gy, const float* x, const float* mean, const float* rstd, float* out, int N,
+                           int C, long long HW, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd, const float* sums,
+                            const float* pre, float* gx, int N, int C, long long HW, void* stream);
 /* nn.Tanh of the ResNet generators (resnetgan/architectures.py:55, :93) */
 int ganlab_tanh_fwd_f32(const float* x, float* y, long long n, void* stream);
 int ganlab_tanh_bwd_f32(const float* gy, const float* y, float* gx, long long n, void* stream);
