@@ -19,8 +19,8 @@
 // current chunk's MFMA loop (register prefetch).
 //
 // Weight gradient: K = pixels.  A = gy[co][8 consecutive px], B = x[8 consecutive px (shifted by the tap)][ci];
-// the three horizontal tap shifts are materialised as three LDS copies of the activation rows so every operand
-// read stays a 16-byte aligned ds_read_b128.
+// the three horizontal tap shifts are materialised as three LDS copies of the activation rows (built from ONE aligned
+// load plus a lane shuffle) so every operand read stays a 16-byte aligned ds_read_b128.
 #include "common.h"
 
 namespace {
@@ -210,16 +210,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
 }
 
 // ---- weight-gradient kernel --------------------------------------------------------------------------------------
-// Workgroup: 64 output channels x 32 input channels x 9 taps, summed over a slice of the pixel tiles (8 rows x 32
+// Workgroup: 64 output channels x 32 input channels x 9 taps, summed over a slice of the pixel tiles (4 rows x 32
 // columns each); wave w owns output-channel block w (16 channels) -> 2 (ci blocks) x 9 (taps) accumulator tiles.
-// LDS: Gs[co 64][row 8][32 px] bf16 (row pitch 64 B, channel pitch padded) and Xc[kx 3][ci 32][row 10][32 px] bf16
+// LDS: Gs[co 64][row 4][32 px] bf16 (row pitch 64 B, channel pitch padded) and Xc[kx 3][ci 32][row 6][32 px] bf16
 // where copy kx holds x[.., col + kx - 1] at position col.
-constexpr int G_CP = TH * TW * 2 + 16;      // bytes per gy channel (8 rows x 64 B, +16 B pad: conflict-free A reads)
-constexpr int X_CP = PR * TW * 2 + 16;      // bytes per x channel of one shifted copy (10 rows x 64 B, +16 B pad)
+// Pixel tile of the weight gradient: 4 rows x 32 columns.  56 KB of LDS per workgroup -> TWO workgroups per CU, so one
+// stages (global -> bf16 -> LDS) while the other multiplies; with 8-row tiles (97 KB, one workgroup per CU) staging
+// and MFMA alternated and the kernel ran at 145 TFLOP/s.
+constexpr int WTH = 4, WPR = WTH + 2;
+constexpr int G_CP = WTH * TW * 2 + 16;     // bytes per gy channel (4 rows x 64 B, +16 B pad: conflict-free A reads)
+constexpr int X_CP = WPR * TW * 2 + 16;     // bytes per x channel of one shifted copy (6 rows x 64 B, +16 B pad)
 constexpr int WG_CI = 32;
-struct __attribute__((packed, aligned(4))) F4u {
-  float x, y, z, w;
-};
 
 struct BfWgArgs {
   const float* gy;
@@ -250,56 +251,84 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(BfWgArgs p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = slot; tile < ntiles; tile += p.slots) {
+  // register prefetch: the next tile's gy / x values (fp32) are loaded while the MFMA loop of the current tile runs and
+  // are converted, shuffled and written to LDS after the barrier
+  float4 gr[8], xr[6];
+  float xe[6];           // edge pixel of the lane's group: x[ox0 - 1] for q == 0, x[ox0 + 32] for q == 7
+  auto load_tile = [&](int tile) {
     const int txi = tile % p.tiles_x;
-    int t2 = tile / p.tiles_x;
-    const int tyi = t2 % p.tiles_y;
-    const int n = t2 / p.tiles_y;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const float* gyb = p.gy + ((long long)n * p.CO + co0) * plane;
+    const int t2 = tile / p.tiles_x;
+    const int tyi = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    const int oy0 = tyi * WTH, ox0 = txi * TW;
+    const float* gyb = p.gy + ((long long)n * p.CO + co0) * plane + (long long)oy0 * p.W + ox0;
     const float* xb = p.x + ((long long)n * p.CI + ci0) * plane;
-    __syncthreads();   // previous tile's operand reads are done
-    // gy tile: 64 co x 8 rows x 8 float4 = 4096 items, 16 per thread
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
       const int e = tid + i * 256;
-      const int q = e & 7, r = (e >> 3) & 7, co = e >> 6;
-      const float4 v = *reinterpret_cast<const float4*>(gyb + (long long)co * plane + (oy0 + r) * p.W + ox0 + 4 * q);
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<u32x2*>(Gs + co * G_CP + r * (TW * 2) + q * 8) = __builtin_bit_cast(u32x2, h);
+      const int q = e & 7, r = (e >> 3) & 3, co = e >> 5;
+      gr[i] = *reinterpret_cast<const float4*>(gyb + (long long)co * plane + r * p.W + 4 * q);
     }
-    // x copies: 3 shifts x 32 ci x 10 rows x 8 groups of 4 px = 7680 items, 30 per thread
-#pragma unroll 5
-    for (int i = 0; i < 30; ++i) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
       const int e = tid + i * 256;
       const int q = e & 7;
-      int t = e >> 3;
-      const int r = t % PR;
-      t /= PR;
-      const int ci = t & 31, kx = t >> 5;
-      const int vy = oy0 - 1 + r, vx = ox0 + 4 * q + kx - 1;
-      float4 v = float4{0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)vy < (unsigned)p.H) {
-        const float* row = xb + (long long)ci * plane + vy * p.W;
-        if (vx >= 0 && vx + 3 < p.W) {
-          const F4u u = *reinterpret_cast<const F4u*>(row + vx);   // 4-byte aligned 16-byte load
-          v = float4{u.x, u.y, u.z, u.w};
-        } else {
-          if ((unsigned)vx < (unsigned)p.W) v.x = row[vx];
-          if ((unsigned)(vx + 1) < (unsigned)p.W) v.y = row[vx + 1];
-          if ((unsigned)(vx + 2) < (unsigned)p.W) v.z = row[vx + 2];
-          if ((unsigned)(vx + 3) < (unsigned)p.W) v.w = row[vx + 3];
-        }
-      }
-      bf16x4 h;
-      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<u32x2*>(Xc + (kx * WG_CI + ci) * X_CP + r * (TW * 2) + q * 8) = __builtin_bit_cast(u32x2, h);
+      const int t = e >> 3;
+      const int r = t % WPR, ci = t / WPR;
+      const int vy = oy0 - 1 + r;
+      const bool rok = (unsigned)vy < (unsigned)p.H;
+      const float* row = xb + (long long)ci * plane + (long long)(rok ? vy : 0) * p.W + ox0;
+      xr[i] = rok ? *reinterpret_cast<const float4*>(row + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+      float ev = 0.f;
+      if (q == 0 && rok && ox0 > 0) ev = row[-1];
+      if (q == 7 && rok && ox0 + TW < p.W) ev = row[TW];
+      xe[i] = ev;
     }
+  };
+  auto store_tile = [&]() {
+    // gy tile: 64 co x 4 rows x 8 float4 = 2048 items, 8 per thread
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + i * 256;
+      const int q = e & 7, r = (e >> 3) & 3, co = e >> 5;
+      bf16x4 h;
+      h[0] = (__bf16)gr[i].x; h[1] = (__bf16)gr[i].y; h[2] = (__bf16)gr[i].z; h[3] = (__bf16)gr[i].w;
+      *reinterpret_cast<u32x2*>(Gs + co * G_CP + r * (TW * 2) + q * 8) = __builtin_bit_cast(u32x2, h);
+    }
+    // x: ONE aligned float4 per (ci, row, 4-pixel group) = 1536 items, 6 per thread; the two shifted copies take their
+    // missing pixel from the neighbouring lane (groups are lane-consecutive) or, at the tile's left / right edge,
+    // from the extra scalar load
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int e = tid + i * 256;
+      const int q = e & 7;
+      const int t = e >> 3;
+      const int r = t % WPR, ci = t / WPR;
+      const float4 v = xr[i];
+      float left = __shfl_up(v.w, 1, 8), right = __shfl_down(v.x, 1, 8);
+      if (q == 0) left = xe[i];
+      if (q == 7) right = xe[i];
+      unsigned char* dst = Xc + ci * X_CP + r * (TW * 2) + q * 8;
+      bf16x4 h;
+      h[0] = (__bf16)left; h[1] = (__bf16)v.x; h[2] = (__bf16)v.y; h[3] = (__bf16)v.z;
+      *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);                          // kx = 0: x[col - 1]
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      *reinterpret_cast<u32x2*>(dst + WG_CI * X_CP) = __builtin_bit_cast(u32x2, h);           // kx = 1
+      h[0] = (__bf16)v.y; h[1] = (__bf16)v.z; h[2] = (__bf16)v.w; h[3] = (__bf16)right;
+      *reinterpret_cast<u32x2*>(dst + 2 * WG_CI * X_CP) = __builtin_bit_cast(u32x2, h);       // kx = 2: x[col + 1]
+    }
+  };
+
+  int tile = slot;
+  if (tile < ntiles) load_tile(tile);
+  while (tile < ntiles) {
+    __syncthreads();   // previous tile's operand reads are done
+    store_tile();
     __syncthreads();
-    // K loop: 8 rows x one 32-pixel k-step
+    const int next = tile + p.slots;
+    if (next < ntiles) load_tile(next);   // in flight during the MFMA loop
+    // K loop: 4 rows x one 32-pixel k-step
 #pragma unroll 2
-    for (int r = 0; r < TH; ++r) {
+    for (int r = 0; r < WTH; ++r) {
       const bf16x8 a = __builtin_bit_cast(
           bf16x8, *reinterpret_cast<const u32x4*>(Gs + (wv * 16 + l16) * G_CP + r * (TW * 2) + kgl * 16));
 #pragma unroll
@@ -313,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(BfWgArgs p) {
           acc[nb][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nb][tap], 0, 0, 0);
         }
     }
+    tile = next;
   }
   // D[i = co][j = ci]: lane holds co = co0 + 16wv + 4kgl + r, ci = ci0 + 16nb + l16
   float* wsb = p.ws + (long long)slot * p.CO * p.CI * 9;
@@ -344,7 +374,7 @@ bool bf16_ok(const ganlab_conv_geom* g) {
 
 int wgrad_slots(const ganlab_conv_geom* g) {
   const int groups = (g->Cout / COT) * (g->Cin / WG_CI);
-  const int ntiles = g->N * (g->Hin / TH) * (g->Win / TW);
+  const int ntiles = g->N * (g->Hin / WTH) * (g->Win / TW);
   int s = (2 * 256 + groups - 1) / groups;   // ~2 workgroups per CU
   if (s > ntiles) s = ntiles;
   if (s > 64) s = 64;
@@ -409,7 +439,7 @@ int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const gan
   BfWgArgs a;
   a.gy = gy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
   a.N = g->N; a.CI = g->Cin; a.CO = g->Cout; a.H = g->Hin; a.W = g->Win;
-  a.tiles_x = a.W / TW; a.tiles_y = a.H / TH; a.tiles_co = a.CO / COT; a.tiles_ci = a.CI / WG_CI;
+  a.tiles_x = a.W / TW; a.tiles_y = a.H / WTH; a.tiles_co = a.CO / COT; a.tiles_ci = a.CI / WG_CI;
   a.slots = wgrad_slots(g);
   const long long grid = (long long)a.tiles_co * a.tiles_ci * a.slots;
   GL_LAUNCH(conv_wgrad_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
