@@ -96,15 +96,69 @@ def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32', c=None, r=No
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4),
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on this
-            # kernel, profiles/r01c_northstar_conv_pmc.csv: 2.42e9 read (1.12x the algorithmic 2 GiB: halo rows /
-            # columns that miss L2) + 2.17e9 written; same file: MFMA pipes busy 0.68-0.71 of the kernel's cycles
-            # at an effective clock of 1.75-2.1 GHz
-            'traffic': 4.5835e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
+            # kernel, profiles/r01c_northstar_conv_pmc.csv: 2.24e9 read (1.04x the algorithmic 2 GiB: the 8-of-72
+            # column halo that misses L2) + 2.15e9 written; same file: MFMA pipes busy 0.74-0.76 of the kernel's
+            # cycles at an effective clock of 1.8-2.1 GHz
+            'traffic': 4.391e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
             'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
-                       f'conv_fwd_strip2_kernel<KS=3,16co,32x8 vertical strips> {c}->{c} @{res}^2 x{batch}' if c <= 16 else
+                       f'conv_fwd_roll_kernel<KS=3,16co,64px column strips,4 rows/step> {c}->{c} @{res}^2 x{batch}'
+                       if (c <= 16 and res % 64 == 0) else
                        f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
                        f'{c}->{c} @{res}^2 x{batch}'),
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
+
+
+class InSituKernelTimer(object):
+    """HIP events around every launch of ONE conv geometry (forward and input gradient: the same kernel) during the
+    timed steps - the dominant kernel's launch duration in the state the training step actually runs it in (clocks,
+    caches, neighbours), rather than in an isolated loop."""
+
+    def __init__(self, torch, ops, batch, c, res):
+        self.torch, self.ops, self.key = torch, ops, (batch, c, res, res, c, 3, 1, 0, 0)
+        self.events = []
+        self._orig = None
+
+    def _match(self, g):
+        return (g.N, g.Cin, g.Hin, g.Win, g.Cout, g.ks, g.pad, g.up, g.pool) == self.key and not g.s2 and g.bf is None
+
+    def __enter__(self):
+        ops, torch = self.ops, self.torch
+        f0, d0 = self._orig = (ops.k_conv_fwd, ops.k_conv_dgrad)     # whatever is installed now: timers nest
+
+        def fwd(x, w, bias, g, *a, **k):
+            if not self._match(g):
+                return f0(x, w, bias, g, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ops._packed(w, ops.PACK_FWD, a[0] if a else k['scale'])     # keep the (cached) weight packing out of the bracket
+            e0.record()
+            y = f0(x, w, bias, g, *a, **k)
+            e1.record()
+            self.events.append((e0, e1))
+            return y
+
+        def dgrad(gy, w, g, scale):
+            if not self._match(g):
+                return d0(gy, w, g, scale)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ops._packed(w, ops.PACK_DGRAD, scale)
+            e0.record()
+            gx = d0(gy, w, g, scale)
+            e1.record()
+            self.events.append((e0, e1))
+            return gx
+        ops.k_conv_fwd, ops.k_conv_dgrad = fwd, dgrad
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.k_conv_fwd, self.ops.k_conv_dgrad = self._orig
+        return False
+
+    def mean_ms(self):
+        if not self.events:
+            return None, 0
+        self.torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in self.events]
+        return sum(ts) / len(ts), len(ts)
 
 
 def cpu_baseline(torch, res, batch):
@@ -170,10 +224,15 @@ def main():
 
     for _ in range(a.warmup):
         one_step(learner, real)
+    from gan_lab_amd import ops as _ops
+    ns_c = 16 if a.res >= 1024 else max(16, min(512, 8192 // (a.res // 2)))
+    insitu = InSituKernelTimer(torch, _ops, a.batch, ns_c, a.res)
+    insitu_top = InSituKernelTimer(torch, _ops, a.batch, 256, 64)      # the kernel with the largest share of the step
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ld, lg = one_step(learner, real)
+    with insitu, insitu_top:
+        for _ in range(a.steps):
+            ld, lg = one_step(learner, real)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -209,10 +268,24 @@ def main():
     if rank == 0:
         out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res, dtype=a.dtype)
         torch.cuda.empty_cache()
+        def with_insitu(r, timer):
+            ms_t, n_t = timer.mean_ms()
+            if r is not None and ms_t is not None:
+                r['isolated_ms_per_launch'], r['isolated_achieved'] = r['ms_per_launch'], r['achieved']
+                r['ms_per_launch'] = round(ms_t, 4)
+                r['achieved'] = round(r['flops_per_launch'] / (ms_t * 1e-3) / 1e12, 2)
+                r['frac'] = round(r['achieved'] / r['peak'], 4)
+                r['launches_timed_in_step'] = n_t
+            return r
+        # the same kernel instance as launched INSIDE the timed steps (device events around each launch, forward and
+        # input gradient): the figure rocprofv3's per-kernel average of the step agrees with; the isolated loop
+        # (2 warm-up + 5 launches on a cold chip) is kept beside it as isolated_*
+        out['roofline'] = with_insitu(out['roofline'], insitu)
         if not a.no_roofline and a.res == 1024 and a.dtype == 'f32':
             # the kernel with the largest share of the step (profiles/r01c_step_kernel_stats.csv: conv_fwd_kernel
             # <KS=3,MB=4,32x8>, 15.6% of the step, the 64..512-channel stride-1 layers): its 256->256 @64^2 instance
-            out['roofline_top_kernel_by_time'] = measure_dominant_kernel(torch, a.batch, a.res, c=256, r=64)
+            out['roofline_top_kernel_by_time'] = with_insitu(
+                measure_dominant_kernel(torch, a.batch, a.res, c=256, r=64), insitu_top)
             out['roofline_top_kernel_by_time']['traffic'] = None
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:

@@ -659,6 +659,148 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
   GL_T(3)
 }
 
+// Rolling-window kernel for the thinnest 3x3 layers (<= 16 -> 16 channels, W % 64 == 0, H % 4 == 0).  A workgroup
+// owns a 64-pixel-wide column strip and walks DOWN it 4 output rows at a time; the input rows live in an LDS ring of 10
+// row slots ([ci 16][80 floats] each): a step needs rows 4t .. 4t+5 of the strip, rows 4t+6 .. 4t+9 are prefetched into
+// registers during its MFMA loop and written into the four free slots afterwards, so
+//   * every input element is fetched ONCE per workgroup (plus the 8-of-72 column halo): 288-byte contiguous runs, 4
+//     cache lines per (channel, row) and 4 output rows, instead of 3 lines per (channel, row) and 0.8 output rows of
+//     the tile-based kernels - the thin layers are bound by the number of line requests, not by bandwidth;
+//   * one barrier per step (144 MFMAs per wave), weights in registers, 51 KB of LDS: 3 workgroups per CU.
+// Wave w computes output row 4t + w (64 pixels = 4 MFMA column blocks).
+constexpr int RW_TW = 64, RW_ROWS = 4, RW_SLOTS = 10, RW_RP = 80, RW_SLOT = 16 * RW_RP, RW_Q = 18;
+constexpr int RW_ITEMS = RW_ROWS * 16 * RW_Q;            // float4 items of one 4-row prefetch: 1152
+constexpr int RW_PT = (RW_ITEMS + 255) / 256;            // 5
+
+__global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float ring[RW_SLOTS * RW_SLOT];
+  constexpr int C4N = 4, NSTEP = 36, PD = 3, NB = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = bid % p.tiles_x;        // x fastest: neighbouring workgroups share image rows
+  bid /= p.tiles_x;
+  const int syi = bid % p.strips_x;
+  const int n0 = bid / p.strips_x;
+  const int step0 = syi * p.strip;
+  const int nsteps = min(p.strip, p.tiles_y - step0);     // tiles_y = H / 4 steps per column
+  const int ox0 = txi * RW_TW, oy_first = step0 * RW_ROWS;
+  const int plane = p.in.Hi * p.in.Wi;
+  const float* xb = p.in.x + (long long)n0 * p.in.Cin * plane;
+
+  // staging items of a 4-row group: (k = row in group, ci, q = float4 column): byte offset without the row term (or the
+  // out-of-range marker) and LDS offset within a slot | k << 20
+  int gbase[RW_PT], lo[RW_PT];
+#pragma unroll
+  for (int i = 0; i < RW_PT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % RW_Q;
+    const int t = e / RW_Q;
+    const int ci = t & 15, k = t >> 4;
+    const int vx = ox0 - 4 + 4 * q;
+    gbase[i] = (e < RW_ITEMS && ci < p.in.Cin && (unsigned)vx < (unsigned)p.in.Wi) ? (ci * plane + vx) * 4
+                                                                                  : (int)0x80000000;
+    lo[i] = (ci * RW_RP + 4 * q) | (k << 20);
+  }
+  // weights -> registers (k-step st = tap * 4 + c4)
+  float wreg[NSTEP];
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st)
+    wreg[st] = p.wp[(long long)((st / C4N) * p.Cin_p + (st % C4N) * 4 + (lane >> 4)) * p.Cout_p + (lane & 15)];
+  const int co_lane = lane & 15;
+  const float bv = (p.bias != nullptr && co_lane < p.Cout) ? p.bias[co_lane] * p.bias_scale : 0.f;
+  int boff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) boff[nb] = (lane >> 4) * RW_RP + nb * 16 + (lane & 15) + 3;   // + LP(4) - pad(1)
+
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (long long)n0 * p.Cout * out_plane, 0, (unsigned)(p.Cout * out_plane * 4), 0x00020000);
+  int vo_lane[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    vo_lane[nb] = co_lane < p.Cout
+                      ? (int)(((long long)co_lane * out_plane + ox0 + nb * 16 + (lane >> 4) * 4) * 4)
+                      : (int)0x80000000;          // channel padding: the store falls outside the descriptor
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 xr[RW_PT];
+  // rows rel0 .. rel0+nrows-1 of the strip (row 0 = input row oy_first - 1) -> registers; rows outside the image and
+  // k >= nrows read as zeros (out-of-range offsets)
+  auto load_rows = [&](int rel0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < RW_PT; ++i) {
+      const int k = lo[i] >> 20;
+      const int vy = oy_first - 1 + rel0 + k;
+      const bool ok = gbase[i] != (int)0x80000000 && k < nrows && (unsigned)vy < (unsigned)p.in.Hi;
+      const int off = ok ? gbase[i] + (int)((unsigned)vy * (unsigned)(p.in.Wi * 4)) : (int)0x80000000;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+  };
+  auto store_rows = [&](int rel0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < RW_PT; ++i) {
+      const int k = lo[i] >> 20;
+      if (tid + i * 256 < RW_ITEMS && k < nrows)
+        *reinterpret_cast<float4*>(ring + ((rel0 + k) % RW_SLOTS) * RW_SLOT + (lo[i] & 0xfffff)) = xr[i];
+    }
+  };
+
+  load_rows(0, 4);
+  store_rows(0, 4);
+  load_rows(4, 2);
+  store_rows(4, 2);
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    // rows 4t+6 .. 4t+9 for the next step (none after the last step: every offset out of range)
+    load_rows(4 * t + 6, t + 1 < nsteps ? 4 : 0);
+    {
+      int sbase[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) sbase[ky] = ((4 * t + wn + ky) % RW_SLOTS) * RW_SLOT;
+      float rb[PD + 1][NB];
+      auto fetch = [&](int st, int slot) {
+        const int ky = st / (3 * C4N), kx = (st / C4N) % 3, c4 = st % C4N;
+        const float* xrow = ring + sbase[ky] + c4 * 4 * RW_RP + kx;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) rb[slot][nb] = xrow[boff[nb]];
+      };
+#pragma unroll
+      for (int st = 0; st < PD; ++st) fetch(st, st % (PD + 1));
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + PD < NSTEP) fetch(st + PD, (st + PD) % (PD + 1));
+        const int slot = st % (PD + 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot][nb], wreg[st], acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    store_rows(4 * t + 6, 4);       // the four slots not read by this step
+    const int orow = (oy_first + 4 * t + wn) * p.Wo * 4;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      u32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[nb][r] + bv;
+        if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+        o[r] = __float_as_uint(v);
+      }
+      // offset in the VGPR, soffset 0: see the store-data hazard note in conv_fwd_strip2_kernel
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane[nb] == (int)0x80000000 ? vo_lane[nb] : vo_lane[nb] + orow,
+                                             0, 0);
+      acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();   // rows 4t .. 4t+5 are no longer read; rows 4t+6 .. 4t+9 are complete
+  }
+}
+
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
 template <class Cfg>
@@ -1046,7 +1188,20 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
           GL_LAUNCH(conv_fwd_strip_kernel<Cfg>, dim3((unsigned)sgrid), dim3(256), 0, st, a);
         } else
 #endif
-        {   // vertical strips: `strip` tiles down a column, `strips_x` strips per column
+        if (a.Wo % RW_TW == 0 && a.Ho % RW_ROWS == 0 && a.Cout <= 16 && a.tiles_co == 1) {
+          // rolling window: 64-pixel column strips, 4 output rows per step
+          ConvArgs r = a;
+          r.tiles_x = a.Wo / RW_TW;
+          r.tiles_y = a.Ho / RW_ROWS;                      // steps per column
+          const long long cols = (long long)r.tiles_x * a.tiles_n;
+          int kk = 1;                                      // strips per column: >= ~4096 workgroups, >= 8 steps each
+          while (kk < r.tiles_y && cols * kk < 4096 && ceil_div(r.tiles_y, kk + 1) >= 8) ++kk;
+          r.strip = ceil_div(r.tiles_y, kk);
+          r.strips_x = ceil_div(r.tiles_y, r.strip);
+          const long long rgrid = cols * r.strips_x;
+          if (rgrid <= 0 || rgrid > 0x7fffffffLL) return GANLAB_EINVAL;
+          GL_LAUNCH(conv_fwd_roll_kernel, dim3((unsigned)rgrid), dim3(256), 0, st, r);
+        } else {   // vertical strips: `strip` tiles down a column, `strips_x` strips per column
           int ky = 1;
           while (ky < a.tiles_y && tiles / ceil_div(a.tiles_y, ky) < 6144) ++ky;
           a.strip = ceil_div(a.tiles_y, ky);
