@@ -90,9 +90,11 @@ struct S2Args {
   int act;
 };
 
-template <int MB_>
+// TWL_ = 5: 32x8 low-res tiles; TWL_ = 4: 16x16 tiles for 16-pixel-wide outputs (a 32-wide tile would be half empty:
+// the 512->512 down layer at 32^2 ran at 63 TFLOP/s executed, its neighbours at 120+)
+template <int MB_, int TWL_ = 5>
 struct SCfg {
-  static constexpr int MB = MB_, NB = 4, TW = 32, TH = 8, TWL = 5;
+  static constexpr int MB = MB_, NB = 4, TWL = TWL_, TW = 1 << TWL_, TH = 256 / TW;
   static constexpr int CO_T = 16 * MB_;
   static constexpr int CI_T = MB_ == 4 ? 4 : 8;
   static constexpr int RPL = TW + 4, RL = TH + 2;             // parity-plane geometry (low-res units)
@@ -657,6 +659,7 @@ int launch_s2(K kernel, S2Args a, hipStream_t st) {
 }
 
 int run_S(S2Args a, hipStream_t st) {
+  if (a.Wl <= 16 && a.Cout > 32) return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
   if (a.Cout <= 16) return launch_s2<SCfg<1>>(conv_s2_down_kernel<SCfg<1>>, a, st);
   if (a.Cout <= 32) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
   return launch_s2<SCfg<4>>(conv_s2_down_kernel<SCfg<4>>, a, st);
