@@ -1256,6 +1256,154 @@ int dispatch_co(const ConvArgs& a, hipStream_t st) {
   return dispatch_geom<KS, 1>(a, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fromRGB / toRGB: 1x1 convolutions with 3 channels on one side (progan/architectures.py:286-292, :150-160;
+// stylegan/architectures.py torgb).  48 multiply-adds per pixel against 64+ bytes of traffic: HBM-bound streaming
+// work, not MFMA work - each thread owns 4 consecutive pixels, the 3 x C weights are wave-uniform scalars.
+//   few_to_many: y[co] = act(sum_ci w[ci][co] * x[ci] + b[co]),  Cin <= 4 (fromRGB forward, toRGB input gradient)
+//   many_to_few: the same with Cout <= 4                          (toRGB forward, fromRGB input gradient)
+//   cross_sums:  part[blk][b][s] = sum_px big[b] * small[s]        (both weight gradients; finished by a fixed-order sum)
+// wp is the packed [Cin_p][Cout_p] layout of pack_kernel (scale folded in).
+// ------------------------------------------------------------------------------------------------
+struct PwArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  int N, Cin, Cout, Cout_p;
+  long long hw4;      // float4 per plane
+  float bias_scale, slope;
+  int act;
+};
+
+__global__ __launch_bounds__(256) void pw_few_to_many_kernel(PwArgs p) {
+  const long long total = (long long)p.N * p.hw4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.hw4, q = i - n * p.hw4;
+    const float4* xb = reinterpret_cast<const float4*>(p.x) + n * p.Cin * p.hw4 + q;
+    float4 xv[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) xv[ci] = ci < p.Cin ? xb[(long long)ci * p.hw4] : float4{0.f, 0.f, 0.f, 0.f};
+    float4* yb = reinterpret_cast<float4*>(p.y) + n * p.Cout * p.hw4 + q;
+    for (int co = 0; co < p.Cout; ++co) {
+      const float b = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
+      float4 a = float4{b, b, b, b};
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const float w = ci < p.Cin ? p.wp[(long long)ci * p.Cout_p + co] : 0.f;
+        a.x += w * xv[ci].x; a.y += w * xv[ci].y; a.z += w * xv[ci].z; a.w += w * xv[ci].w;
+      }
+      if (p.act == GANLAB_ACT_LRELU) {
+        a.x = gl_lrelu(a.x, p.slope); a.y = gl_lrelu(a.y, p.slope); a.z = gl_lrelu(a.z, p.slope); a.w = gl_lrelu(a.w, p.slope);
+      }
+      yb[(long long)co * p.hw4] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pw_many_to_few_kernel(PwArgs p) {
+  const long long total = (long long)p.N * p.hw4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.hw4, q = i - n * p.hw4;
+    const float4* xb = reinterpret_cast<const float4*>(p.x) + n * p.Cin * p.hw4 + q;
+    float4 a[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
+      a[co] = float4{b, b, b, b};
+    }
+    for (int ci = 0; ci < p.Cin; ++ci) {
+      const float4 v = xb[(long long)ci * p.hw4];
+#pragma unroll
+      for (int co = 0; co < 4; ++co) {
+        const float w = co < p.Cout ? p.wp[(long long)ci * p.Cout_p + co] : 0.f;
+        a[co].x += w * v.x; a[co].y += w * v.y; a[co].z += w * v.z; a[co].w += w * v.w;
+      }
+    }
+    float4* yb = reinterpret_cast<float4*>(p.y) + n * p.Cout * p.hw4 + q;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      if (co >= p.Cout) continue;
+      float4 v = a[co];
+      if (p.act == GANLAB_ACT_LRELU) {
+        v.x = gl_lrelu(v.x, p.slope); v.y = gl_lrelu(v.y, p.slope); v.z = gl_lrelu(v.z, p.slope); v.w = gl_lrelu(v.w, p.slope);
+      }
+      yb[(long long)co * p.hw4] = v;
+    }
+  }
+}
+
+// part[blk][b][s]: b < B (<= 16 per launch: block of the "big" tensor's channels b0 .. b0+15), s < 4
+__global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restrict__ big, const float* __restrict__ small,
+                                                            float* __restrict__ part, int N, int B, int b0, int S,
+                                                            long long hw4, int Btot) {
+  __shared__ float red[4][64];
+  float acc[16][4];
+#pragma unroll
+  for (int b = 0; b < 16; ++b)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[b][s] = 0.f;
+  const long long total = (long long)N * hw4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / hw4, q = i - n * hw4;
+    const float4* sb = reinterpret_cast<const float4*>(small) + n * S * hw4 + q;
+    const float4* bb = reinterpret_cast<const float4*>(big) + (n * Btot + b0) * hw4 + q;
+    float4 sv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sv[s] = s < S ? sb[(long long)s * hw4] : float4{0.f, 0.f, 0.f, 0.f};
+    float4 bv[16];        // all loads first (independent, in flight together), then the multiply-adds
+#pragma unroll
+    for (int b = 0; b < 16; ++b) bv[b] = b < B ? bb[(long long)b * hw4] : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc[b][s] += (bv[b].x * sv[s].x + bv[b].y * sv[s].y) + (bv[b].z * sv[s].z + bv[b].w * sv[s].w);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int b = 0; b < 16; ++b)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float v = gl_wave_sum(acc[b][s]);
+      if (lane == 0) red[wv][b * 4 + s] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    part[(long long)blockIdx.x * 64 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// gw[co][ci] (OIHW, 1x1) = scale * sum_blk part[blk][b][s];  big_is_out: (b, s) = (co - b0, ci) else (ci - b0, co)
+__global__ void pw_cross_finish_kernel(const float* __restrict__ part, float* __restrict__ gw, int blocks, int B, int b0,
+                                       int S, int Cout, int Cin, int big_is_out, float scale) {
+  __shared__ float red[16][64];
+  const int t = threadIdx.x & 63, j = threadIdx.x >> 6;       // t = b * 4 + s; 16 groups of 64 threads split the blocks
+  float s0 = 0.f, s1 = 0.f;
+  int k = j;
+  for (; k + 16 < blocks; k += 32) {
+    s0 += part[(long long)k * 64 + t];
+    s1 += part[(long long)(k + 16) * 64 + t];
+  }
+  if (k < blocks) s0 += part[(long long)k * 64 + t];
+  red[j][t] = s0 + s1;
+  __syncthreads();
+  if (j != 0) return;
+  const int b = t >> 2, s = t & 3;
+  if (b >= B || s >= S) return;
+  float sum = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) sum += red[g][t];               // fixed order: deterministic
+  const int co = big_is_out ? b0 + b : s, ci = big_is_out ? s : b0 + b;
+  gw[(long long)co * Cin + ci] = sum * scale;
+}
+
+inline bool pw_small_ok(int Cin, int Cout, int ks, int pad, int up, int Hi, int Wi, const void* a, const void* b) {
+  const long long hw = (long long)Hi * Wi;
+  return ks == 1 && pad == 0 && !up && (hw & 3) == 0 && hw >= 4096 && ((Cin <= 4 && Cout <= 64) || (Cout <= 4 && Cin <= 64)) &&
+         aligned16(a) && aligned16(b);
+}
+
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,
              int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
@@ -1268,6 +1416,18 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
   if ((long long)Cin * a.in.Hi * a.in.Wi * 16 >= 0x7fffffffLL) return GANLAB_EINVAL;  // int offsets per tile
   a.Cin_p = round_up_c(Cin, cin_pad(ks)); a.Cout_p = round_up_c(Cout, 64);
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  if (pw_small_ok(Cin, Cout, ks, pad, up, Hi, Wi, x, y)) {      // fromRGB / toRGB: HBM-bound streaming kernels
+    PwArgs q{};
+    q.x = x; q.wp = wp; q.bias = bias; q.y = y;
+    q.N = N; q.Cin = Cin; q.Cout = Cout; q.Cout_p = a.Cout_p;
+    q.hw4 = (long long)Hi * Wi / 4;
+    q.bias_scale = bias_scale; q.slope = slope; q.act = act;
+    const long long items = (long long)N * q.hw4;
+    const unsigned blocks = (unsigned)((items + 255) / 256 < 256 * 16 ? (items + 255) / 256 : 256 * 16);
+    if (Cin <= 4) GL_LAUNCH(pw_few_to_many_kernel, dim3(blocks), dim3(256), 0, st, q);
+    else GL_LAUNCH(pw_many_to_few_kernel, dim3(blocks), dim3(256), 0, st, q);
+    return GL_CHECK_LAUNCH();
+  }
   if (ks == 1) return dispatch_co<1>(a, st);
   if (ks == 3) return dispatch_co<3>(a, st);
   return GANLAB_EINVAL;
@@ -1449,7 +1609,11 @@ size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g) {
   if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK) return 0;
   const PatchArgs in = make_patch(nullptr, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
   const WgPlan pl = plan_wgrad(in, nullptr, g->ks, g->Cout, ho, wo);
-  return (size_t)(pl.slots + 32) * g->Cout * g->Cin * g->ks * g->ks * sizeof(float);
+  size_t bytes = (size_t)(pl.slots + 32) * g->Cout * g->Cin * g->ks * g->ks * sizeof(float);
+  const void* al = reinterpret_cast<const void*>(uintptr_t(16));
+  if (pw_small_ok(g->Cin, g->Cout, g->ks, g->pad, g->up, g->Hin, g->Win, al, al) && bytes < 2048 * 64 * sizeof(float))
+    bytes = 2048 * 64 * sizeof(float);      // 2048 partial-sum blocks of the fromRGB / toRGB cross-sum kernel
+  return bytes;
 }
 
 int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
@@ -1461,6 +1625,27 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   const WgPlan pl = plan_wgrad(in, gy, g->ks, g->Cout, ho, wo);
   const long long nw = (long long)g->Cout * g->Cin * g->ks * g->ks;
   if (!workspace || workspace_bytes < (size_t)(pl.slots + 32) * nw * sizeof(float)) return GANLAB_EWORKSPACE;
+  if (pw_small_ok(g->Cin, g->Cout, g->ks, g->pad, g->up, g->Hin, g->Win, gy, x)) {
+    // fromRGB / toRGB weight gradient: cross sums between the 3-channel tensor and blocks of 16 channels of the other
+    const bool big_is_out = g->Cin <= 4;                 // fromRGB: gy is the wide tensor
+    const float* big = big_is_out ? gy : x;
+    const float* small = big_is_out ? x : gy;
+    const int Btot = big_is_out ? g->Cout : g->Cin, S = big_is_out ? g->Cin : g->Cout;
+    const long long hw4 = (long long)g->Hin * g->Win / 4;
+    long long blocks = (long long)(workspace_bytes / (64 * sizeof(float)));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks >= 64) {
+      hipStream_t st = gl_stream(stream);
+      for (int b0 = 0; b0 < Btot; b0 += 16) {
+        const int B = Btot - b0 < 16 ? Btot - b0 : 16;
+        GL_LAUNCH(pw_cross_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, big, small, (float*)workspace, g->N, B,
+                  b0, S, hw4, Btot);
+        GL_LAUNCH(pw_cross_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, gw, (int)blocks, B, b0, S,
+                  g->Cout, g->Cin, big_is_out ? 1 : 0, scale);
+      }
+      return GL_CHECK_LAUNCH();
+    }
+  }
   LaunchFn f{};
   f.a.in = in; f.a.gy = gy; f.a.part = (float*)workspace;
   f.a.Cout = g->Cout; f.a.Ho = ho; f.a.Wo = wo;
