@@ -166,18 +166,23 @@ __global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y,
 // ---------------------------------------------------------------------------------------------- //
 enum { BF_FWD = 0, BF_A = 1, BF_AT = 2 };
 
-template <int MODE, int R>
+// STATS (BF_FWD only): grid (chunks, C, N) - a block stays inside ONE (n, c) plane and also accumulates sum / sum of
+// squares of its outputs in fp64 (the InstanceNorm statistics of the next op: stylegan/architectures.py:524-526 reads
+// the tensor this kernel writes); block partials go to spart[((n*C + c)*chunks + chunk)*2 + {0,1}].
+template <int MODE, int R, bool STATS = false>
 __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in, const float* __restrict__ y,
                                                          const float* __restrict__ noise,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ noise_w, float* __restrict__ out,
                                                          float* __restrict__ part, int N, int C, int H, int W,
                                                          int chunks, float bias_scale, int act, float slope,
-                                                         int want_sums) {
+                                                         int want_sums, double* __restrict__ spart = nullptr) {
   __shared__ float red[4];
+  __shared__ double dred[2][4];
   const int c = blockIdx.y, chunk = blockIdx.x;
   const int w4 = W >> 2, hr = H / R;
-  const long long per_n = (long long)hr * w4, total = (long long)N * per_n, HW = (long long)H * W;
+  const long long per_n = (long long)hr * w4, total = STATS ? per_n : (long long)N * per_n, HW = (long long)H * W;
+  double ds = 0.0, dss = 0.0;
   const float b = (MODE == BF_FWD && bias) ? bias[c] * bias_scale : 0.f;
   const float nw = (MODE == BF_FWD && noise) ? noise_w[c] : 0.f;
   float s0 = 0.f, s1 = 0.f;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
     const long long i = base + threadIdx.x;
     const bool live = i < total;
     const long long ii = live ? i : total - 1;
-    const long long n = ii / per_n, rem = ii - n * per_n;
+    const long long n = STATS ? (long long)blockIdx.z : ii / per_n, rem = STATS ? ii : ii - n * per_n;
     const int rr = (int)(rem / w4), q = (int)(rem - (long long)rr * w4);
     const long long plane = (n * C + c) * HW;
     const int y0 = R * rr, x0 = 4 * q;
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
           float t = o[j] + b + nw * nz[j];
           if (act == GANLAB_ACT_LRELU) t = gl_lrelu(t, slope);
           o[j] = t;
+          if (STATS) {
+            const double d = (double)t;
+            ds += d;
+            dss += d * d;
+          }
         }
       } else if (MODE == BF_A) {
         float m[4];
@@ -231,6 +241,22 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
         }
       }
       *reinterpret_cast<float4*>(out + plane + co + (long long)k * W) = *reinterpret_cast<float4*>(o);
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ds += __shfl_xor(ds, o, 64);
+      dss += __shfl_xor(dss, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      dred[0][threadIdx.x >> 6] = ds;
+      dred[1][threadIdx.x >> 6] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const int k = threadIdx.x;
+      spart[(((long long)blockIdx.z * C + c) * chunks + chunk) * 2 + k] = (dred[k][0] + dred[k][1]) + (dred[k][2] + dred[k][3]);
     }
   }
   if (MODE != BF_FWD && want_sums) {
@@ -265,6 +291,80 @@ inline int blur_fused_chunks(int N, int H, int W) {
   long long c = ((long long)N * (H / blur_rows(H)) * (W / 4) + 256 * 4 - 1) / (256 * 4);
   if (c < 1) c = 1;
   if (c > 128) c = 128;
+  return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------------- //
+// bias / noise / activation that also accumulates the InstanceNorm statistics of its output: grid (chunks, N*C), a block
+// stays inside one plane; spart[(plane*chunks + chunk)*2 + {0,1}] = sum y, sum y^2 (fp64).  HW % 4 == 0.
+// ---------------------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void bias_act_stats_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                             const float* __restrict__ noise,
+                                                             const float* __restrict__ noise_w, float* __restrict__ y,
+                                                             double* __restrict__ spart, int C, long long hw4,
+                                                             int chunks, float bias_scale, int act, float slope) {
+  __shared__ double dred[2][4];
+  const long long pl = blockIdx.y;
+  const int c = (int)(pl % C);
+  const long long n = pl / C;
+  const float b = bias ? bias[c] * bias_scale : 0.f;
+  const float nw = noise ? noise_w[c] : 0.f;
+  const float4* xp = reinterpret_cast<const float4*>(x) + pl * hw4;
+  const float4* np = noise ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
+  float4* yp = reinterpret_cast<float4*>(y) + pl * hw4;
+  double ds = 0.0, dss = 0.0;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < hw4; i += (long long)chunks * 256) {
+    float v[4], nz[4] = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<float4*>(v) = xp[i];
+    if (np) *reinterpret_cast<float4*>(nz) = np[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = v[k] + b + nw * nz[k];
+      if (act == GANLAB_ACT_LRELU) t = gl_lrelu(t, slope);
+      v[k] = t;
+      const double d = (double)t;
+      ds += d;
+      dss += d * d;
+    }
+    yp[i] = *reinterpret_cast<float4*>(v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ds += __shfl_xor(ds, o, 64);
+    dss += __shfl_xor(dss, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    dred[0][threadIdx.x >> 6] = ds;
+    dred[1][threadIdx.x >> 6] = dss;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x;
+    spart[(pl * chunks + blockIdx.x) * 2 + k] = (dred[k][0] + dred[k][1]) + (dred[k][2] + dred[k][3]);
+  }
+}
+
+// mean / rstd of every plane from the chunk partials (fixed order, fp64)
+__global__ void act_stats_finish_kernel(const double* __restrict__ spart, float* __restrict__ mean,
+                                        float* __restrict__ rstd, long long planes, int chunks, double inv_hw, float eps) {
+  const long long pl = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pl >= planes) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += spart[(pl * chunks + k) * 2];
+    ss += spart[(pl * chunks + k) * 2 + 1];
+  }
+  const double m = s * inv_hw;
+  double var = ss * inv_hw - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[pl] = (float)m;
+  rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+inline int act_stats_chunks(long long hw4) {
+  long long c = (hw4 + 256 * 8 - 1) / (256 * 8);      // ~8 float4 per thread
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
   return (int)c;
 }
 
@@ -992,6 +1092,58 @@ int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noi
   const int chunks = blur_fused_chunks(N, H, W);
   BLUR_FUSED_LAUNCH(BF_FWD, x, (const float*)nullptr, noise, bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks,
                     bias_scale, act, slope, 0);
+  return GL_CHECK_LAUNCH();
+}
+
+size_t ganlab_act_stats_workspace(int N, int C, long long HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)N * C * 128 * 2 * sizeof(double);       // up to 128 chunks per plane (blur: blur_fused_chunks)
+}
+
+/* y = act(x + noise + bias) and the InstanceNorm statistics (mean, rstd with eps) of y in the same pass */
+int ganlab_bias_act_stats_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                              float* mean, float* rstd, int N, int C, long long HW, float bias_scale, int act,
+                              float slope, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !y || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
+  if ((HW & 3) != 0) return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < ganlab_act_stats_workspace(N, C, HW)) return GANLAB_EWORKSPACE;
+  const long long hw4 = HW / 4, planes = (long long)N * C;
+  const int chunks = act_stats_chunks(hw4);
+  double* sp = reinterpret_cast<double*>(workspace);
+  GL_LAUNCH(bias_act_stats_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, x, bias, noise, noise_w,
+            y, sp, C, hw4, chunks, bias_scale, act, slope);
+  GL_LAUNCH(act_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, (const double*)sp, mean,
+            rstd, planes, chunks, 1.0 / (double)HW, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+/* y = act(blur(x) + noise + bias) and the InstanceNorm statistics of y in the same pass */
+int ganlab_blur_bias_act_stats_f32(const float* x, const float* bias, const float* noise, const float* noise_w,
+                                   float* y, float* mean, float* rstd, int N, int C, int H, int W, float bias_scale,
+                                   int act, float slope, float eps, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (!x || !y || !mean || !rstd || N <= 0 || C <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < ganlab_act_stats_workspace(N, C, (long long)H * W)) return GANLAB_EWORKSPACE;
+  const int rows = blur_rows_mode(H, BF_FWD);
+  long long per_n = (long long)(H / rows) * (W / 4);
+  int chunks = (int)((per_n + 256 * 4 - 1) / (256 * 4));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 128) chunks = 128;
+  double* sp = reinterpret_cast<double*>(workspace);
+  const dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)N);
+  if (rows == 8)
+    GL_LAUNCH((blur_fused_kernel<BF_FWD, 8, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
+              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+  else if (rows == 4)
+    GL_LAUNCH((blur_fused_kernel<BF_FWD, 4, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
+              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+  else
+    GL_LAUNCH((blur_fused_kernel<BF_FWD, 2, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
+              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+  const long long planes = (long long)N * C;
+  GL_LAUNCH(act_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, (const double*)sp, mean,
+            rstd, planes, chunks, 1.0 / ((double)H * W), eps);
   return GL_CHECK_LAUNCH();
 }
 

@@ -350,6 +350,44 @@ def k_blur_bias_act(x, bias, noise, noise_w, bias_scale, act, slope):
     return y
 
 
+def _stats_out(x, n, c, hw):
+    L = _lib.lib()
+    ws = torch.empty((max(L.ganlab_act_stats_workspace(n, c, hw), 8) + 7) // 8, dtype=torch.float64, device=x.device)
+    return _new((n * c,), x), _new((n * c,), x), ws
+
+
+def k_blur_bias_act_stats(x, bias, noise, noise_w, bias_scale, act, slope, eps):
+    """k_blur_bias_act that also returns the InstanceNorm statistics (mean, rstd) of its output."""
+    x = _c(x)
+    n, c, h, w = x.shape
+    bias = _c(bias) if bias is not None else None
+    if noise is not None:
+        noise, noise_w = _c(noise), _c(noise_w)
+        assert noise.numel() == n * h * w and noise_w.numel() == c
+    y = torch.empty_like(x)
+    mean, rstd, ws = _stats_out(x, n, c, h * w)
+    check(_lib.lib().ganlab_blur_bias_act_stats_f32(_p(x), _p(bias), _p(noise), _p(noise_w), _p(y), _p(mean), _p(rstd),
+                                                    n, c, h, w, bias_scale, act, slope, eps, _p(ws), ws.numel() * 8,
+                                                    _st()), 'blur_bias_act_stats')
+    return y, mean, rstd
+
+
+def k_bias_act_stats(x, bias, noise, noise_w, bias_scale, act, slope, eps):
+    x = _c(x)
+    n, c, hw = _nchw(x)
+    y = torch.empty_like(x)
+    bias = _c(bias) if bias is not None else None
+    noise = _c(noise) if noise is not None else None
+    noise_w = _c(noise_w) if noise_w is not None else None
+    if noise is not None:
+        assert noise.numel() == n * hw and noise_w.numel() == c
+    mean, rstd, ws = _stats_out(x, n, c, hw)
+    check(_lib.lib().ganlab_bias_act_stats_f32(_p(x), _p(bias), _p(noise), _p(noise_w), _p(y), _p(mean), _p(rstd), n, c,
+                                               hw, bias_scale, act, slope, eps, _p(ws), ws.numel() * 8, _st()),
+          'bias_act_stats')
+    return y, mean, rstd
+
+
 def k_blur_act_bwd(g, y, slope, bias_scale, want_gb):
     g, y = _c(g), _c(y)
     assert g.shape == y.shape
@@ -637,16 +675,22 @@ class _BlurBiasAct(Function):
     StyleAddNoise / Conv2dBias / LeakyReLU (stylegan/architectures.py:331-360 + :105-119)."""
 
     @staticmethod
-    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope):
-        y = k_blur_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope, stats_eps=None):
+        stats = None
+        if stats_eps is None:
+            y = k_blur_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+        else:    # + the InstanceNorm statistics of y in the same pass (handed to instnorm_style as constants)
+            y, mean, rstd = k_blur_bias_act_stats(x, bias, noise, noise_w, bias_scale, act, slope, stats_eps)
+            ctx.mark_non_differentiable(mean, rstd)
+            stats = (mean, rstd)
         ctx.save_for_backward(y if act != ACT_NONE else None, noise)
         ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
-        return y
+        return y if stats is None else (y,) + stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         y, noise = ctx.saved_tensors
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
@@ -655,7 +699,7 @@ class _BlurBiasAct(Function):
         gx, gb, gnw = _ActBwdBlur.apply(gy, y if act else gy, noise if want_nw else None,
                                         ctx.slope if act else 1.0, ctx.bias_scale, bool(want_b), bool(want_nw))
         return (gx if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if want_b else None), None, \
-            (gnw.view(ctx.nw_shape) if want_nw else None), None, None, None
+            (gnw.view(ctx.nw_shape) if want_nw else None), None, None, None, None
 
 
 class _ChanSum(Function):
@@ -718,16 +762,22 @@ class _BiasAct(Function):
     custom_layers.py:213-226, stylegan/architectures.py:105-119)."""
 
     @staticmethod
-    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope):
-        y = k_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+    def forward(ctx, x, bias, noise, noise_w, bias_scale, act, slope, stats_eps=None):
+        stats = None
+        if stats_eps is None:
+            y = k_bias_act(x, bias, noise, noise_w, bias_scale, act, slope)
+        else:
+            y, mean, rstd = k_bias_act_stats(x, bias, noise, noise_w, bias_scale, act, slope, stats_eps)
+            ctx.mark_non_differentiable(mean, rstd)
+            stats = (mean, rstd)
         ctx.save_for_backward(y if act != ACT_NONE else None, noise)
         ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
-        return y
+        return y if stats is None else (y,) + stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         y, noise = ctx.saved_tensors
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
@@ -741,7 +791,7 @@ class _BiasAct(Function):
         if ctx.nw_shape is not None and ctx.needs_input_grad[3] and params:
             gnw = _ChanSum.apply(gz, noise, 1.0).view(ctx.nw_shape)
         return (gz if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if gb is not None else None), \
-            None, gnw, None, None, None
+            None, gnw, None, None, None, None
 
 
 class _Blur(Function):
@@ -810,12 +860,14 @@ class _InstNormStyle(Function):
     (custom_layers.py:98-99 + stylegan/architectures.py:524-526); style=None -> plain IN."""
 
     @staticmethod
-    def forward(ctx, x, style, eps):
+    def forward(ctx, x, style, eps, mean=None, rstd=None):
         x = _c(x)
         n, c, hw = _nchw(x)
         L = _lib.lib()
-        mean, rstd = _new((n * c,), x), _new((n * c,), x)
-        check(L.ganlab_instnorm_stats_f32(_p(x), _p(mean), _p(rstd), n * c, hw, eps, _st()), 'instnorm_stats')
+        if mean is None:     # otherwise: produced by the kernel that wrote x (bias_act(..., stats_eps=eps))
+            mean, rstd = _new((n * c,), x), _new((n * c,), x)
+            check(L.ganlab_instnorm_stats_f32(_p(x), _p(mean), _p(rstd), n * c, hw, eps, _st()), 'instnorm_stats')
+        assert mean.numel() == n * c and rstd.numel() == n * c
         style_c = _c(style) if style is not None else None
         if style_c is not None:
             assert style_c.numel() == n * 2 * c
@@ -844,7 +896,7 @@ class _InstNormStyle(Function):
         gstyle = None
         if style is not None and ctx.needs_input_grad[1]:
             gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)  # d/dys = sum gy*xhat ; d/dyb = sum gy
-        return gx, gstyle, None
+        return gx, gstyle, None, None, None
 
 
 class _PixelNorm(Function):
@@ -1324,14 +1376,31 @@ def linear(x, weight, bias=None, scale=1.0, bias_scale=1.0, act=None, slope=0.2)
     return y.view(n, cout)
 
 
-def bias_act(x, bias=None, noise=None, noise_w=None, bias_scale=1.0, act=None, slope=0.2, blur=False):
-    """act(blur?(x) + noise_w*noise + bias*bias_scale); ``blur``: the binomial blur in front (one fused pass)."""
+STATS_MIN_PLANE = 1024   # planes below 32x32: the separate one-block-per-plane statistics kernel costs nothing
+
+
+def bias_act(x, bias=None, noise=None, noise_w=None, bias_scale=1.0, act=None, slope=0.2, blur=False, stats_eps=None):
+    """act(blur?(x) + noise_w*noise + bias*bias_scale); ``blur``: the binomial blur in front (one fused pass).
+    ``stats_eps``: also return the InstanceNorm statistics of the result, ``(y, (mean, rstd))`` - or ``(y, None)``
+    where the plane is too small / ragged for the fused accumulation - to hand to ``instnorm_style(stats=...)``."""
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    eps = None
+    if stats_eps is not None and x.dim() == 4:
+        hw = x.shape[2] * x.shape[3]
+        if hw >= STATS_MIN_PLANE and hw % 4 == 0:
+            eps = float(stats_eps)
     if blur:
         if blur_fusable(x):
-            return _BlurBiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope))
+            out = _BlurBiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope), eps)
+            return _with_stats(out, stats_eps, eps)
         x = _Blur.apply(x)
-    return _BiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope))
+    return _with_stats(_BiasAct.apply(x, bias, noise, noise_w, float(bias_scale), a, float(slope), eps), stats_eps, eps)
+
+
+def _with_stats(out, asked, fused):
+    if asked is None:
+        return out
+    return (out[0], (out[1], out[2])) if fused is not None else (out, None)
 
 
 def blur(x):
@@ -1366,8 +1435,11 @@ def global_avg_pool(x):
     return (_ChanSum.apply(x.reshape(1, n * c, h * w), None, 1.0 / (h * w))).view(n, c, 1, 1)
 
 
-def instnorm_style(x, style=None, eps=1e-8):
-    return _InstNormStyle.apply(x, style, float(eps))
+def instnorm_style(x, style=None, eps=1e-8, stats=None):
+    """``stats``: (mean, rstd) of ``x`` for this ``eps`` from ``bias_act(..., stats_eps=eps)`` (saves the pass)."""
+    if stats is None:
+        return _InstNormStyle.apply(x, style, float(eps))
+    return _InstNormStyle.apply(x, style, float(eps), stats[0], stats[1])
 
 
 def pixelnorm(x, eps=1e-8):

@@ -24,6 +24,7 @@ from ..utils.latent_utils import gen_rand_latent_vars
 from .base import StyleGAN
 
 FMAP_G_INIT_FCTR = 1
+IN_EPS = 1e-8     # NormalizeLayer('InstanceNorm') epsilon (custom_layers.py:98-99)
 
 
 class StyleMappingNetwork(nn.Module):
@@ -241,17 +242,20 @@ class StyleGenerator(StyleGAN):
         bias = mods.pop(0) if mods and isinstance(mods[0], Conv2dBias) else None
         act = mods.pop(0) if mods and isinstance(mods[0], LeakyReLU) else None
         nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
+        if not self.use_instancenorm:
+            raise NotImplementedError('use_instancenorm=False (AdaIN without normalisation) has no fused kernel')
+        # blur + noise + bias + LeakyReLU in one pass, which also accumulates the InstanceNorm statistics of its
+        # output when the InstanceNorm reads exactly that tensor (no PixelNorm in between)
         out = ops.bias_act(out, bias.bias if bias is not None else None, nz,
                            layer[1].noise_weight if nz is not None else None,
                            act='lrelu' if act is not None else None,
                            slope=act.negative_slope if act is not None else 0.2,
-                           blur=blur)                                  # blur + noise + bias + LeakyReLU: one pass
+                           blur=blur, stats_eps=None if self.use_pixelnorm else IN_EPS)
+        out, stats = (out, None) if self.use_pixelnorm else out
         if self.use_pixelnorm:
             out = ops.pixelnorm(out)
         y = layer[3](w)                                                # (B, 2C) style
-        if not self.use_instancenorm:
-            raise NotImplementedError('use_instancenorm=False (AdaIN without normalisation) has no fused kernel')
-        return ops.instnorm_style(out, y)                              # IN + (ys+1, yb) in one pass
+        return ops.instnorm_style(out, y, IN_EPS, stats)               # IN + (ys+1, yb) in one pass
 
     def _new_w(self, bs, dev):
         z2 = gen_rand_latent_vars(num_samples=bs, length=self.len_latent, distribution=self.latent_distribution,

@@ -154,6 +154,18 @@ int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* g
 int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, float* out, float* gb, float* gnw,
                             int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* The same two forward ops, also producing the InstanceNorm statistics of their OUTPUT in the same pass (the generator
+ * layer is conv -> [blur] -> noise + bias + LeakyReLU -> InstanceNorm + style, stylegan/architectures.py:497-526: the
+ * statistics pass of ganlab_instnorm_stats_f32 over the tensor just written is saved).  mean / rstd: (N*C,), rstd =
+ * 1/sqrt(biased var + eps); fp64 sums; workspace ganlab_act_stats_workspace bytes.  HW % 4 == 0. */
+size_t ganlab_act_stats_workspace(int N, int C, long long HW);
+int ganlab_bias_act_stats_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
+                              float* mean, float* rstd, int N, int C, long long HW, float bias_scale, int act,
+                              float slope, float eps, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_blur_bias_act_stats_f32(const float* x, const float* bias, const float* noise, const float* noise_w,
+                                   float* y, float* mean, float* rstd, int N, int C, int H, int W, float bias_scale,
+                                   int act, float slope, float eps, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);

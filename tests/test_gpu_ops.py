@@ -527,3 +527,48 @@ def test_thin_layer_multi_tile_strips(ops, n, r):
     gz = gy * torch.where(y.detach().cpu() > 0, 1.0, 0.2)    # the kernel's own sign pattern (|pre| ~ 1e-7 ties)
     gx = F.conv_transpose2d(gz, wt * scale, padding=1)
     assert_close(xg.grad.cpu(), gx, TOL, 'strip dgrad')
+
+
+@pytest.mark.parametrize('shape,blur', [((2, 5, 32, 32), False), ((2, 5, 32, 32), True), ((3, 4, 64, 128), True),
+                                        ((1, 3, 256, 256), True), ((1, 2, 512, 512), True), ((2, 3, 40, 52), False),
+                                        ((2, 3, 16, 16), True)])
+def test_bias_act_with_fused_instnorm_statistics(ops, shape, blur):
+    """The generator layer tail (stylegan/architectures.py:497-526): noise + bias + LeakyReLU (+ blur in front) whose
+    kernel also accumulates the InstanceNorm statistics of its output.  Same result as the separate statistics pass
+    (both fp64 sums of the same fp32 values) and as the float64 oracle, forward and backward; near-constant planes
+    (|mean| >> std) keep their variance."""
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((shape, blur)).encode()))
+    n, c, h, w = shape
+    for offset, std in [(0.0, 1.0), (3.0, 1e-2)]:
+        x = (offset + std * torch.randn(*shape, generator=gen)).requires_grad_(True)
+        b = (0.1 * torch.randn(c, generator=gen)).requires_grad_(True)
+        nz = std * torch.randn(n, 1, h, w, generator=gen)
+        nw = (0.3 * torch.randn(c, generator=gen)).requires_grad_(True)
+        st = torch.randn(n, 2 * c, generator=gen)
+        cot = torch.randn(*shape, generator=gen)
+        xd = x.double()
+        pre = (_blur_ref(xd) if blur else xd) + nw.double().view(1, c, 1, 1) * nz.double() + b.double().view(1, c, 1, 1)
+        ref = O.adain_affine(O.instancenorm(F.leaky_relu(pre, 0.2)), st.double())
+        (ref * cot.double()).sum().backward()
+        want = [x.grad.clone(), b.grad.clone(), nw.grad.clone()]
+
+        outs = []
+        for fused in (True, False):
+            xg, bg, nwg = (gpu(v).requires_grad_(True) for v in (x, b, nw))
+            y = ops.bias_act(xg, bg, nz.cuda(), nwg, act='lrelu', blur=blur, stats_eps=1e-8 if fused else None)
+            y, stats = y if fused else (y, None)
+            if fused:
+                assert (stats is not None) == (h * w >= ops.STATS_MIN_PLANE and (h * w) % 4 == 0)
+            o = ops.instnorm_style(y, st.cuda(), 1e-8, stats)
+            (o * cot.cuda()).sum().backward()
+            outs.append((o.detach(), xg.grad, bg.grad, nwg.grad))
+        f, s = outs
+        tol = TOL if std == 1.0 else 2e-3
+        assert_close(f[0], ref.float(), tol, f'fused-stats fwd {shape} blur={blur} std={std}')
+        assert_close(f[0], s[0], 1e-6, f'fused vs separate statistics {shape} blur={blur} std={std}')
+        for got, sep, w_, name in zip(f[1:], s[1:], want, ('dx', 'dbias', 'dnoise_w')):
+            if name == 'dbias' and std != 1.0:
+                continue     # all-positive planes: a channel shift in front of the IN has an exactly zero gradient
+            assert_close(got, w_.float(), tol, f'fused-stats {name} {shape} blur={blur} std={std}')
+            assert_close(got, sep, 1e-5, f'fused vs separate {name} {shape} blur={blur} std={std}')
