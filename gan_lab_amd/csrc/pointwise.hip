@@ -658,6 +658,57 @@ __global__ void instnorm_bwd_apply_kernel(const float* __restrict__ gy, const fl
   }
 }
 
+// InstanceNorm+style backward fused with the backward of the LeakyReLU / bias / noise in front of it (the generator
+// layer tail, stylegan/architectures.py:497-526): x is at once the InstanceNorm input and the LeakyReLU output, so
+//   gz = [k*(gy - a1 - xhat*a2)] * lrelu'(x)      and its channel sums  sum gz (bias),  sum gz*noise (noise weight)
+// come out of ONE pass.  grid (chunks, N*C); part[(c*N + n)*chunks + chunk] (+ C*N*chunks for the noise sums).
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ style, const float* __restrict__ s1,
+    const float* __restrict__ s2, const float* __restrict__ noise, float* __restrict__ gz, float* __restrict__ part,
+    int N, int C, long long hw4, int chunks, int act, float slope, int want_b, int want_nw) {
+  __shared__ float red[4];
+  const long long pl = blockIdx.y;
+  const int c = (int)(pl % C);
+  const long long n = pl / C;
+  const float m = mean[pl], r = rstd[pl];
+  const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
+  const float inv = 1.f / (float)(hw4 * 4);
+  const float k = r * ys, a1 = s1[pl] * inv, a2 = s2[pl] * inv;
+  const float4* pg = reinterpret_cast<const float4*>(gy) + pl * hw4;
+  const float4* px = reinterpret_cast<const float4*>(x) + pl * hw4;
+  const float4* pn = (want_nw && noise) ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
+  float4* po = reinterpret_cast<float4*>(gz) + pl * hw4;
+  float sb = 0.f, snw = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < hw4; i += (long long)chunks * 256) {
+    float g[4], v[4], o[4];
+    *reinterpret_cast<float4*>(g) = pg[i];
+    *reinterpret_cast<float4*>(v) = px[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = k * (g[j] - a1 - (v[j] - m) * r * a2);
+      if (act == GANLAB_ACT_LRELU && !(v[j] > 0.f)) t *= slope;
+      o[j] = t;
+    }
+    po[i] = *reinterpret_cast<float4*>(o);
+    sb += (o[0] + o[1]) + (o[2] + o[3]);
+    if (pn) {
+      const float4 z = pn[i];
+      snw += (o[0] * z.x + o[1] * z.y) + (o[2] * z.z + o[3] * z.w);
+    }
+  }
+  const long long slot = ((long long)c * N + n) * chunks + blockIdx.x;
+  if (want_b) {
+    sb = gl_block_sum_256(sb, red);
+    if (threadIdx.x == 0) part[slot] = sb;
+  }
+  if (want_nw) {
+    if (want_b) __syncthreads();
+    snw = gl_block_sum_256(snw, red);
+    if (threadIdx.x == 0) part[(long long)C * N * chunks + slot] = snw;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- //
 // PixelNorm over channels (custom_layers.py:85-86); one thread per pixel, coalesced across pixels
 // ---------------------------------------------------------------------------------------------- //
@@ -1098,6 +1149,36 @@ int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noi
 size_t ganlab_act_stats_workspace(int N, int C, long long HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   return (size_t)N * C * 128 * 2 * sizeof(double);       // up to 128 chunks per plane (blur: blur_fused_chunks)
+}
+
+size_t ganlab_instnorm_bwd_act_workspace(int N, int C, long long HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)2 * N * C * 64 * sizeof(float);
+}
+
+/* backward of  out = InstanceNorm(x)*(ys+1)+yb  with  x = lrelu(z + noise_w*noise + bias*bias_scale):
+ * gz = dL/dz, gb = bias_scale * sum gz (or NULL), gnw = sum gz*noise (or NULL).  s1, s2 from
+ * ganlab_instnorm_style_bwd_reduce_f32.  HW % 4 == 0. */
+int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                      const float* style, const float* s1, const float* s2, const float* noise,
+                                      float* gz, float* gb, float* gnw, int N, int C, long long HW, int act,
+                                      float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!gy || !x || !mean || !rstd || !s1 || !s2 || !gz || N <= 0 || C <= 0 || HW <= 0 || (gnw && !noise))
+    return GANLAB_EINVAL;
+  if ((HW & 3) != 0) return GANLAB_EUNSUPPORTED;
+  if ((gb || gnw) && (!workspace || workspace_bytes < ganlab_instnorm_bwd_act_workspace(N, C, HW)))
+    return GANLAB_EWORKSPACE;
+  const long long hw4 = HW / 4, planes = (long long)N * C;
+  const int chunks = act_stats_chunks(hw4);
+  float* part = reinterpret_cast<float*>(workspace);
+  GL_LAUNCH(instnorm_bwd_apply_act_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, gy, x, mean,
+            rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part, gb, C, N * chunks, bias_scale);
+  if (gnw)
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part + (size_t)C * N * chunks, gnw, C,
+              N * chunks, 1.f);
+  return GL_CHECK_LAUNCH();
 }
 
 /* y = act(x + noise + bias) and the InstanceNorm statistics (mean, rstd with eps) of y in the same pass */

@@ -899,6 +899,65 @@ class _InstNormStyle(Function):
         return gx, gstyle, None, None, None
 
 
+class _LayerTail(Function):
+    """out = InstanceNorm(act(blur?(x) + noise_w*noise + bias*bias_scale)) * (ys+1) + yb: everything of a generator
+    layer after its convolution (stylegan/architectures.py:497-526) as two forward passes (the first one also accumulates
+    the InstanceNorm statistics) and, backward, the reduce pass + ONE apply pass that also undoes the LeakyReLU and sums
+    the bias / noise-weight gradients (+ blur^T when ``blur``).  First order only, like _InstNormStyle."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_w, style, bias_scale, act, slope, blur, eps):
+        kern = k_blur_bias_act_stats if blur else k_bias_act_stats
+        noise = _c(noise) if noise is not None else None
+        y, mean, rstd = kern(x, bias, noise, noise_w, bias_scale, act, slope, eps)
+        n, c, hw = _nchw(y)
+        style_c = _c(style) if style is not None else None
+        if style_c is not None:
+            assert style_c.numel() == n * 2 * c
+        out = torch.empty_like(y)
+        check(_lib.lib().ganlab_instnorm_style_fwd_f32(_p(y), _p(mean), _p(rstd), _p(style_c), _p(out), n, c, hw, _st()),
+              'instnorm_style_fwd')
+        ctx.save_for_backward(y, mean, rstd, style_c, noise)
+        ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, blur
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.style_shape = style.shape if style is not None else None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        y, mean, rstd, style, noise = ctx.saved_tensors
+        gout = _c(gout)
+        n, c, hw = _nchw(y)
+        L = _lib.lib()
+        params = _want_param_grads()
+        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
+        want_nw = ctx.nw_shape is not None and ctx.needs_input_grad[3] and params
+        s1, s2 = _new((n, c), y), _new((n, c), y)
+        check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
+                                                     _st()), 'instnorm_bwd_reduce')
+        gx = gb = gnw = None
+        if ctx.needs_input_grad[0] or want_b or want_nw:
+            gz = torch.empty_like(y)
+            gb = _new((c,), y) if want_b else None
+            gnw = _new((c,), y) if want_nw else None
+            ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
+                             device=y.device) if (want_b or want_nw) else None
+            check(L.ganlab_instnorm_style_bwd_act_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
+                                                      _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
+                                                      hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
+                                                      ws.numel() * 4 if ws is not None else 0, _st()),
+                  'instnorm_bwd_act')
+            if ctx.needs_input_grad[0]:
+                gx = k_blur(gz) if ctx.blur else gz
+        gstyle = None
+        if style is not None and ctx.needs_input_grad[4]:
+            gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)
+        return gx, (gb.view(ctx.bias_shape) if want_b else None), None, \
+            (gnw.view(ctx.nw_shape) if want_nw else None), gstyle, None, None, None, None, None
+
+
 class _PixelNorm(Function):
     @staticmethod
     def forward(ctx, x, eps):
@@ -1433,6 +1492,21 @@ def global_avg_pool(x):
     """nn.AvgPool2d(kernel_size=H) on an (N,C,H,H) map -> (N,C,1,1): plane sums through the channel-sum kernel."""
     n, c, h, w = x.shape
     return (_ChanSum.apply(x.reshape(1, n * c, h * w), None, 1.0 / (h * w))).view(n, c, 1, 1)
+
+
+def layer_tail(x, bias=None, noise=None, noise_w=None, style=None, bias_scale=1.0, act=None, slope=0.2, blur=False,
+               eps=1e-8):
+    """InstanceNorm+style of act(blur?(x) + noise_w*noise + bias*bias_scale): the generator layer after its conv.
+    Large planes take the fused forward / backward passes (_LayerTail); small or ragged ones compose the two ops."""
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    if x.dim() == 4 and noise is not None and noise.dim() == 4 and noise.shape[0] != x.shape[0]:
+        noise = noise.expand(x.shape[0], *noise.shape[1:])
+    hw = x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+    if hw >= STATS_MIN_PLANE and hw % 4 == 0 and (not blur or blur_fusable(x)):
+        return _LayerTail.apply(x, bias, noise, noise_w, style, float(bias_scale), a, float(slope), bool(blur),
+                                float(eps))
+    y = bias_act(x, bias, noise, noise_w, bias_scale, act, slope, blur)
+    return instnorm_style(y, style, eps)
 
 
 def instnorm_style(x, style=None, eps=1e-8, stats=None):

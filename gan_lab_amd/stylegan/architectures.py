@@ -244,18 +244,16 @@ class StyleGenerator(StyleGAN):
         nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
         if not self.use_instancenorm:
             raise NotImplementedError('use_instancenorm=False (AdaIN without normalisation) has no fused kernel')
-        # blur + noise + bias + LeakyReLU in one pass, which also accumulates the InstanceNorm statistics of its
-        # output when the InstanceNorm reads exactly that tensor (no PixelNorm in between)
-        out = ops.bias_act(out, bias.bias if bias is not None else None, nz,
-                           layer[1].noise_weight if nz is not None else None,
-                           act='lrelu' if act is not None else None,
-                           slope=act.negative_slope if act is not None else 0.2,
-                           blur=blur, stats_eps=None if self.use_pixelnorm else IN_EPS)
-        out, stats = (out, None) if self.use_pixelnorm else out
-        if self.use_pixelnorm:
-            out = ops.pixelnorm(out)
+        bias_t = bias.bias if bias is not None else None
+        nw = layer[1].noise_weight if nz is not None else None
+        name = 'lrelu' if act is not None else None
+        slope = act.negative_slope if act is not None else 0.2
         y = layer[3](w)                                                # (B, 2C) style
-        return ops.instnorm_style(out, y, IN_EPS, stats)               # IN + (ys+1, yb) in one pass
+        if not self.use_pixelnorm:
+            # blur + noise + bias + LeakyReLU (+ the InstanceNorm statistics) in one pass, IN + (ys+1, yb) in a second
+            return ops.layer_tail(out, bias_t, nz, nw, y, act=name, slope=slope, blur=blur, eps=IN_EPS)
+        out = ops.pixelnorm(ops.bias_act(out, bias_t, nz, nw, act=name, slope=slope, blur=blur))
+        return ops.instnorm_style(out, y, IN_EPS)
 
     def _new_w(self, bs, dev):
         z2 = gen_rand_latent_vars(num_samples=bs, length=self.len_latent, distribution=self.latent_distribution,

@@ -166,6 +166,15 @@ int ganlab_blur_bias_act_stats_f32(const float* x, const float* bias, const floa
                                    float* y, float* mean, float* rstd, int N, int C, int H, int W, float bias_scale,
                                    int act, float slope, float eps, void* workspace, size_t workspace_bytes,
                                    void* stream);
+/* ... and the matching backward: InstanceNorm+style backward fused with the LeakyReLU / bias / noise backward in front
+ * of it (x = that layer's activated output = the InstanceNorm input).  gz = dL/d(pre-activation), gb (C,) =
+ * bias_scale * sum gz or NULL, gnw (C,) = sum gz*noise or NULL; s1, s2 from ganlab_instnorm_style_bwd_reduce_f32. */
+size_t ganlab_instnorm_bwd_act_workspace(int N, int C, long long HW);
+int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                      const float* style, const float* s1, const float* s2, const float* noise,
+                                      float* gz, float* gb, float* gnw, int N, int C, long long HW, int act,
+                                      float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);

@@ -549,26 +549,33 @@ def test_bias_act_with_fused_instnorm_statistics(ops, shape, blur):
         cot = torch.randn(*shape, generator=gen)
         xd = x.double()
         pre = (_blur_ref(xd) if blur else xd) + nw.double().view(1, c, 1, 1) * nz.double() + b.double().view(1, c, 1, 1)
+        st = st.requires_grad_(True)
         ref = O.adain_affine(O.instancenorm(F.leaky_relu(pre, 0.2)), st.double())
         (ref * cot.double()).sum().backward()
-        want = [x.grad.clone(), b.grad.clone(), nw.grad.clone()]
+        want = [x.grad.clone(), b.grad.clone(), nw.grad.clone(), st.grad.clone()]
+        st = st.detach()
 
         outs = []
-        for fused in (True, False):
-            xg, bg, nwg = (gpu(v).requires_grad_(True) for v in (x, b, nw))
-            y = ops.bias_act(xg, bg, nz.cuda(), nwg, act='lrelu', blur=blur, stats_eps=1e-8 if fused else None)
-            y, stats = y if fused else (y, None)
-            if fused:
-                assert (stats is not None) == (h * w >= ops.STATS_MIN_PLANE and (h * w) % 4 == 0)
-            o = ops.instnorm_style(y, st.cuda(), 1e-8, stats)
+        for variant in ('stats', 'separate', 'tail'):
+            xg, bg, nwg, sg = (gpu(v).requires_grad_(True) for v in (x, b, nw, st))
+            if variant == 'tail':       # the whole layer tail as one autograd node (fused backward as well)
+                o = ops.layer_tail(xg, bg, nz.cuda(), nwg, sg, act='lrelu', blur=blur, eps=1e-8)
+            else:
+                fused = variant == 'stats'
+                y = ops.bias_act(xg, bg, nz.cuda(), nwg, act='lrelu', blur=blur, stats_eps=1e-8 if fused else None)
+                y, stats = y if fused else (y, None)
+                if fused:
+                    assert (stats is not None) == (h * w >= ops.STATS_MIN_PLANE and (h * w) % 4 == 0)
+                o = ops.instnorm_style(y, sg, 1e-8, stats)
             (o * cot.cuda()).sum().backward()
-            outs.append((o.detach(), xg.grad, bg.grad, nwg.grad))
-        f, s = outs
+            outs.append((o.detach(), xg.grad, bg.grad, nwg.grad, sg.grad))
+        s = outs[1]
         tol = TOL if std == 1.0 else 2e-3
-        assert_close(f[0], ref.float(), tol, f'fused-stats fwd {shape} blur={blur} std={std}')
-        assert_close(f[0], s[0], 1e-6, f'fused vs separate statistics {shape} blur={blur} std={std}')
-        for got, sep, w_, name in zip(f[1:], s[1:], want, ('dx', 'dbias', 'dnoise_w')):
-            if name == 'dbias' and std != 1.0:
-                continue     # all-positive planes: a channel shift in front of the IN has an exactly zero gradient
-            assert_close(got, w_.float(), tol, f'fused-stats {name} {shape} blur={blur} std={std}')
-            assert_close(got, sep, 1e-5, f'fused vs separate {name} {shape} blur={blur} std={std}')
+        for f, tag in ((outs[0], 'fused-stats'), (outs[2], 'layer-tail')):
+            assert_close(f[0], ref.float(), tol, f'{tag} fwd {shape} blur={blur} std={std}')
+            assert_close(f[0], s[0], 1e-6, f'{tag} vs separate statistics {shape} blur={blur} std={std}')
+            for got, sep, w_, name in zip(f[1:], s[1:], want, ('dx', 'dbias', 'dnoise_w', 'dstyle')):
+                if name == 'dbias' and std != 1.0:
+                    continue     # all-positive planes: a channel shift in front of the IN has an exactly zero gradient
+                assert_close(got, w_.float(), tol, f'{tag} {name} {shape} blur={blur} std={std}')
+                assert_close(got, sep, 1e-5, f'{tag} vs separate {name} {shape} blur={blur} std={std}')
