@@ -1274,7 +1274,17 @@ struct PwArgs {
   long long hw4;      // float4 per plane
   float bias_scale, slope;
   int act;
+  // LeakyReLU derivative folded into the "many" side: factor 1 where mask > 0 else mslope.  few_to_many multiplies its
+  // OUTPUT (mask: N x Cout planes), many_to_few its INPUT (mask: N x Cin planes) - the fromRGB activation's backward
+  const float* mask;
+  float mslope;
 };
+
+__device__ __forceinline__ float4 pw_masked(float4 v, float4 m, float sl) {
+  v.x = m.x > 0.f ? v.x : v.x * sl; v.y = m.y > 0.f ? v.y : v.y * sl;
+  v.z = m.z > 0.f ? v.z : v.z * sl; v.w = m.w > 0.f ? v.w : v.w * sl;
+  return v;
+}
 
 __global__ __launch_bounds__(256) void pw_few_to_many_kernel(PwArgs p) {
   const long long total = (long long)p.N * p.hw4;
@@ -1296,6 +1306,8 @@ __global__ __launch_bounds__(256) void pw_few_to_many_kernel(PwArgs p) {
       if (p.act == GANLAB_ACT_LRELU) {
         a.x = gl_lrelu(a.x, p.slope); a.y = gl_lrelu(a.y, p.slope); a.z = gl_lrelu(a.z, p.slope); a.w = gl_lrelu(a.w, p.slope);
       }
+      if (p.mask != nullptr)
+        a = pw_masked(a, (reinterpret_cast<const float4*>(p.mask) + n * p.Cout * p.hw4 + q)[(long long)co * p.hw4], p.mslope);
       yb[(long long)co * p.hw4] = a;
     }
   }
@@ -1312,8 +1324,10 @@ __global__ __launch_bounds__(256) void pw_many_to_few_kernel(PwArgs p) {
       const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
       a[co] = float4{b, b, b, b};
     }
+    const float4* mb = p.mask != nullptr ? reinterpret_cast<const float4*>(p.mask) + n * p.Cin * p.hw4 + q : nullptr;
     for (int ci = 0; ci < p.Cin; ++ci) {
-      const float4 v = xb[(long long)ci * p.hw4];
+      float4 v = xb[(long long)ci * p.hw4];
+      if (mb != nullptr) v = pw_masked(v, mb[(long long)ci * p.hw4], p.mslope);
 #pragma unroll
       for (int co = 0; co < 4; ++co) {
         const float w = co < p.Cout ? p.wp[(long long)ci * p.Cout_p + co] : 0.f;
@@ -1334,9 +1348,13 @@ __global__ __launch_bounds__(256) void pw_many_to_few_kernel(PwArgs p) {
 }
 
 // part[blk][b][s]: b < B (<= 16 per launch: block of the "big" tensor's channels b0 .. b0+15), s < 4
+// mask (shape of big): big is multiplied by the LeakyReLU derivative of mask on load; ones: column s = S of the small
+// tensor is taken as 1, so acc[b][S] = sum_px big[b] (the bias gradient of fromRGB comes out of the same pass)
 __global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restrict__ big, const float* __restrict__ small,
                                                             float* __restrict__ part, int N, int B, int b0, int S,
-                                                            long long hw4, int Btot) {
+                                                            long long hw4, int Btot,
+                                                            const float* __restrict__ mask = nullptr, float mslope = 1.f,
+                                                            int ones = 0) {
   __shared__ float red[4][64];
   float acc[16][4];
 #pragma unroll
@@ -1350,10 +1368,19 @@ __global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restr
     const float4* bb = reinterpret_cast<const float4*>(big) + (n * Btot + b0) * hw4 + q;
     float4 sv[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) sv[s] = s < S ? sb[(long long)s * hw4] : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 4; ++s) {
+      const float f = (ones && s == S) ? 1.f : 0.f;
+      sv[s] = s < S ? sb[(long long)s * hw4] : float4{f, f, f, f};
+    }
     float4 bv[16];        // all loads first (independent, in flight together), then the multiply-adds
 #pragma unroll
     for (int b = 0; b < 16; ++b) bv[b] = b < B ? bb[(long long)b * hw4] : float4{0.f, 0.f, 0.f, 0.f};
+    if (mask != nullptr) {
+      const float4* mk = reinterpret_cast<const float4*>(mask) + (n * Btot + b0) * hw4 + q;
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        if (b < B) bv[b] = pw_masked(bv[b], mk[(long long)b * hw4], mslope);
+    }
 #pragma unroll
     for (int b = 0; b < 16; ++b)
 #pragma unroll
@@ -1376,7 +1403,8 @@ __global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restr
 
 // gw[co][ci] (OIHW, 1x1) = scale * sum_blk part[blk][b][s];  big_is_out: (b, s) = (co - b0, ci) else (ci - b0, co)
 __global__ void pw_cross_finish_kernel(const float* __restrict__ part, float* __restrict__ gw, int blocks, int B, int b0,
-                                       int S, int Cout, int Cin, int big_is_out, float scale) {
+                                       int S, int Cout, int Cin, int big_is_out, float scale,
+                                       float* __restrict__ gb = nullptr, float bias_scale = 1.f) {
   __shared__ float red[16][64];
   const int t = threadIdx.x & 63, j = threadIdx.x >> 6;       // t = b * 4 + s; 16 groups of 64 threads split the blocks
   float s0 = 0.f, s1 = 0.f;
@@ -1390,10 +1418,15 @@ __global__ void pw_cross_finish_kernel(const float* __restrict__ part, float* __
   __syncthreads();
   if (j != 0) return;
   const int b = t >> 2, s = t & 3;
-  if (b >= B || s >= S) return;
+  const bool is_bias = gb != nullptr && s == S;                // the "ones" column of pw_cross_sums_kernel
+  if (b >= B || (s >= S && !is_bias)) return;
   float sum = 0.f;
 #pragma unroll
   for (int g = 0; g < 16; ++g) sum += red[g][t];               // fixed order: deterministic
+  if (is_bias) {
+    gb[b0 + b] = sum * bias_scale;
+    return;
+  }
   const int co = big_is_out ? b0 + b : s, ci = big_is_out ? s : b0 + b;
   gw[(long long)co * Cin + ci] = sum * scale;
 }
@@ -1405,7 +1438,8 @@ inline bool pw_small_ok(int Cin, int Cout, int ks, int pad, int up, int Hi, int 
 }
 
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,
-             int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st) {
+             int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st,
+             const float* pw_mask = nullptr, float pw_mslope = 1.f) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
   ConvArgs a{};
   a.in = make_patch(x, N, Cin, Hi, Wi, pad, up);
@@ -1422,12 +1456,14 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
     q.N = N; q.Cin = Cin; q.Cout = Cout; q.Cout_p = a.Cout_p;
     q.hw4 = (long long)Hi * Wi / 4;
     q.bias_scale = bias_scale; q.slope = slope; q.act = act;
+    q.mask = pw_mask; q.mslope = pw_mslope;
     const long long items = (long long)N * q.hw4;
     const unsigned blocks = (unsigned)((items + 255) / 256 < 256 * 16 ? (items + 255) / 256 : 256 * 16);
     if (Cin <= 4) GL_LAUNCH(pw_few_to_many_kernel, dim3(blocks), dim3(256), 0, st, q);
     else GL_LAUNCH(pw_many_to_few_kernel, dim3(blocks), dim3(256), 0, st, q);
     return GL_CHECK_LAUNCH();
   }
+  if (pw_mask != nullptr) return GANLAB_EUNSUPPORTED;             // only the streaming 1x1 kernels fold the mask in
   if (ks == 1) return dispatch_co<1>(a, st);
   if (ks == 3) return dispatch_co<3>(a, st);
   return GANLAB_EINVAL;
@@ -1602,6 +1638,57 @@ int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual, c
   // padding ks-1-pad, producing the gradient w.r.t. the virtual (possibly upsampled) input
   return run_conv(gy, wp, nullptr, gx_virtual, g->N, g->Cout, ho, wo, g->Cin, g->ks, g->ks - 1 - g->pad, 0, 0.f,
                   GANLAB_ACT_NONE, 0.f, gl_stream(stream));
+}
+
+/* 1 when the conv's LeakyReLU backward can be folded into its own dgrad / wgrad kernels (the HBM-streaming 1x1
+ * few-channel kernels: fromRGB at >= 64x64) */
+int ganlab_conv_act_bwd_fused_supported(const ganlab_conv_geom* g) {
+  if (!geom_ok(g)) return 0;
+  const void* al = reinterpret_cast<const void*>(uintptr_t(16));
+  return (g->Cin <= 3 && pw_small_ok(g->Cin, g->Cout, g->ks, g->pad, g->up, g->Hin, g->Win, al, al)) ? 1 : 0;
+}
+
+/* gx = dgrad(gy * lrelu'(y), w): y is the conv's activated output */
+int ganlab_conv_dgrad_act_f32(const float* gy, const float* y, const float* wp, float* gx, const ganlab_conv_geom* g,
+                              float slope, void* stream) {
+  if (!gy || !y || !wp || !gx) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || !aligned16(gy) || !aligned16(y) || !aligned16(gx))
+    return GANLAB_EUNSUPPORTED;
+  return run_conv(gy, wp, nullptr, gx, g->N, g->Cout, g->Hin, g->Win, g->Cin, 1, 0, 0, 0.f, GANLAB_ACT_NONE, 0.f,
+                  gl_stream(stream), y, slope);
+}
+
+/* out = conv(x, w) * lrelu'(y)   (the adjoint of ganlab_conv_dgrad_act_f32 w.r.t. gy: R1's second-order sweep) */
+int ganlab_conv_fwd_mask_f32(const float* x, const float* wp, const float* y, float* out, const ganlab_conv_geom* g,
+                             float slope, void* stream) {
+  if (!x || !y || !wp || !out) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || !aligned16(x) || !aligned16(y) || !aligned16(out))
+    return GANLAB_EUNSUPPORTED;
+  return run_conv(x, wp, nullptr, out, g->N, g->Cin, g->Hin, g->Win, g->Cout, 1, 0, 0, 0.f, GANLAB_ACT_NONE, 0.f,
+                  gl_stream(stream), y, slope);
+}
+
+/* gw = scale * wgrad(gy * lrelu'(y), x),  gb = bias_scale * sum(gy * lrelu'(y)) (or NULL) in one pass;
+ * workspace: ganlab_conv_wgrad_workspace(g) bytes */
+int ganlab_conv_wgrad_act_f32(const float* gy, const float* y, const float* x, float* gw, float* gb,
+                              const ganlab_conv_geom* g, float scale, float bias_scale, float slope, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!gy || !y || !x || !gw) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || !aligned16(gy) || !aligned16(y) || !aligned16(x))
+    return GANLAB_EUNSUPPORTED;
+  long long blocks = (long long)(workspace_bytes / (64 * sizeof(float)));
+  if (blocks > 1024) blocks = 1024;
+  if (!workspace || blocks < 64) return GANLAB_EWORKSPACE;
+  const long long hw4 = (long long)g->Hin * g->Win / 4;
+  hipStream_t st = gl_stream(stream);
+  for (int b0 = 0; b0 < g->Cout; b0 += 16) {
+    const int B = g->Cout - b0 < 16 ? g->Cout - b0 : 16;
+    GL_LAUNCH(pw_cross_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gy, x, (float*)workspace, g->N, B, b0,
+              g->Cin, hw4, g->Cout, y, slope, gb ? 1 : 0);
+    GL_LAUNCH(pw_cross_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, gw, (int)blocks, B, b0,
+              g->Cin, g->Cout, g->Cin, 1, scale, gb, bias_scale);
+  }
+  return GL_CHECK_LAUNCH();
 }
 
 size_t ganlab_conv_wgrad_workspace(const ganlab_conv_geom* g) {

@@ -270,6 +270,41 @@ def k_conv_dgrad(gy, w, g, scale):
     return gxv
 
 
+def conv_act_bwd_fusable(g):
+    """The conv's LeakyReLU backward folds into its own gradient kernels (fromRGB at >= 64x64, fp32)."""
+    return g.bf is None and not g.s2 and bool(_lib.lib().ganlab_conv_act_bwd_fused_supported(g.ref()))
+
+
+def k_conv_dgrad_act(gy, y, w, g, scale, slope):
+    gy, y, w = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(w, 'conv weight')
+    assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape
+    gx = _new(g.in_shape, gy)
+    check(_lib.lib().ganlab_conv_dgrad_act_f32(_p(gy), _p(y), _p(_packed(w, PACK_DGRAD, scale)), _p(gx), g.ref(), slope,
+                                               _st()), 'conv_dgrad_act')
+    return gx
+
+
+def k_conv_fwd_mask(x, w, y, g, scale, slope):
+    x, y, w = _c(x, 'conv input'), _c(y, 'conv output'), _c(w, 'conv weight')
+    assert tuple(x.shape) == g.in_shape and tuple(y.shape) == g.out_shape
+    out = torch.empty_like(y)
+    check(_lib.lib().ganlab_conv_fwd_mask_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), _p(y), _p(out), g.ref(), slope,
+                                              _st()), 'conv_fwd_mask')
+    return out
+
+
+def k_conv_wgrad_act(gy, y, x, g, scale, slope, bias_scale, want_gb):
+    gy, y, x = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(x, 'conv input')
+    assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    L = _lib.lib()
+    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
+    gb = _new((g.Cout,), x) if want_gb else None
+    ws = torch.empty((max(L.ganlab_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    check(L.ganlab_conv_wgrad_act_f32(_p(gy), _p(y), _p(x), _p(gw), _p(gb), g.ref(), scale, bias_scale, slope, _p(ws),
+                                      ws.numel() * 4, _st()), 'conv_wgrad_act')
+    return gw, gb
+
+
 def k_conv_wgrad(gy, x, g, scale):
     gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
@@ -588,6 +623,66 @@ class _ConvWgrad(Function):
         return d_gy, d_x, None, None
 
 
+# The three maps below fold m = lrelu'(y) (y: the conv's activated output, a constant of all of them) into the conv
+# gradient kernels; they are each other's derivatives, so R1 / WGAN-GP second-order sweeps stay on fused kernels.
+class _ConvDgradAct(Function):
+    """gx = dgrad(gy * m, w)."""
+
+    @staticmethod
+    def forward(ctx, gy, y, w, g, s, slope):
+        ctx.save_for_backward(gy, y, w)
+        ctx.g, ctx.s, ctx.slope = g, s, slope
+        return k_conv_dgrad_act(gy, y, w, g, s, slope)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, y, w = ctx.saved_tensors
+        d_gy = _ConvFwdMask.apply(ggx, w, y, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgradAct.apply(gy, y, ggx, ctx.g, ctx.s, ctx.slope, 1.0, False)[0] if ctx.needs_input_grad[2] \
+            else None
+        return d_gy, None, d_w, None, None, None
+
+
+class _ConvFwdMask(Function):
+    """out = conv(x, w) * m."""
+
+    @staticmethod
+    def forward(ctx, x, w, y, g, s, slope):
+        ctx.save_for_backward(x, w, y)
+        ctx.g, ctx.s, ctx.slope = g, s, slope
+        return k_conv_fwd_mask(x, w, y, g, s, slope)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w, y = ctx.saved_tensors
+        d_x = _ConvDgradAct.apply(go, y, w, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgradAct.apply(go, y, x, ctx.g, ctx.s, ctx.slope, 1.0, False)[0] if ctx.needs_input_grad[1] else None
+        return d_x, d_w, None, None, None, None
+
+
+class _ConvWgradAct(Function):
+    """(gw, gb) = (wgrad(gy * m, x), bias_scale * sum(gy * m))."""
+
+    @staticmethod
+    def forward(ctx, gy, y, x, g, s, slope, bias_scale, want_gb):
+        ctx.save_for_backward(gy, y, x)
+        ctx.g, ctx.s, ctx.slope = g, s, slope
+        gw, gb = k_conv_wgrad_act(gy, y, x, g, s, slope, bias_scale, want_gb)
+        if gb is None:
+            gb = gw.new_zeros(())
+            ctx.mark_non_differentiable(gb)
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, ggw, ggb):
+        if ggb is not None and ggb.numel() > 1 and bool(ggb.ne(0).any()):
+            raise NotImplementedError('second derivative through the fused fromRGB bias gradient')
+        gy, y, x = ctx.saved_tensors
+        d_gy = _ConvFwdMask.apply(x, ggw, y, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
+        d_x = _ConvDgradAct.apply(gy, y, ggw, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[2] else None
+        return d_gy, None, d_x, None, None, None, None, None
+
+
 class _ActBwd(Function):
     """gz = gy * lrelu'(y) from the saved OUTPUT y (sign(y) == sign(pre-activation))."""
 
@@ -740,6 +835,14 @@ class _ConvBiasAct(Function):
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[2] and params
         gb = None
+        if ctx.act != ACT_NONE and not ctx.blur and conv_act_bwd_fusable(ctx.g):
+            # fromRGB: no separate  gz = gy * lrelu'(y)  pass - its gradient kernels take (gy, y)
+            gx = _ConvDgradAct.apply(gy, y, w, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
+            gw = None
+            if params and (ctx.needs_input_grad[1] or want_b):
+                gw, gb = _ConvWgradAct.apply(gy, y, x, ctx.g, ctx.s, ctx.slope, ctx.bias_scale, bool(want_b))
+            return gx, (gw if ctx.needs_input_grad[1] else None), (gb.view(ctx.bias_shape) if want_b else None), \
+                None, None, None, None, None, None
         if ctx.blur and ctx.act != ACT_NONE:
             gz, gb = _BlurActBwd.apply(gy, y, ctx.slope, ctx.bias_scale, bool(want_b))
         else:

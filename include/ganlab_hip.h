@@ -72,6 +72,21 @@ int ganlab_conv_fwd_f32(const float* x, const float* wp, const float* bias, floa
 int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual,
                           const ganlab_conv_geom* g, void* stream);
 
+/* fromRGB (1x1 conv from <= 3 channels + bias + LeakyReLU, progan/architectures.py:232-237) at >= 64x64 runs on
+ * HBM-streaming kernels that can fold the activation's backward into the conv's own gradient kernels, saving the
+ * separate  gz = gy * lrelu'(y)  pass over the widest tensor of the discriminator:
+ *   dgrad_act : gx = dgrad(gy * lrelu'(y), w)             fwd_mask : out = conv(x, w) * lrelu'(y)  (its adjoint)
+ *   wgrad_act : gw = scale * wgrad(gy * lrelu'(y), x) and gb = bias_scale * sum(gy * lrelu'(y))
+ * y is the conv's activated OUTPUT.  *_supported() == 0 -> GANLAB_EUNSUPPORTED, compose the plain entry points. */
+int ganlab_conv_act_bwd_fused_supported(const ganlab_conv_geom* g);
+int ganlab_conv_dgrad_act_f32(const float* gy, const float* y, const float* wp, float* gx, const ganlab_conv_geom* g,
+                              float slope, void* stream);
+int ganlab_conv_fwd_mask_f32(const float* x, const float* wp, const float* y, float* out, const ganlab_conv_geom* g,
+                             float slope, void* stream);
+int ganlab_conv_wgrad_act_f32(const float* gy, const float* y, const float* x, float* gw, float* gb,
+                              const ganlab_conv_geom* g, float scale, float bias_scale, float slope, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* gw[co][ci][ky][kx] = scale * sum_{n,y,x} gy[n,co,y,x] * up2?(x)[n,ci,y+ky-pad,x+kx-pad].
  * Deterministic two-stage reduction through `workspace`; query the size with
  * ganlab_conv_wgrad_workspace (bytes). */

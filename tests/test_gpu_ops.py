@@ -579,3 +579,48 @@ def test_bias_act_with_fused_instnorm_statistics(ops, shape, blur):
                     continue     # all-positive planes: a channel shift in front of the IN has an exactly zero gradient
                 assert_close(got, w_.float(), tol, f'{tag} {name} {shape} blur={blur} std={std}')
                 assert_close(got, sep, 1e-5, f'{tag} vs separate {name} {shape} blur={blur} std={std}')
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 3, 16, 64, 64), (3, 3, 32, 64, 96), (1, 1, 8, 128, 64), (2, 3, 16, 32, 32)])
+def test_fromrgb_activation_backward_folded_into_gradient_kernels(ops, n, cin, cout, h, w):
+    """fromRGB (1x1 conv from the image + bias + LeakyReLU, progan/architectures.py:232-237): at >= 64x64 its backward
+    takes (gy, y) straight into the dgrad / wgrad kernels (no separate gy * lrelu'(y) pass) and the bias gradient comes
+    out of the weight-gradient pass.  First order against float64, and the R1-shaped second order (d/dw, d/dw2 of
+    ||d out / d image||^2); the last case is below the streaming kernels' size and takes the composed path."""
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((n, cin, cout, h, w)).encode()))
+    x = rnd(gen, n, cin, h, w).requires_grad_(True)
+    w1 = rnd(gen, cout, cin, 1, 1).requires_grad_(True)
+    b1 = rnd(gen, cout).requires_grad_(True)
+    w2 = rnd(gen, 8, cout, 3, 3).requires_grad_(True)
+    cot = rnd(gen, n, cout, h, w)
+
+    def ref_net(x_, w1_, b1_):
+        return F.leaky_relu(F.conv2d(x_.double() * 0.5, w1_.double(), b1_.double() * 0.7), 0.2)
+
+    (ref_net(x, w1, b1) * cot.double()).sum().backward()
+    want1 = [t_.grad.clone() for t_ in (x, w1, b1)]
+    for t_ in (x, w1, b1):
+        t_.grad = None
+    out = F.conv2d(ref_net(x, w1, b1) * 0.2, w2.double(), None, padding=1)
+    g, = torch.autograd.grad(out.sum(), x, create_graph=True)
+    pen = (g ** 2).sum()
+    pen.backward()
+
+    xg, w1g, b1g, w2g = (gpu(t_).requires_grad_(True) for t_ in (x, w1, b1, w2))
+    from gan_lab_amd import ops as raw
+    geom_fused = h * w >= 4096
+    y = ops.conv2d(xg, w1g, b1g, scale=0.5, bias_scale=0.7, act='lrelu')
+    (y * cot.cuda()).sum().backward()
+    for got, want, name in zip((xg.grad, w1g.grad, b1g.grad), want1, ('dx', 'dw', 'dbias')):
+        assert_close(got, want.float(), 2e-5, f'fromRGB first order {name}')
+    xg.grad = w1g.grad = b1g.grad = None
+    hmid = ops.conv2d(xg, w1g, b1g, scale=0.5, bias_scale=0.7, act='lrelu')
+    assert bool(raw.conv_act_bwd_fusable(raw.Geom(n, cin, h, w, cout, 1, 0))) == geom_fused
+    outg = ops.conv2d(hmid, w2g, None, scale=0.2, padding=1)
+    gg, = torch.autograd.grad(ops.sum_all(outg), xg, create_graph=True)
+    assert_close(gg, g.float(), TOL, 'fromRGB R1 first-order grad')
+    peng = ops.sumsq_all(gg)
+    assert_close(peng, pen.float(), TOL, 'fromRGB R1 penalty')
+    peng.backward()
+    assert_close(w1g.grad, w1.grad, 5e-4, 'fromRGB R1 ggw1')
+    assert_close(w2g.grad, w2.grad, 5e-4, 'fromRGB R1 ggw2')
