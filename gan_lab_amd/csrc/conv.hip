@@ -305,6 +305,10 @@ struct ConvArgs {
   int strip, strips_x;   // each workgroup walks `strip` consecutive tiles along x
   float bias_scale, slope;
   int act;
+  // output mask (general kernel only): y *= (mask > 0 ? 1 : mslope), mask shaped like y.  The input gradient of a conv
+  // whose input is a LeakyReLU output comes out already multiplied by that LeakyReLU's derivative.
+  const float* mask;
+  float mslope;
 };
 
 template <int KS_, int MB_, int TWL_, int THL_, int NIL_, int XMODE_>
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
 
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
-template <class Cfg>
+template <class Cfg, bool MASK = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
@@ -911,6 +915,34 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
     const int co = co0 + mb * 16 + (lane & 15);
     bv[mb] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
   }
+  if constexpr (MASK && G::XMODE != XSCALAR) {   // (its own instantiation: the plain kernel's registers stay as they were)
+    {                              // all mask loads in flight together, then the stores
+      float4 mk[NB][MB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j0 = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
+        const int oy = oy0 + ((j0 >> G::TWL) & (TH - 1)), ox = ox0 + (j0 & (TW - 1));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int co = co0 + mb * 16 + (lane & 15);
+          mk[nb][mb] = (co < p.Cout && n0 < p.in.N && oy < p.Ho && ox < p.Wo)
+                           ? *reinterpret_cast<const float4*>(p.mask + ((long long)n0 * p.Cout + co) * out_plane +
+                                                              (long long)oy * p.Wo + ox)
+                           : float4{1.f, 1.f, 1.f, 1.f};
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float4 m = mk[nb][mb];
+          if (!(m.x > 0.f)) acc[mb][nb][0] *= p.mslope;
+          if (!(m.y > 0.f)) acc[mb][nb][1] *= p.mslope;
+          if (!(m.z > 0.f)) acc[mb][nb][2] *= p.mslope;
+          if (!(m.w > 0.f)) acc[mb][nb][3] *= p.mslope;
+        }
+    }
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int j0 = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
@@ -936,8 +968,9 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
           const int j = j0 + r;
           const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
           const int n = n0 + ni, oy = oy0 + ty, ox = ox0 + tx;
-          if (n < p.in.N && oy < p.Ho && ox < p.Wo)
+          if (n < p.in.N && oy < p.Ho && ox < p.Wo) {
             p.y[((long long)n * p.Cout + co) * out_plane + (long long)oy * p.Wo + ox] = v[r];
+          }
         }
       }
     }
@@ -1175,7 +1208,7 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
     const bool ok = a.Cin_p == Cfg::CI_T && a.Wo % G::TW == 0 && a.Ho % G::TH == 0 && a.Cout % Cfg::CO_T == 0 &&
                     (long long)a.in.Cin * a.in.Hi * a.in.Wi * 4 < 0x7fffffffLL &&
                     (long long)a.Cout * a.Ho * a.Wo * 4 < 0x7fffffffLL;
-    if (ok) {
+    if (ok && a.mask == nullptr) {             // (the strip / rolling kernels have no mask epilogue)
       int k = 1;                               // strips per tile row
       while (k < a.tiles_x && tiles / ceil_div(a.tiles_x, k) < 6144) ++k;
       a.strip = ceil_div(a.tiles_x, k);
@@ -1217,6 +1250,14 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
     }
   }
   if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+  if (a.mask != nullptr) {        // output mask: the 3x3 vector-staged kernels only (ganlab_conv_dgrad_mask_supported)
+    if constexpr (Cfg::KS == 3 && G::XMODE == XVEC) {
+      GL_LAUNCH((conv_fwd_kernel<Cfg, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+      return GL_CHECK_LAUNCH();
+    } else {
+      return GANLAB_EUNSUPPORTED;
+    }
+  }
   GL_LAUNCH(conv_fwd_kernel<Cfg>, dim3((unsigned)tiles), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
@@ -1439,7 +1480,7 @@ inline bool pw_small_ok(int Cin, int Cout, int ks, int pad, int up, int Hi, int 
 
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,
              int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st,
-             const float* pw_mask = nullptr, float pw_mslope = 1.f) {
+             const float* pw_mask = nullptr, float pw_mslope = 1.f, const float* out_mask = nullptr) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
   ConvArgs a{};
   a.in = make_patch(x, N, Cin, Hi, Wi, pad, up);
@@ -1450,7 +1491,8 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
   if ((long long)Cin * a.in.Hi * a.in.Wi * 16 >= 0x7fffffffLL) return GANLAB_EINVAL;  // int offsets per tile
   a.Cin_p = round_up_c(Cin, cin_pad(ks)); a.Cout_p = round_up_c(Cout, 64);
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
-  if (pw_small_ok(Cin, Cout, ks, pad, up, Hi, Wi, x, y)) {      // fromRGB / toRGB: HBM-bound streaming kernels
+  a.mask = out_mask; a.mslope = pw_mslope;
+  if (out_mask == nullptr && pw_small_ok(Cin, Cout, ks, pad, up, Hi, Wi, x, y)) {      // fromRGB / toRGB: HBM-bound streaming kernels
     PwArgs q{};
     q.x = x; q.wp = wp; q.bias = bias; q.y = y;
     q.N = N; q.Cin = Cin; q.Cout = Cout; q.Cout_p = a.Cout_p;
@@ -1638,6 +1680,23 @@ int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual, c
   // padding ks-1-pad, producing the gradient w.r.t. the virtual (possibly upsampled) input
   return run_conv(gy, wp, nullptr, gx_virtual, g->N, g->Cout, ho, wo, g->Cin, g->ks, g->ks - 1 - g->pad, 0, 0.f,
                   GANLAB_ACT_NONE, 0.f, gl_stream(stream));
+}
+
+/* gx = dgrad(gy, w) * lrelu'(x): x (the conv's INPUT, shaped like gx) is itself a LeakyReLU output, and its derivative
+ * is applied in the dgrad epilogue instead of a separate pass in the producing layer's backward.  Plain (no upsample,
+ * no pool) fp32 convs. */
+int ganlab_conv_dgrad_mask_supported(const ganlab_conv_geom* g) {
+  // 3x3 "same" convs on >= 16-wide, 4-aligned rows (the vector-staged kernels)
+  return (geom_ok(g) && g->ks == 3 && g->pad == 1 && !g->up && g->Win >= 16 && (g->Win & 3) == 0) ? 1 : 0;
+}
+
+int ganlab_conv_dgrad_mask_f32(const float* gy, const float* wp, const float* x, float* gx, const ganlab_conv_geom* g,
+                               float slope, void* stream) {
+  int ho, wo;
+  if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK || !x) return GANLAB_EINVAL;
+  if (!ganlab_conv_dgrad_mask_supported(g)) return GANLAB_EUNSUPPORTED;
+  return run_conv(gy, wp, nullptr, gx, g->N, g->Cout, ho, wo, g->Cin, g->ks, g->ks - 1 - g->pad, 0, 0.f,
+                  GANLAB_ACT_NONE, 0.f, gl_stream(stream), nullptr, slope, x);
 }
 
 /* 1 when the conv's LeakyReLU backward can be folded into its own dgrad / wgrad kernels (the HBM-streaming 1x1

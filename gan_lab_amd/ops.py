@@ -270,6 +270,20 @@ def k_conv_dgrad(gy, w, g, scale):
     return gxv
 
 
+def conv_dgrad_mask_ok(g):
+    """The conv's input gradient can come out multiplied by lrelu'(x) (x: its input, a LeakyReLU output)."""
+    return g.bf is None and not g.s2 and not g.up and bool(_lib.lib().ganlab_conv_dgrad_mask_supported(g.ref()))
+
+
+def k_conv_dgrad_mask(gy, w, x, g, scale, slope):
+    gy, w, x = _c(gy, 'conv grad_out'), _c(w, 'conv weight'), _c(x, 'conv input')
+    assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    gx = torch.empty_like(x)
+    check(_lib.lib().ganlab_conv_dgrad_mask_f32(_p(gy), _p(_packed(w, PACK_DGRAD, scale)), _p(x), _p(gx), g.ref(), slope,
+                                                _st()), 'conv_dgrad_mask')
+    return gx
+
+
 def conv_act_bwd_fusable(g):
     """The conv's LeakyReLU backward folds into its own gradient kernels (fromRGB at >= 64x64, fp32)."""
     return g.bf is None and not g.s2 and bool(_lib.lib().ganlab_conv_act_bwd_fused_supported(g.ref()))
@@ -608,6 +622,41 @@ class _ConvDgrad(Function):
         return d_gy, d_w, None, None
 
 
+class _ConvDgradMask(Function):
+    """gx = dgrad(gy, w) * lrelu'(x) in the dgrad kernel's epilogue: x, the conv's input, is the LeakyReLU output of the
+    layer in front, whose backward then receives the gradient of its PRE-activation (see ``conv2d(defer_act_grad=)``)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, x, g, s, slope):
+        ctx.save_for_backward(gy, w, x)
+        ctx.g, ctx.s, ctx.slope = g, s, slope
+        return k_conv_dgrad_mask(gy, w, x, g, s, slope)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w, x = ctx.saved_tensors
+        t = _ActBwd.apply(ggx, x, ctx.slope)
+        d_gy = _ConvFwd.apply(t, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgrad.apply(gy, t, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        return d_gy, d_w, None, None, None, None
+
+
+class _DeferredActGrad(Function):
+    """Identity whose backward applies lrelu'(x): the explicit form of what _ConvDgradMask folds into the dgrad kernel,
+    for consumers of a ``defer_act_grad`` tensor that cannot fold it in."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return _ActBwd.apply(g, x, ctx.slope), None
+
+
 class _ConvWgrad(Function):
     @staticmethod
     def forward(ctx, gy, x, g, s):
@@ -820,10 +869,14 @@ class _ConvBiasAct(Function):
     epilogue).  Reference: Conv2dEx.forward (+ nn.LeakyReLU) custom_layers.py:202-211."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False):
+    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False, defer=False, in_slope=None):
+        # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
+        # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer) else None)
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
+        ctx.defer, ctx.in_slope = bool(defer), in_slope
+        assert not (defer and blur)
         ctx.bias_shape = bias.shape if bias is not None else None
         # blur=True: the D block's  conv -> bias -> LeakyReLU -> blur  (progan/architectures.py:280-293);
         # forward is conv kernel + blur kernel, backward is ONE pass (blur^T, LeakyReLU', bias gradient)
@@ -835,29 +888,33 @@ class _ConvBiasAct(Function):
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[2] and params
         gb = None
-        if ctx.act != ACT_NONE and not ctx.blur and conv_act_bwd_fusable(ctx.g):
+        act = ACT_NONE if ctx.defer else ctx.act
+        if act != ACT_NONE and not ctx.blur and ctx.in_slope is None and conv_act_bwd_fusable(ctx.g):
             # fromRGB: no separate  gz = gy * lrelu'(y)  pass - its gradient kernels take (gy, y)
             gx = _ConvDgradAct.apply(gy, y, w, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
             gw = None
             if params and (ctx.needs_input_grad[1] or want_b):
                 gw, gb = _ConvWgradAct.apply(gy, y, x, ctx.g, ctx.s, ctx.slope, ctx.bias_scale, bool(want_b))
             return gx, (gw if ctx.needs_input_grad[1] else None), (gb.view(ctx.bias_shape) if want_b else None), \
-                None, None, None, None, None, None
-        if ctx.blur and ctx.act != ACT_NONE:
+                None, None, None, None, None, None, None, None
+        if ctx.blur and act != ACT_NONE:
             gz, gb = _BlurActBwd.apply(gy, y, ctx.slope, ctx.bias_scale, bool(want_b))
         else:
             if ctx.blur:
                 gy = _Blur.apply(gy)
-            if ctx.act != ACT_NONE and want_b:
+            if act != ACT_NONE and want_b:
                 gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
             else:
-                gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
+                gz = _ActBwd.apply(gy, y, ctx.slope) if act != ACT_NONE else gy
                 if want_b:
                     gb = _ChanSum.apply(gz, None, ctx.bias_scale)
-        gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.in_slope is None else \
+                _ConvDgradMask.apply(gz, w, x, ctx.g, ctx.s, ctx.in_slope)
         gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and params) else None
         return gx, gw, (gb.view(ctx.bias_shape) if want_b and gb is not None else None), None, None, None, None, \
-            None, None
+            None, None, None, None
 
 
 class _BiasAct(Function):
@@ -1498,24 +1555,37 @@ class _ChNormPenalty(Function):
 # ---------------------------------------------------------------------------------------------- #
 # functional API
 # ---------------------------------------------------------------------------------------------- #
+ACT_DEFERRED = '_ganlab_act_deferred'    # attribute on a conv2d(defer_act_grad=True) result that really deferred
+
+
 def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False,
-           blur=False):
+           blur=False, defer_act_grad=False, in_act_slope=None):
     """blur?(act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale)) on the matrix cores.
     ``pool``: the D down layer conv -> AvgPool2d(2) -> +bias -> LeakyReLU (progan/architectures.py:261-284)
     as one stride-2 kernel when the shape qualifies, else composed from the plain kernels.
     ``blur``: the binomial blur that follows conv+bias+LeakyReLU in a D block; its backward is fused with
-    the LeakyReLU / bias backward."""
+    the LeakyReLU / bias backward.
+    ``defer_act_grad`` / ``in_act_slope``: a pair of layers A -> B where B is a conv and the ONLY reader of A's
+    LeakyReLU output (D block k's pooled conv -> block k+1's first conv).  A(defer_act_grad=True) may leave the
+    multiplication by lrelu'(y_A) to B; when it does its result carries the attribute ``ACT_DEFERRED`` and the caller
+    MUST run B with in_act_slope=<A's slope> - B's dgrad epilogue (or an explicit pass) then applies it."""
     n, cin, h, w = x.shape
     cout, cin_w, ks, _ = weight.shape
+    if in_act_slope is not None:
+        in_act_slope = float(in_act_slope)
+        fold = not up and not pool and ks == 3 and (bias is not None or act == 'lrelu') and \
+            conv_dgrad_mask_ok(Geom(n, cin, h, w, cout, ks, padding, 0, 0))
+        if not fold:
+            x, in_act_slope = _DeferredActGrad.apply(x, in_act_slope), None
     if blur:
         y = None
         if not pool and not up and ks in (1, 3) and act == 'lrelu':
             g = Geom(n, cin, h, w, cout, ks, padding, 0, 0)
             if _lib.lib().ganlab_blur_fused_supported(g.Ho, g.Wo):
                 y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), ACT_LRELU, float(slope),
-                                       True)
+                                       True, False, in_act_slope)
         return y if y is not None else _Blur.apply(conv2d(x, weight, bias, scale, padding, up, bias_scale, act, slope,
-                                                          pool))
+                                                          pool, in_act_slope=in_act_slope))
     if pool and not (not up and pool_fusable(n, cin, h, w, cout, ks, padding)):
         y = avg_pool2(conv2d(x, weight, None, scale, padding, up))
         return bias_act(y, bias, bias_scale=bias_scale, act=act, slope=slope)
@@ -1526,8 +1596,14 @@ def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0,
     g = Geom(n, cin, h, w, cout, ks, padding, up, pool)
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
     if bias is None and a == ACT_NONE:
+        assert in_act_slope is None
         return _ConvFwd.apply(x, weight, g, float(scale))
-    return _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), a, float(slope))
+    defer = bool(defer_act_grad) and a == ACT_LRELU and not conv_act_bwd_fusable(g)
+    y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), a, float(slope), False, defer,
+                           in_act_slope)
+    if defer:
+        setattr(y, ACT_DEFERRED, True)
+    return y
 
 
 def linear(x, weight, bias=None, scale=1.0, bias_scale=1.0, act=None, slope=0.2):

@@ -164,13 +164,15 @@ class _DiscriminatorBody(object):
 
     def forward(self, x):
         x = x.view(-1, FMAP_SAMPLES + self.num_classes, self.curr_res, self.curr_res)
-        h = fused_sequential([self.disc_blocks[0]], fused_sequential([self.fromrgb], x))
+        h = fused_sequential([self.fromrgb], x)
+        rest = list(self.disc_blocks)
         if self.fade_in_phase:
+            h = fused_sequential([rest.pop(0)], h)
             skip = fused_sequential([self.prev_fromrgb], ops.avg_pool2(x))
             h = ops.lerp(skip, h, self.alpha)                                        # (:311-313)
-        for disc_block in self.disc_blocks[1:]:
-            h = fused_sequential([disc_block], h)
-        return h.view(-1)
+        # all blocks as ONE sequence: where block k's last LeakyReLU feeds block k+1's first conv directly, that conv's
+        # input-gradient kernel applies the LeakyReLU derivative (fused_sequential)
+        return fused_sequential(rest, h).view(-1)
 
 
 class ProDiscriminator(_DiscriminatorBody, ProGAN):

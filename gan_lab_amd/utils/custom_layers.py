@@ -208,7 +208,8 @@ class Conv2dEx(nn.Module):
         s = self.wscale if (self.equalized_lr and self.wscale is not None) else 1.0
         return s * (self.lrmul if self.use_lrmul else 1.0)
 
-    def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None, blur=False):
+    def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None, blur=False, defer_act_grad=False,
+                in_act_slope=None):
         # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
         # pool / bias_mod: the D down layer  conv -> AvgPool2d -> Conv2dBias -> LeakyReLU  as one kernel
         bias, bias_scale = self.conv2d.bias, (self.lrmul if self.use_lrmul else 1.0)
@@ -216,7 +217,8 @@ class Conv2dEx(nn.Module):
             assert bias is None
             bias, bias_scale = bias_mod.bias, (bias_mod.lrmul if bias_mod.use_lrmul else 1.0)
         return ops.conv2d(x, self.conv2d.weight, bias, scale=self.scale, padding=self.padding, up=up,
-                          bias_scale=bias_scale, act=act, slope=slope, pool=pool, blur=blur)
+                          bias_scale=bias_scale, act=act, slope=slope, pool=pool, blur=blur,
+                          defer_act_grad=defer_act_grad, in_act_slope=in_act_slope)
 
 
 class Conv2dBias(nn.Module):
@@ -283,6 +285,13 @@ class LinearBias(nn.Module):
 
 
 # -- peephole executor ------------------------------------------------------------------------------ #
+def _folds_act_grad(conv, after, width):
+    """``conv`` (fed a ``width``-wide map, followed by ``after``) applies the previous layer's LeakyReLU derivative in
+    its dgrad epilogue: a plain 3x3 'same' conv (no pooling behind it) on the fp32 kernels, rows of >= 16 pixels."""
+    return isinstance(conv, Conv2dEx) and not isinstance(after, AvgPool2x) and conv.conv2d.kernel_size == (3, 3) and \
+        conv.padding == 1 and width >= 16 and width % 4 == 0 and ops.get_compute_dtype() == 'f32'
+
+
 def fused_sequential(mods, x):
     """Run a list of modules with kernel fusion where the pattern allows:
          Upsample2x, Conv2dEx                      -> stride-2 transposed kernel (upsample folded in)
@@ -307,6 +316,7 @@ def fused_sequential(mods, x):
     for m in mods:
         add(m)
     i, n = 0, len(flat)
+    pending_slope = None     # the previous conv left its LeakyReLU derivative to the conv that comes next
     while i < n:
         m = flat[i]
         up = False
@@ -323,6 +333,7 @@ def fused_sequential(mods, x):
             if isinstance(nxt, LeakyReLU):
                 kw.update(act='lrelu', slope=nxt.negative_slope)
                 i += 1
+            assert pending_slope is None
             x = m(x, **kw)
         elif isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
             kw = {}
@@ -345,8 +356,22 @@ def fused_sequential(mods, x):
                     i += 1
             if up:
                 kw['up'] = True
+            if isinstance(m, Conv2dEx):
+                if pending_slope is not None:
+                    kw['in_act_slope'] = pending_slope
+                # conv + LeakyReLU feeding the next conv directly (D block k -> block k+1): that conv's dgrad epilogue
+                # applies this LeakyReLU's derivative, saving the separate pass over this layer's output gradient
+                if 'act' in kw and 'blur' not in kw and not up and i + 1 < n and \
+                        _folds_act_grad(flat[i + 1], flat[i + 2] if i + 2 < n else None,
+                                        x.shape[-1] // (2 if 'pool' in kw else 1)):
+                    kw['defer_act_grad'] = True
+            else:
+                assert pending_slope is None
             x = m(x, **kw)
+            pending_slope = kw['slope'] if getattr(x, ops.ACT_DEFERRED, False) else None
         else:
+            assert pending_slope is None
             x = m(x)
         i += 1
+    assert pending_slope is None
     return x

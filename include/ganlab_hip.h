@@ -72,6 +72,14 @@ int ganlab_conv_fwd_f32(const float* x, const float* wp, const float* bias, floa
 int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual,
                           const ganlab_conv_geom* g, void* stream);
 
+/* gx = dgrad(gy, w) * lrelu'(x) where x, the conv's input (shaped like gx), is the LeakyReLU output of the layer in
+ * front (D block k's pooled conv -> block k+1's first conv, progan/architectures.py:280-293): that layer's backward then
+ * takes gx as the gradient of its PRE-activation and skips its own gy * lrelu'(y) pass.  3x3 pad-1 convs, no
+ * upsample, rows of >= 16 4-aligned pixels (*_supported). */
+int ganlab_conv_dgrad_mask_supported(const ganlab_conv_geom* g);
+int ganlab_conv_dgrad_mask_f32(const float* gy, const float* wp, const float* x, float* gx, const ganlab_conv_geom* g,
+                               float slope, void* stream);
+
 /* fromRGB (1x1 conv from <= 3 channels + bias + LeakyReLU, progan/architectures.py:232-237) at >= 64x64 runs on
  * HBM-streaming kernels that can fold the activation's backward into the conv's own gradient kernels, saving the
  * separate  gz = gy * lrelu'(y)  pass over the widest tensor of the discriminator:

@@ -624,3 +624,53 @@ def test_fromrgb_activation_backward_folded_into_gradient_kernels(ops, n, cin, c
     peng.backward()
     assert_close(w1g.grad, w1.grad, 5e-4, 'fromRGB R1 ggw1')
     assert_close(w2g.grad, w2.grad, 5e-4, 'fromRGB R1 ggw2')
+
+
+@pytest.mark.parametrize('blur', [True, False])
+def test_activation_gradient_deferred_to_next_conv(ops, blur):
+    """D block k's pooled conv + LeakyReLU feeding block k+1's first conv (progan/architectures.py:280-293): the first
+    layer leaves the multiplication by lrelu'(y) to the second one's input-gradient kernel (epilogue mask).  Gradients of
+    every input, first order and R1-shaped second order, against float64 autograd of the plain composition."""
+    gen = torch.Generator().manual_seed(77 + int(blur))
+    x = rnd(gen, 2, 16, 64, 64).requires_grad_(True)
+    wa, ba = rnd(gen, 32, 16, 3, 3).requires_grad_(True), rnd(gen, 1, 32, 1, 1).requires_grad_(True)
+    wb, bb = rnd(gen, 32, 32, 3, 3).requires_grad_(True), rnd(gen, 32).requires_grad_(True)
+    wc = rnd(gen, 8, 32, 3, 3).requires_grad_(True)
+    leaves = (x, wa, ba, wb, bb, wc)
+
+    def ref(x_):
+        a = F.leaky_relu(F.avg_pool2d(F.conv2d(x_.double() * 0.3, wa.double(), None, padding=1), 2) + ba.double(), 0.2)
+        b = F.leaky_relu(F.conv2d(a * 0.2, wb.double(), bb.double(), padding=1), 0.2)
+        if blur:
+            b = _blur_ref(b)
+        return F.conv2d(b * 0.1, wc.double(), None, padding=1)
+
+    def hip(xg, wag, bag, wbg, bbg, wcg):
+        a = ops.conv2d(xg, wag, bag, scale=0.3, padding=1, act='lrelu', pool=True, defer_act_grad=True)
+        assert getattr(a, ops.ACT_DEFERRED, False), 'the pooled conv should have deferred its activation gradient'
+        b = ops.conv2d(a, wbg, bbg, scale=0.2, padding=1, act='lrelu', blur=blur, in_act_slope=0.2)
+        return ops.conv2d(b, wcg, None, scale=0.1, padding=1)
+
+    cot = rnd(gen, 2, 8, 32, 32)
+    (ref(x) * cot.double()).sum().backward()
+    want = [t_.grad.clone() for t_ in leaves]
+    for t_ in leaves:
+        t_.grad = None
+    dev = [gpu(t_).requires_grad_(True) for t_ in leaves]
+    (hip(*dev) * cot.cuda()).sum().backward()
+    for got, w_, name in zip(dev, want, ('dx', 'dwa', 'dba', 'dwb', 'dbb', 'dwc')):
+        assert_close(got.grad, w_.float(), 5e-5, f'deferred act grad, first order {name}')
+
+    g, = torch.autograd.grad(ref(x).sum(), x, create_graph=True)
+    pen = (g ** 2).sum()
+    pen.backward()
+    dev = [gpu(t_).requires_grad_(True) for t_ in leaves]
+    gg, = torch.autograd.grad(ops.sum_all(hip(*dev)), dev[0], create_graph=True)
+    assert_close(gg, g.float(), TOL, 'deferred act grad, R1 first-order grad')
+    peng = ops.sumsq_all(gg)
+    assert_close(peng, pen.float(), TOL, 'deferred act grad, R1 penalty')
+    peng.backward()
+    for got, t_, name in zip(dev[1:], leaves[1:], ('wa', 'ba', 'wb', 'bb', 'wc')):
+        if name in ('ba', 'bb'):
+            continue        # LeakyReLU'' == 0: no second-order bias gradient
+        assert_close(got.grad, t_.grad.float(), 5e-4, f'deferred act grad, R1 d/d{name}')
