@@ -137,22 +137,31 @@ def test_full_width_layer_shapes_vs_oracle():
     assert_close(y, ref, TOL)
 
 
-def test_full_width_stylegan64_step_gradients_vs_oracle():
-    """REAL channel widths (512 ... 256 at 64^2), batch 4: generator image, D logits, R1 value, and every
-    parameter gradient of a D step and a G step - HIP path vs the CPU oracle on identical weights, latents and
-    noise.  Exercises the thick-channel kernel configurations (plain, stride-2 down / up, their dgrad / wgrad)
-    in the composition the 1024^2 benchmark network uses."""
+@pytest.mark.parametrize('res,fmap_base,fmap_max,b,min_entries,noise_ratio',
+                         [(64, 8192, 512, 4, 60, 1.0), (256, 4096, 64, 2, 80, 4.0)],
+                         ids=['full-width-64', 'thin-top-256'])
+def test_stylegan_step_gradients_vs_oracle(res, fmap_base, fmap_max, b, min_entries, noise_ratio):
+    """Generator image, D logits, R1 value, and every parameter gradient of a D step and a G step - HIP path vs the
+    CPU oracle on identical weights, latents and noise, in the composition the 1024^2 benchmark network uses.
+    full-width-64: REAL channel widths (512 ... 256 at 64^2), batch 4 - the thick-channel kernel configurations (plain,
+    stride-2 down / up, their dgrad / wgrad).  thin-top-256: the benchmark network's TOP (16 channels at 256^2, 32 at
+    128^2, 64 below), batch 2 - the rolling-window / thin stride-2 kernels, the streaming fromRGB / toRGB kernels and
+    the fused layer tail on large planes.  ``noise_ratio``: how much more fp32 rounding noise than the CPU library the
+    HIP path may carry on the deepest generator gradients (judged against float64, below).  Measured on the 256^2
+    network: every conv kernel is within 1.2e-6 of float64 per op, 2-4x the CPU library's error (one MFMA accumulator
+    adds its K terms in sequence, the CPU kernels keep 16 partial sums); G(z) 1.7e-5 vs 6.1e-6; the gradient of the
+    image through D alone 1.8e-3 (HIP) vs 2.9e-3 (CPU fp32) - the chain, not a kernel, produces the 1e-3 level."""
     from gan_lab_amd import ops, progressive as P
     from gan_lab_amd.progan.architectures import StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
     from gan_lab_amd.utils import backprop_utils as bp
     from oracle import nets, ops as O, step
-    P.FMAP_BASE, P.FMAP_MAX = 8192, 512
+    P.FMAP_BASE, P.FMAP_MAX = fmap_base, fmap_max
     torch.manual_seed(3)
     P.StyleGAN.reset_state()
-    g = StyleGenerator(final_res=64, blur_type='binomial')
-    d = StyleDiscriminator(final_res=64, blur_type='binomial')
-    for _ in range(4):
+    g = StyleGenerator(final_res=res, blur_type='binomial')
+    d = StyleDiscriminator(final_res=res, blur_type='binomial')
+    for _ in range(int(np.log2(res)) - 2):
         g.increase_scale()
         d.increase_scale()
     g.fade_in_phase = False
@@ -168,8 +177,7 @@ def test_full_width_stylegan64_step_gradients_vs_oracle():
     g.cuda().eval()
     g.use_truncation_trick = False
     d.cuda().train()
-    b = 4
-    z, real = torch.randn(b, 512), torch.rand(b, 3, 64, 64) * 2 - 1
+    z, real = torch.randn(b, 512), torch.rand(b, 3, res, res) * 2 - 1
     noise = [torch.randn(b, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2)) for n in range(len(g.gen_layers))]
     img = g(z.cuda(), noise=[n.cuda() for n in noise])
     fake = img.detach()
@@ -233,7 +241,7 @@ def test_full_width_stylegan64_step_gradients_vs_oracle():
         # when it is within 3x of the CPU path's error on that entry OR no worse than the CPU path's own worst entry.
         cpu_worst = max(e for _, e in judged.values())
         for k, (e_hip, e_cpu) in judged.items():
-            if e_hip > max(TOL, 3 * e_cpu, cpu_worst):
+            if e_hip > max(TOL, 3 * e_cpu, cpu_worst) * noise_ratio:
                 still[k] = (e_hip, e_cpu)
         assert not still, (still, cpu_worst)
-    assert len(worst) > 60
+    assert len(worst) > min_entries
