@@ -761,14 +761,22 @@ int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const g
   else GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<1>>, dim3(wgrid), dim3(256), 0, st, a);
   float* ws = (float*)workspace;
   float* stage2 = ws + (long long)pl.slots * nk;
-  const int groups = pl.slots >= 64 ? 32 : 1;
+  // slots -> 32 groups -> 1 with the wide reduce kernel (16*Cl*Ch threads); the fold kernel has only Cl*Ch threads
+  // (512 for the 16 -> 32 layer), so every slot it still had to add up cost it 16 serial strided reads per thread
   const float* folded_src = ws;
   int fold_groups = pl.slots;
-  if (groups > 1) {
-    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), groups), dim3(256), 0, st, (const float*)ws,
-              stage2, nk, pl.slots, groups);
+  if (fold_groups >= 64) {
+    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 32), dim3(256), 0, st, (const float*)ws,
+              stage2, nk, pl.slots, 32);
     folded_src = stage2;
-    fold_groups = groups;
+    fold_groups = 32;
+  }
+  if (fold_groups > 2) {
+    float* dst = folded_src == ws ? stage2 : ws;
+    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 1), dim3(256), 0, st, folded_src, dst, nk,
+              fold_groups, 1);
+    folded_src = dst;
+    fold_groups = 1;
   }
   const long long nw = (long long)g->Cout * g->Cin;
   GL_LAUNCH(fold_s2_kernel, dim3((unsigned)((nw + 127) / 128)), dim3(128), 0, st, folded_src, gw, g->Cout, g->Cin, Cl,
