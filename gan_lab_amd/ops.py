@@ -241,6 +241,16 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         check(_lib.lib().ganlab_conv_s2_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope,
                                                 _st()), 'conv_s2_fwd')
         return y
+    if g.ks == 1 and g.Hin == 1 and g.Win == 1 and g.N <= 64 and g.Cin >= 2048 and g.Cin % 128 == 0:
+        # A linear layer with a long contraction and few rows (the critic's 4x4 "valid" conv: 8192 -> 512 on `batch`
+        # rows): the forward kernel would walk all of K in 32 workgroups.  y[n][co] = sum_k x[n][k] w[co][k] is the
+        # weight-gradient contraction with k as the pixel axis, x as a (1, N, k) "output gradient" and w as a
+        # (1, Cout, k) "input" - no copies - and that kernel splits the pixel axis over ~1024 workgroups.
+        g2 = Geom(1, g.Cout, g.Cin // 128, 128, g.N, 1, 0)
+        y = k_conv_wgrad(x.view(g2.out_shape), w.view(g2.in_shape), g2, scale).view(g.out_shape)
+        if bias is not None or act != ACT_NONE:
+            y = k_bias_act(y, bias, None, None, bias_scale, act, slope)
+        return y
     wp = _packed(w, PACK_FWD, scale)
     check(_lib.lib().ganlab_conv_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _st()),
           'conv_fwd')

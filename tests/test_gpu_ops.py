@@ -77,7 +77,9 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
         assert_close(bg.grad, b.grad, TOL, 'bias grad')
 
 
-LIN_CASES = [(8, 512, 512, 0.01), (4, 16, 32, 1.0), (32, 512, 1, 1.0), (5, 24, 70, 1.0), (32, 512, 1024, 1.0)]
+LIN_CASES = [(8, 512, 512, 0.01), (4, 16, 32, 1.0), (32, 512, 1, 1.0), (5, 24, 70, 1.0), (32, 512, 1024, 1.0),
+             # long contraction, few rows: the critic's 4x4 valid conv as a linear (8192 -> 512), split over workgroups
+             (32, 8192, 512, 1.0), (4, 8192, 512, 1.0), (64, 2048, 40, 1.0)]
 
 
 @pytest.mark.parametrize('case', LIN_CASES, ids=[str(c) for c in LIN_CASES])
