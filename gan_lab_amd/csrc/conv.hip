@@ -673,6 +673,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
 //   * one barrier per step (144 MFMAs per wave), weights in registers, 51 KB of LDS: 3 workgroups per CU.
 // Wave w computes output row 4t + w (64 pixels = 4 MFMA column blocks).
 constexpr int RW_TW = 64, RW_ROWS = 4, RW_SLOTS = 10, RW_RP = 80, RW_SLOT = 16 * RW_RP, RW_Q = 18;
+#ifndef RW_LOAD_AT
+#define RW_LOAD_AT 6
+#endif
 constexpr int RW_ITEMS = RW_ROWS * 16 * RW_Q;            // float4 items of one 4-row prefetch: 1152
 constexpr int RW_PT = (RW_ITEMS + 255) / 256;            // 5
 
@@ -753,6 +756,21 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
         *reinterpret_cast<float4*>(ring + ((rel0 + k) % RW_SLOTS) * RW_SLOT + (lo[i] & 0xfffff)) = xr[i];
     }
   };
+  // the steady-state form: all four rows, slot of the first row given (a scalar), no per-item modulo
+  int lo_k[RW_PT], lo_off[RW_PT];
+#pragma unroll
+  for (int i = 0; i < RW_PT; ++i) {
+    lo_k[i] = lo[i] >> 20;
+    lo_off[i] = (lo[i] & 0xfffff) + lo_k[i] * RW_SLOT;
+  }
+  auto store_rows4 = [&](int slot0) {      // slot0 = (rel0 % RW_SLOTS), wave-uniform
+#pragma unroll
+    for (int i = 0; i < RW_PT; ++i) {
+      const int wrap = (slot0 + lo_k[i] >= RW_SLOTS) ? RW_SLOTS * RW_SLOT : 0;
+      if (i + 1 < RW_PT || tid + i * 256 < RW_ITEMS)
+        *reinterpret_cast<float4*>(ring + slot0 * RW_SLOT + lo_off[i] - wrap) = xr[i];
+    }
+  };
 
   load_rows(0, 4);
   store_rows(0, 4);
@@ -760,8 +778,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
   store_rows(4, 2);
   __syncthreads();
   for (int t = 0; t < nsteps; ++t) {
-    // rows 4t+6 .. 4t+9 for the next step (none after the last step: every offset out of range)
-    load_rows(4 * t + 6, t + 1 < nsteps ? 4 : 0);
     {
       int sbase[3];
 #pragma unroll
@@ -782,10 +798,14 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot][nb], wreg[st], acc[nb], 0, 0, 0);
+        // rows 4t+6 .. 4t+9 for the next step (none after the last step: every offset out of range).  Issued a few
+        // k-steps INTO the loop: the loads reuse the registers the previous step's output stores read their data from, so
+        // the compiler waits for those stores first - with MFMAs already queued that wait costs nothing
+        if (st == RW_LOAD_AT) load_rows(4 * t + 6, t + 1 < nsteps ? 4 : 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    store_rows(4 * t + 6, 4);       // the four slots not read by this step
+    store_rows4((4 * t + 6) % RW_SLOTS);       // the four slots not read by this step
     const int orow = (oy_first + 4 * t + wn) * p.Wo * 4;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
