@@ -945,10 +945,11 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const int co = co0 + mb * 16 + (lane & 15);
-          mk[nb][mb] = (co < p.Cout && n0 < p.in.N && oy < p.Ho && ox < p.Wo)
-                           ? *reinterpret_cast<const float4*>(p.mask + ((long long)n0 * p.Cout + co) * out_plane +
-                                                              (long long)oy * p.Wo + ox)
-                           : float4{1.f, 1.f, 1.f, 1.f};
+          // out-of-range outputs are never stored: they read mask[0..3] (always there) instead of being predicated,
+          // which keeps eight saved exec masks out of the scalar registers
+          const bool ok = co < p.Cout && n0 < p.in.N && oy < p.Ho && ox < p.Wo;
+          const long long off = ok ? ((long long)n0 * p.Cout + co) * out_plane + (long long)oy * p.Wo + ox : 0LL;
+          mk[nb][mb] = *reinterpret_cast<const float4*>(p.mask + off);
         }
       }
 #pragma unroll
