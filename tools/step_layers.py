@@ -40,6 +40,11 @@ def main():
     ops.k_conv_fwd = wrap('fwd', ops.k_conv_fwd, 3)
     ops.k_conv_dgrad = wrap('dgrad', ops.k_conv_dgrad, 2)
     ops.k_conv_wgrad = wrap('wgrad', ops.k_conv_wgrad, 2)
+    # the variants with a LeakyReLU derivative folded in (masked dgrad epilogue; fromRGB's streaming kernels)
+    ops.k_conv_dgrad_mask = wrap('dgrad', ops.k_conv_dgrad_mask, 3)
+    ops.k_conv_dgrad_act = wrap('dgrad', ops.k_conv_dgrad_act, 3)
+    ops.k_conv_wgrad_act = wrap('wgrad', ops.k_conv_wgrad_act, 3)
+    ops.k_conv_fwd_mask = wrap('fwd', ops.k_conv_fwd_mask, 3)
     torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s0.record()
