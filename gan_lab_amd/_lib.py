@@ -38,6 +38,9 @@ SIGNATURES = {
     'ganlab_conv_pack_f32': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_conv_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_splitk_plan': (_c_int, [_GP, _c_int]),
+    'ganlab_conv_fwd_splitk_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_dgrad_splitk_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p, _c_sz, _c_p]),
     'ganlab_conv_dgrad_mask_supported': (_c_int, [_GP]),
     'ganlab_conv_dgrad_mask_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
     'ganlab_conv_act_bwd_fused_supported': (_c_int, [_GP]),

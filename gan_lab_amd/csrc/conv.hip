@@ -309,6 +309,10 @@ struct ConvArgs {
   // whose input is a LeakyReLU output comes out already multiplied by that LeakyReLU's derivative.
   const float* mask;
   float mslope;
+  // split-K (scalar-staged small geometries only): workgroup (tile, ks) contracts input channels
+  // [ks * ksplit_ci, (ks + 1) * ksplit_ci) and writes its raw partial sums to y + ks * ksplit_stride
+  int ksplit, ksplit_ci;
+  long long ksplit_stride;
 };
 
 template <int KS_, int MB_, int TWL_, int THL_, int NIL_, int XMODE_>
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
 
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
-template <class Cfg, bool MASK = false>
+template <class Cfg, bool MASK = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
@@ -840,6 +844,14 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  int c_begin = 0, c_end = p.Cin_p;
+  if constexpr (SPLITK) {
+    const int ks = bid % p.ksplit;
+    bid /= p.ksplit;
+    c_begin = ks * p.ksplit_ci;
+    c_end = min(p.Cin_p, c_begin + p.ksplit_ci);
+    p.y += ks * p.ksplit_stride;
+  }
   const int co_t = bid % p.tiles_co;
   bid /= p.tiles_co;
   const int txi = bid % p.tiles_x;
@@ -886,17 +898,17 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
       wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
                          : float4{0.f, 0.f, 0.f, 0.f};
   };
-  x_load<G, CI_T, PLANE>(xr, xst, xb, 0, p.in.Cin, plane);
-  load_w(0);
+  x_load<G, CI_T, PLANE>(xr, xst, xb, c_begin, p.in.Cin, plane);
+  load_w(c_begin);
 
-  for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
+  for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
     __syncthreads();  // every wave is done reading the previous chunk
     x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);   // every staging mode goes through the register prefetch
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
-    if (ci0 + CI_T < p.Cin_p) {  // prefetch the next chunk: in flight during the MFMA phase below
+    if (ci0 + CI_T < c_end) {  // prefetch the next chunk: in flight during the MFMA phase below
       x_load<G, CI_T, PLANE>(xr, xst, xb, ci0 + CI_T, p.in.Cin, plane);
       load_w(ci0 + CI_T);
     }
@@ -1271,6 +1283,15 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
     }
   }
   if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+  if (a.ksplit > 1) {             // split-K: the scalar-staged small geometries only (splitk_plan)
+    if constexpr (G::XMODE == XSCALAR) {
+      a.ksplit_ci = round_up_c(ceil_div(a.Cin_p / Cfg::CI_T, a.ksplit) * Cfg::CI_T, Cfg::CI_T);
+      GL_LAUNCH((conv_fwd_kernel<Cfg, false, true>), dim3((unsigned)(tiles * a.ksplit)), dim3(256), 0, st, a);
+      return GL_CHECK_LAUNCH();
+    } else {
+      return GANLAB_EUNSUPPORTED;
+    }
+  }
   if (a.mask != nullptr) {        // output mask: the 3x3 vector-staged kernels only (ganlab_conv_dgrad_mask_supported)
     if constexpr (Cfg::KS == 3 && G::XMODE == XVEC) {
       GL_LAUNCH((conv_fwd_kernel<Cfg, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
@@ -1499,9 +1520,47 @@ inline bool pw_small_ok(int Cin, int Cout, int ks, int pad, int up, int Hi, int 
          aligned16(a) && aligned16(b);
 }
 
+// y = act(sum_s part[s] + bias): finishes a split-K launch (fixed summation order)
+__global__ void splitk_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                     float* __restrict__ y, int S, long long total, int C, int HW, float bias_scale,
+                                     int act, float slope) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = part[i];
+  for (int k = 1; k < S; ++k) v += part[(long long)k * total + i];
+  if (bias != nullptr) v += bias[(int)((i / HW) % C)] * bias_scale;
+  if (act == GANLAB_ACT_LRELU) v = gl_lrelu(v, slope);
+  y[i] = v;
+}
+
+// Split-K factor for a conv with output (N, Cout, Ho, Wo) contracting Cin channels: only the small geometries that
+// dispatch_geom runs on the scalar-staged kernels (Wo < 16 or 1x1), and only when the plain launch would put fewer than
+// ~2 workgroups on a CU.  Mirrors dispatch_co's channel-tile choice.
+int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
+  long long px_tiles;
+  if (Ho == 1 && Wo == 1) px_tiles = ceil_div(N, 64);
+  else if (Wo >= 16) return 1;
+  else if (Wo >= 8) px_tiles = (long long)ceil_div(Wo, 8) * ceil_div(Ho, 8) * ceil_div(N, 4);
+  else px_tiles = (long long)ceil_div(Wo, 4) * ceil_div(Ho, 4) * ceil_div(N, 16);
+  int mb = 1;
+  if (Cout <= 16) mb = 1;
+  else if (Cout <= 32) mb = 2;
+  else if (px_tiles * ceil_div(Cout, 64) >= 256) mb = 4;
+  else if (px_tiles * ceil_div(Cout, 32) >= 256) mb = 2;
+  const long long wgs = px_tiles * ceil_div(Cout, 16 * mb);
+  const int chunks = round_up_c(Cin, cin_pad(ks)) / (ks == 1 ? 32 : 8);
+  long long S = (512 + wgs - 1) / wgs;
+  const int cap = (Ho == 1 && Wo == 1) ? 8 : 4;
+  if (S > cap) S = cap;
+  if (S > chunks / 4) S = chunks / 4;      // at least four K-chunks per workgroup
+  while (S > 1 && (S - 1) * ceil_div(chunks, (int)S) >= chunks) --S;   // no empty split
+  return S < 2 ? 1 : (int)S;
+}
+
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,
              int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st,
-             const float* pw_mask = nullptr, float pw_mslope = 1.f, const float* out_mask = nullptr) {
+             const float* pw_mask = nullptr, float pw_mslope = 1.f, const float* out_mask = nullptr,
+             float* splitk_ws = nullptr, int ksplit = 1) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
   ConvArgs a{};
   a.in = make_patch(x, N, Cin, Hi, Wi, pad, up);
@@ -1527,6 +1586,17 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
     return GL_CHECK_LAUNCH();
   }
   if (pw_mask != nullptr) return GANLAB_EUNSUPPORTED;             // only the streaming 1x1 kernels fold the mask in
+  if (ksplit > 1) {
+    if (splitk_ws == nullptr || out_mask != nullptr || up) return GANLAB_EINVAL;
+    const long long total = (long long)N * Cout * a.Ho * a.Wo;
+    a.y = splitk_ws; a.bias = nullptr; a.act = GANLAB_ACT_NONE;
+    a.ksplit = ksplit; a.ksplit_stride = total;
+    const int rc = ks == 1 ? dispatch_co<1>(a, st) : dispatch_co<3>(a, st);
+    if (rc != GANLAB_OK) return rc;
+    GL_LAUNCH(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)splitk_ws,
+              bias, y, ksplit, total, Cout, a.Ho * a.Wo, bias_scale, act, slope);
+    return GL_CHECK_LAUNCH();
+  }
   if (ks == 1) return dispatch_co<1>(a, st);
   if (ks == 3) return dispatch_co<3>(a, st);
   return GANLAB_EINVAL;
@@ -1706,6 +1776,37 @@ int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual, c
 /* gx = dgrad(gy, w) * lrelu'(x): x (the conv's INPUT, shaped like gx) is itself a LeakyReLU output, and its derivative
  * is applied in the dgrad epilogue instead of a separate pass in the producing layer's backward.  Plain (no upsample,
  * no pool) fp32 convs. */
+/* Split-K for the small, channel-heavy layers (512-channel 4x4 / 8x8 maps, linear layers at small batch): 0 / 1 = run the
+ * plain entry point; S >= 2 = ganlab_conv_{fwd,dgrad}_splitk_f32 with a workspace of S * (output elements) floats. */
+int ganlab_conv_splitk_plan(const ganlab_conv_geom* g, int dgrad) {
+  int ho, wo;
+  if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK || g->up) return 0;
+  return dgrad ? splitk_plan(g->N, g->Cout, g->Cin, g->Hin, g->Win, g->ks)
+               : splitk_plan(g->N, g->Cin, g->Cout, ho, wo, g->ks);
+}
+
+int ganlab_conv_fwd_splitk_f32(const float* x, const float* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                               float bias_scale, int act, float slope, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  const int S = ganlab_conv_splitk_plan(g, 0);
+  int ho, wo;
+  if (S < 2 || ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK) return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < (size_t)S * g->N * g->Cout * ho * wo * sizeof(float)) return GANLAB_EWORKSPACE;
+  return run_conv(x, wp, bias, y, g->N, g->Cin, g->Hin, g->Win, g->Cout, g->ks, g->pad, 0, bias_scale, act, slope,
+                  gl_stream(stream), nullptr, 1.f, nullptr, (float*)workspace, S);
+}
+
+int ganlab_conv_dgrad_splitk_f32(const float* gy, const float* wp, float* gx, const ganlab_conv_geom* g, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  const int S = ganlab_conv_splitk_plan(g, 1);
+  int ho, wo;
+  if (S < 2 || ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK) return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < (size_t)S * g->N * g->Cin * g->Hin * g->Win * sizeof(float))
+    return GANLAB_EWORKSPACE;
+  return run_conv(gy, wp, nullptr, gx, g->N, g->Cout, ho, wo, g->Cin, g->ks, g->ks - 1 - g->pad, 0, 0.f,
+                  GANLAB_ACT_NONE, 0.f, gl_stream(stream), nullptr, 1.f, nullptr, (float*)workspace, S);
+}
+
 int ganlab_conv_dgrad_mask_supported(const ganlab_conv_geom* g) {
   // 3x3 "same" convs on >= 16-wide, 4-aligned rows (the vector-staged kernels)
   return (geom_ok(g) && g->ks == 3 && g->pad == 1 && !g->up && g->Win >= 16 && (g->Win & 3) == 0) ? 1 : 0;

@@ -252,8 +252,14 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
             y = k_bias_act(y, bias, None, None, bias_scale, act, slope)
         return y
     wp = _packed(w, PACK_FWD, scale)
-    check(_lib.lib().ganlab_conv_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _st()),
-          'conv_fwd')
+    L = _lib.lib()
+    split = 0 if g.up else L.ganlab_conv_splitk_plan(g.ref(), 0)
+    if split >= 2:     # few output tiles, long contraction (512-channel 4x4 / 8x8 maps, small-batch linears)
+        ws = torch.empty((split,) + tuple(y.shape), dtype=torch.float32, device=x.device)
+        check(L.ganlab_conv_fwd_splitk_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _p(ws),
+                                           ws.numel() * 4, _st()), 'conv_fwd_splitk')
+        return y
+    check(L.ganlab_conv_fwd_f32(_p(x), _p(wp), _p(bias), _p(y), g.ref(), bias_scale, act, slope, _st()), 'conv_fwd')
     return y
 
 
@@ -274,6 +280,12 @@ def k_conv_dgrad(gy, w, g, scale):
     wp = _packed(w, PACK_DGRAD, scale)
     hv, wv = (2 * g.Hin, 2 * g.Win) if g.up else (g.Hin, g.Win)
     gxv = _new((g.N, g.Cin, hv, wv), gy)
+    split = 0 if g.up else _lib.lib().ganlab_conv_splitk_plan(g.ref(), 1)
+    if split >= 2:
+        ws = torch.empty((split,) + tuple(gxv.shape), dtype=torch.float32, device=gy.device)
+        check(_lib.lib().ganlab_conv_dgrad_splitk_f32(_p(gy), _p(wp), _p(gxv), g.ref(), _p(ws), ws.numel() * 4, _st()),
+              'conv_dgrad_splitk')
+        return gxv
     check(_lib.lib().ganlab_conv_dgrad_f32(_p(gy), _p(wp), _p(gxv), g.ref(), _st()), 'conv_dgrad')
     if g.up:
         return k_pool2(gxv, 1.0)   # adjoint of the nearest upsample

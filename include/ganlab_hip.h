@@ -72,6 +72,17 @@ int ganlab_conv_fwd_f32(const float* x, const float* wp, const float* bias, floa
 int ganlab_conv_dgrad_f32(const float* gy, const float* wp, float* gx_virtual,
                           const ganlab_conv_geom* g, void* stream);
 
+/* Split-K variants for the small, channel-heavy layers (512-channel 4x4 / 8x8 maps; linear layers at small batch), whose
+ * plain launch is a few dozen workgroups walking a long contraction: ganlab_conv_splitk_plan returns S (0 / 1: use the plain
+ * entry point); S >= 2: S workgroups share one output tile, raw partial sums go to the workspace (S * output elements
+ * floats) and a finishing kernel adds them in a fixed order, + bias, + activation.  No upsample. */
+int ganlab_conv_splitk_plan(const ganlab_conv_geom* g, int dgrad);
+int ganlab_conv_fwd_splitk_f32(const float* x, const float* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                               float bias_scale, int act, float slope, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int ganlab_conv_dgrad_splitk_f32(const float* gy, const float* wp, float* gx, const ganlab_conv_geom* g, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* gx = dgrad(gy, w) * lrelu'(x) where x, the conv's input (shaped like gx), is the LeakyReLU output of the layer in
  * front (D block k's pooled conv -> block k+1's first conv, progan/architectures.py:280-293): that layer's backward then
  * takes gx as the gradient of its PRE-activation and skips its own gy * lrelu'(y) pass.  3x3 pad-1 convs, no
