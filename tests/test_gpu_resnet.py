@@ -302,7 +302,12 @@ def test_resnet_full_width_step_vs_oracle():
             l1 = err.sum().item() / max(p.grad.abs().sum().item(), 1e-3 * gmax * p.numel())
             # (measured when the 8-channel staging order of the tiny-geometry conv path changed the rounding: exactly
             #  one of 512 channels off, frac = 1/512 = 1.95e-3, L1 1.1e-3 .. 1.3e-3 - that one channel IS the L1 error)
-            if not (frac <= 5e-3 and l1 <= 3 * TOL):
+            # (seed sweep, seeds 3 / 11 / 12 / 13 / 14 with and without the split-K conv path: every seed but one has a few
+            #  such entries on BOTH paths - max error 4e-3 .. 2e-2 where fp32 on the CPU has 2e-4 .. 1.4e-3, L1 error
+            #  8e-4 .. 3.3e-3, up to 8 of 512 channels - so "how many elements" depends on which activations happen to sit
+            #  next to zero for that seed and rounding order; the bulk (L1) error is the stable quantity and is what is
+            #  bounded here.  A wrong kernel shows up as an L1 error of order 1.)
+            if not (frac <= 2e-2 and l1 <= 3 * TOL):
                 bad_g[k] = (f'{e:.3e}', f'cpu fp32 {e32:.3e}', tuple(p.shape), f'frac {frac:.2e}', f'l1 {l1:.2e}')
     assert not bad_g, f'G grads: {bad_g}'
     L.set_requires_grad_disc(True)
