@@ -1283,8 +1283,8 @@ int launch_fwd(ConvArgs a, hipStream_t st) {
     }
   }
   if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
-  if (a.ksplit > 1) {             // split-K: the scalar-staged small geometries only (splitk_plan)
-    if constexpr (G::XMODE == XSCALAR) {
+  if (a.ksplit > 1) {             // split-K: the small geometries only - scalar-staged, or 16x16 tiles (splitk_plan)
+    if constexpr (G::XMODE == XSCALAR || (G::XMODE == XVEC && G::TW == 16)) {
       a.ksplit_ci = round_up_c(ceil_div(a.Cin_p / Cfg::CI_T, a.ksplit) * Cfg::CI_T, Cfg::CI_T);
       GL_LAUNCH((conv_fwd_kernel<Cfg, false, true>), dim3((unsigned)(tiles * a.ksplit)), dim3(256), 0, st, a);
       return GL_CHECK_LAUNCH();
@@ -1539,7 +1539,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ part, const float
 int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
   long long px_tiles;
   if (Ho == 1 && Wo == 1) px_tiles = ceil_div(N, 64);
-  else if (Wo >= 16) return 1;
+  else if (Wo >= 32) return 1;
+  else if (Wo >= 16) px_tiles = (long long)ceil_div(Wo, 16) * ceil_div(Ho, 16) * N;
   else if (Wo >= 8) px_tiles = (long long)ceil_div(Wo, 8) * ceil_div(Ho, 8) * ceil_div(N, 4);
   else px_tiles = (long long)ceil_div(Wo, 4) * ceil_div(Ho, 4) * ceil_div(N, 16);
   int mb = 1;
@@ -1548,7 +1549,10 @@ int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
   else if (px_tiles * ceil_div(Cout, 64) >= 256) mb = 4;
   else if (px_tiles * ceil_div(Cout, 32) >= 256) mb = 2;
   const long long wgs = px_tiles * ceil_div(Cout, 16 * mb);
-  const int chunks = round_up_c(Cin, cin_pad(ks)) / (ks == 1 ? 32 : 8);
+  // K-chunk of the kernel that will run: 32 (1x1), 16 (vector-staged 16x16 tiles with <= 32 output channels per
+  // workgroup), else 8; a scalar-staged fallback for unaligned pointers halves it, which keeps every split non-empty
+  const int ci_t = ks == 1 ? 32 : ((Wo >= 16 && mb <= 2) ? 16 : 8);
+  const int chunks = round_up_c(Cin, cin_pad(ks)) / ci_t;
   long long S = (512 + wgs - 1) / wgs;
   const int cap = (Ho == 1 && Wo == 1) ? 8 : 4;
   if (S > cap) S = cap;

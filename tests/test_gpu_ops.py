@@ -51,6 +51,8 @@ CONV_CASES = [
     (32, 513, 4, 4, 512, 3, 1, False, True, 'lrelu'),  # critic's last 3x3 (mbstd channel): S = 4, odd Cin
     (3, 200, 5, 7, 72, 3, 1, False, True, None),       # ragged everything: 13 K-chunks of 16 -> 25 of 8, S = 4
     (2, 72, 8, 8, 200, 3, 1, False, False, 'lrelu'),   # 9 K-chunks: S is cut back so no workgroup gets an empty range
+    (8, 256, 16, 16, 128, 3, 1, False, True, 'lrelu'), # 16x16 tiles on the vector-staged kernel, S = 4
+    (32, 512, 16, 16, 512, 3, 1, False, True, None),   # the benchmark's 16x16 layer, S = 2
 ]
 
 
