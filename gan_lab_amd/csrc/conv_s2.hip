@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
-    if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);
+    if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);   // (issuing it inside the tap loop costs 20 VGPRs = the third workgroup)
 #pragma unroll 1
     for (int a = 0; a < 4; ++a) {
       const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
@@ -354,11 +354,14 @@ __global__ __launch_bounds__(256, 2) void conv_s2_up_kernel(S2Args p) {
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
-    if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);
+    const bool has_next = ci0 + CI_T < p.Cin_p;
     // K-steps of 4 channels are a real loop (bounds register pressure); the 16 (phase, tap) combinations
     // inside are unrolled with immediate LDS offsets and static accumulator indices
 #pragma unroll 1
     for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+      // the next chunk's loads go out after the first K-step: nothing but LDS reads between the barrier and the
+      // first MFMA, and the address arithmetic runs under queued matrix work (2 workgroups per CU either way)
+      if (c4 == 1 && has_next) load(ci0 + CI_T);
       const float* wc = Ws + c4 * 4 * COP + aoff;
       const float* xc = Xs + c4 * 4 * PLANE;
 #pragma unroll
