@@ -261,7 +261,7 @@ struct TCfg {
   static constexpr int MB = MB_, NBL = NBL_;
   static constexpr int TW = NBL_ == 4 ? 32 : 16, TH = NBL_ == 1 ? 4 : 8, TWL = NBL_ == 4 ? 5 : 4;
   static constexpr int CO_T = 16 * MB_;
-  static constexpr int CI_T = MB_ == 4 ? 8 : 16;
+  static constexpr int CI_T = 8;
   static constexpr int RP = TW + 8, R = TH + 2;
   static constexpr int PLANE = pad_mod32(R * RP, 16);
   static constexpr int ROW4 = RP / 4;
@@ -272,7 +272,7 @@ struct TCfg {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(256, 2) void conv_s2_up_kernel(S2Args p) {
+__global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel(S2Args p) {
   constexpr int MB = Cfg::MB, NBL = Cfg::NBL, CI_T = Cfg::CI_T, PLANE = Cfg::PLANE, RP = Cfg::RP, COP = Cfg::COP;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
