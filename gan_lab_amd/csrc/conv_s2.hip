@@ -96,7 +96,7 @@ template <int MB_, int TWL_ = 5>
 struct SCfg {
   static constexpr int MB = MB_, NB = 4, TWL = TWL_, TW = 1 << TWL_, TH = 256 / TW;
   static constexpr int CO_T = 16 * MB_;
-  static constexpr int CI_T = MB_ >= 2 ? 4 : 8;
+  static constexpr int CI_T = 4;
   static constexpr int RPL = TW + 4, RL = TH + 2;             // parity-plane geometry (low-res units)
   static constexpr int PL = pad_mod32(RL * RPL, 16);
   static constexpr int HROWS = 2 * RL, HROW4 = (2 * TW + 8) / 4;   // high-res rows / float4 per row
