@@ -676,14 +676,21 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
 //     the tile-based kernels - the thin layers are bound by the number of line requests, not by bandwidth;
 //   * one barrier per step (144 MFMAs per wave), weights in registers, 51 KB of LDS: 3 workgroups per CU.
 // Wave w computes output row 4t + w (64 pixels = 4 MFMA column blocks).
-constexpr int RW_TW = 64, RW_ROWS = 4, RW_SLOTS = 10, RW_RP = 80, RW_SLOT = 16 * RW_RP, RW_Q = 18;
+#ifndef RW_NSLOTS
+#define RW_NSLOTS 6
+#endif
+// RW_SLOTS = 10: the four prefetched rows go into slots nobody reads, one barrier per step (51 KB: 3 workgroups per CU).
+// RW_SLOTS = 6: they overwrite rows 4t .. 4t+3 after a barrier of their own (31 KB: 4 workgroups per CU, the kernel
+// needs 127 VGPRs) - two barriers per step, the second one right behind five LDS stores.
+constexpr int RW_TW = 64, RW_ROWS = 4, RW_SLOTS = RW_NSLOTS, RW_RP = 80, RW_SLOT = 16 * RW_RP, RW_Q = 18;
+static_assert(RW_SLOTS == 6 || RW_SLOTS == 10, "ring of 6 (two barriers) or 10 (one barrier) row slots");
 #ifndef RW_LOAD_AT
 #define RW_LOAD_AT 6
 #endif
 constexpr int RW_ITEMS = RW_ROWS * 16 * RW_Q;            // float4 items of one 4-row prefetch: 1152
 constexpr int RW_PT = (RW_ITEMS + 255) / 256;            // 5
 
-__global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float ring[RW_SLOTS * RW_SLOT];
   constexpr int C4N = 4, NSTEP = 36, PD = 3, NB = 4;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -809,7 +816,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    store_rows4((4 * t + 6) % RW_SLOTS);       // the four slots not read by this step
+    if constexpr (RW_SLOTS == 10) store_rows4((4 * t + 6) % RW_SLOTS);       // the four slots not read by this step
     const int orow = (oy_first + 4 * t + wn) * p.Wo * 4;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -825,7 +832,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_kernel(ConvArgs p) {
                                              0, 0);
       acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();   // rows 4t .. 4t+5 are no longer read; rows 4t+6 .. 4t+9 are complete
+    __syncthreads();   // rows 4t .. 4t+5 are no longer read; (10 slots:) rows 4t+6 .. 4t+9 are complete
+    if constexpr (RW_SLOTS == 6) {
+      store_rows4((4 * t + 6) % RW_SLOTS);     // = the slots of rows 4t .. 4t+3
+      __syncthreads();
+    }
   }
 }
 
