@@ -65,24 +65,19 @@ __device__ __forceinline__ void blur_row(const float* __restrict__ in, const flo
   const int lane = threadIdx.x & 63;
   float l = __shfl_up(v.w, 1, 64);
   float r = __shfl_down(v.x, 1, 64);
-  if (q == 0) {
-    l = 0.f;
-  } else if (lane == 0) {
-    l = 0.f;
-    if (valid) {
-      l = in[ro + x0 - 1];
-      if (MASKED) l = m[ro + x0 - 1] > 0.f ? l : l * slope;
-    }
+  // the wave's two outer neighbours: lane 0 fetches the element left of its segment, lane 63 the one right of it -
+  // ONE divergent load (two when masked) serves both
+  const bool need_l = lane == 0 && q != 0, need_r = lane == 63 && q != w4 - 1;
+  float e = 0.f;
+  if (valid && (need_l || need_r)) {
+    const long long eo = ro + x0 + (need_l ? -1 : 4);
+    e = in[eo];
+    if (MASKED) e = m[eo] > 0.f ? e : e * slope;
   }
-  if (q == w4 - 1) {
-    r = 0.f;
-  } else if (lane == 63) {
-    r = 0.f;
-    if (valid) {
-      r = in[ro + x0 + 4];
-      if (MASKED) r = m[ro + x0 + 4] > 0.f ? r : r * slope;
-    }
-  }
+  if (q == 0) l = 0.f;
+  else if (lane == 0) l = e;
+  if (q == w4 - 1) r = 0.f;
+  else if (lane == 63) r = e;
   hrow[0] = l + 2.f * v.x + v.y;
   hrow[1] = v.x + 2.f * v.y + v.z;
   hrow[2] = v.y + 2.f * v.z + v.w;
