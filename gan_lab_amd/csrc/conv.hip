@@ -183,6 +183,24 @@ __device__ __forceinline__ void x_load(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r, 
 }
 
 // strip variant: `xbase` = tile origin column in source units (ox0, or ox0/2 for the folded upsample)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// the same through a buffer descriptor over ONE image's Cin planes (vector mode, one image per tile): invalid items
+// read as zero by the hardware's bounds check (offset 0x80000000) - no exec-mask branches around the loads
+template <class G, int CI_T, int PLANE>
+__device__ __forceinline__ void x_load_desc(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
+                                            const XStage<G, CI_T, PLANE>& st, __amdgpu_buffer_rsrc_t rsrc, int ci0,
+                                            int Cin, int plane) {
+  constexpr int PT = XStage<G, CI_T, PLANE>::PT;
+  static_assert(G::XMODE == XVEC && G::NI == 1, "descriptor loads: plain vector staging, one image per tile");
+  const int soff = ci0 * plane * 4;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int ci = (st.loff[i] >> 20) & 0x3ff;
+    const int off = (st.goff[i] >= 0 && ci0 + ci < Cin) ? st.goff[i] * 4 : (int)0x80000000;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0);
+    r.v[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  }
+}
 template <class G, int CI_T, int PLANE>
 __device__ __forceinline__ void x_load_strip(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
                                              const XStage<G, CI_T, PLANE>& st, const float* xb, int ci0, int Cin,
@@ -202,7 +220,6 @@ __device__ __forceinline__ void x_load_strip(XRegs<G, XStage<G, CI_T, PLANE>::PT
 // Buffer-descriptor variant: `rsrc` spans the Cin*plane floats of this workgroup's image, so channel padding
 // (ci >= Cin) falls outside the descriptor and reads as 0 in hardware; rows / columns in the zero padding get an
 // out-of-range offset.  No exec-mask branches: ~6 instructions per float4 instead of ~20.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <class G, int CI_T, int PLANE>
 __device__ __forceinline__ void x_load_buf(XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
                                            const XStage<G, CI_T, PLANE>& st, __amdgpu_buffer_rsrc_t rsrc, int ci0,
@@ -903,13 +920,34 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
 
   XRegs<G, XS_t::PT> xr;
   float4 wr[WPT];
+  // plain vector staging (the thick layers): patch and weight prefetch through buffer descriptors - out-of-range items
+  // come back as zeros from the bounds check, so the ~20 loads of a chunk are straight-line code between the barrier
+  // and the MFMA loop instead of 20 exec-mask branches
+  constexpr bool DESC = G::XMODE == XVEC && G::NI == 1 && !SPLITK;
+  __amdgpu_buffer_rsrc_t rs_x, rs_w;
+  if constexpr (DESC) {
+    rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+    rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (unsigned)(KK * p.Cin_p * p.Cout_p * 4),
+                                             0x00020000);
+  }
   auto load_w = [&](int ci0) {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
-                         : float4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WPT; ++i) {
+      if constexpr (DESC) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wg[i] >= 0 ? wg[i] * 4 : (int)0x80000000,
+                                                              ci0 * p.Cout_p * 4, 0);
+        wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      } else {
+        wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+                           : float4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   };
-  x_load<G, CI_T, PLANE>(xr, xst, xb, c_begin, p.in.Cin, plane);
+  auto load_x = [&](int ci0) {
+    if constexpr (DESC) x_load_desc<G, CI_T, PLANE>(xr, xst, rs_x, ci0, p.in.Cin, plane);
+    else x_load<G, CI_T, PLANE>(xr, xst, xb, ci0, p.in.Cin, plane);
+  };
+  load_x(c_begin);
   load_w(c_begin);
 
   for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
@@ -920,7 +958,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
       if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
     if (ci0 + CI_T < c_end) {  // prefetch the next chunk: in flight during the MFMA phase below
-      x_load<G, CI_T, PLANE>(xr, xst, xb, ci0 + CI_T, p.in.Cin, plane);
+      load_x(ci0 + CI_T);
       load_w(ci0 + CI_T);
     }
     // taps: ky is a real loop (bounds the compiler's hoisting of LDS reads, i.e. register pressure),
