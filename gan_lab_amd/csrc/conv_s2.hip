@@ -21,6 +21,7 @@
 #include "common.h"
 
 namespace {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int ceil_div_c(int a, int b) { return (a + b - 1) / b; }
@@ -167,18 +168,26 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float4 xr[XPT], wr[WPT];
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wp), 0, (unsigned)(16 * p.Cin_p * p.Cout_p * 4), 0x00020000);
   auto load = [&](int ci0) {
-    const float* src = xb + (long long)ci0 * plane;
+    // buffer descriptors (this image's Cin planes; the packed weights): items outside the image / past Cin get the
+    // offset 0x80000000 and read as zeros from the bounds check - straight-line code instead of exec-mask branches
+    const int xs = ci0 * plane * 4, wsoff = ci0 * p.Cout_p * 4;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int ci = (xl[i] >> 20) & 0x3ff;
-      xr[i] = (xg[i] >= 0 && ci0 + ci < p.Cin) ? *reinterpret_cast<const float4*>(src + xg[i])
-                                                 : float4{0.f, 0.f, 0.f, 0.f};
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_x, (xg[i] >= 0 && ci0 + ci < p.Cin) ? xg[i] * 4 : (int)0x80000000, xs, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
-                         : float4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WPT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wg[i] >= 0 ? wg[i] * 4 : (int)0x80000000, wsoff, 0);
+      wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
   };
   load(0);
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
@@ -331,18 +340,26 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel
       for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float4 xr[XPT], wr[WPT];
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wp), 0, (unsigned)(16 * p.Cin_p * p.Cout_p * 4), 0x00020000);
   auto load = [&](int ci0) {
-    const float* src = xb + (long long)ci0 * plane;
+    // buffer descriptors (this image's Cin planes; the packed weights): items outside the image / past Cin get the
+    // offset 0x80000000 and read as zeros from the bounds check - straight-line code instead of exec-mask branches
+    const int xs = ci0 * plane * 4, wsoff = ci0 * p.Cout_p * 4;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       const int ci = (xl[i] >> 20) & 0x3ff;
-      xr[i] = (xg[i] >= 0 && ci0 + ci < p.Cin) ? *reinterpret_cast<const float4*>(src + xg[i])
-                                                 : float4{0.f, 0.f, 0.f, 0.f};
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_x, (xg[i] >= 0 && ci0 + ci < p.Cin) ? xg[i] * 4 : (int)0x80000000, xs, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
-                         : float4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WPT; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wg[i] >= 0 ? wg[i] * 4 : (int)0x80000000, wsoff, 0);
+      wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
   };
   load(0);
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
