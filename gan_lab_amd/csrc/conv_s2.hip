@@ -572,11 +572,9 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_kernel(W2Args p) {
     }
     __syncthreads();
     const int next = tile + p.S;
+    if (next < n_tiles) load_tile(next);   // (issued inside the K loop instead: same-box A/B 288.4 vs 287.6 ms/step - no gain)
 #pragma unroll 4
     for (int q = 0; q < PX_T / 4; ++q) {
-      // the next tile's loads go out after the first four K-steps: from the barrier to the first MFMA the wave issues
-      // no address arithmetic, and the loads still have 12 K-steps (96 MFMAs) to land
-      if (q == 4 && next < n_tiles) load_tile(next);
       const int j = 4 * q + (lane >> 4);
       const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
       const int poff = (ty + 1) * RPL + tx + 2 + (lane & 15) * PL + tap_base;
