@@ -254,3 +254,46 @@ def test_bf16_compute_mode_host_side():
     assert g_thin.bf is None
     assert ops.get_compute_dtype() == 'f32' and ops.Geom(8, 128, 32, 32, 128, 3, 1).bf is None
     assert ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)
+
+
+def test_splitk_and_fusion_plans_host_side():
+    """Pure host queries of the C ABI (no GPU): which layers get split-K and with how many splits, that no split is ever
+    empty, and which geometries fold a LeakyReLU derivative into their gradient kernels."""
+    from gan_lab_amd import _lib
+    L = _lib.lib()
+
+    def geom(n, cin, h, w, cout, ks=3, pad=1, up=0, pool=0):
+        return ctypes.byref(_lib.ConvGeom(n, cin, h, w, cout, ks, pad, up, pool))
+
+    def plan(*a, dgrad=0, **k):
+        return L.ganlab_conv_splitk_plan(geom(*a, **k), dgrad)
+    # the benchmark's low-resolution 512-channel layers at batch 32, forward and input gradient alike
+    assert plan(32, 512, 4, 4, 512) == 4 and plan(32, 512, 8, 8, 512) == 2 and plan(32, 512, 16, 16, 512) == 2
+    assert plan(32, 512, 8, 8, 512, dgrad=1) == 2
+    assert plan(32, 512, 32, 32, 512) <= 1 and plan(32, 16, 1024, 1024, 16) <= 1      # enough tiles: plain launch
+    assert plan(32, 512, 8, 8, 512, up=1) == 0                                         # never with the folded upsample
+    # linear layers (1x1 "images"): mapping network at batch 32 / 8, style affine; a short contraction is left alone
+    assert plan(32, 512, 1, 1, 512, ks=1, pad=0) == 4 and plan(8, 512, 1, 1, 1024, ks=1, pad=0) == 4
+    assert plan(8, 128, 1, 1, 8192, ks=1, pad=0) <= 1
+    # no empty split for any channel count: (S - 1) * ceil(chunks / S) < chunks with the kernel's K-chunk
+    for cin in list(range(8, 80, 7)) + [96, 200, 257, 513, 1000]:
+        for (h, ks) in [(4, 3), (8, 3), (16, 3), (1, 1)]:
+            for cout in (16, 40, 72, 512):
+                s = plan(3, cin, h, h, cout, ks=ks, pad=ks // 2)
+                if s >= 2:
+                    mb = 1 if cout <= 16 else (2 if cout <= 32 else None)
+                    ci_t = 32 if ks == 1 else (16 if (h >= 16 and mb is not None) else 8)
+                    pad_to = 32 if ks == 1 else 16
+                    cin_p = -(-cin // pad_to) * pad_to
+                    for t in {ci_t, 8 if ks == 3 else 32}:            # vector-staged or scalar-staged variant
+                        chunks = cin_p // t
+                        assert (s - 1) * -(-chunks // s) < chunks, (cin, h, ks, cout, s, t)
+    # LeakyReLU-derivative folding: fromRGB's streaming kernels from 64x64 up; the dgrad epilogue mask for plain 3x3
+    # 'same' convs on rows of >= 16 4-aligned pixels
+    assert L.ganlab_conv_act_bwd_fused_supported(geom(32, 3, 1024, 1024, 16, ks=1, pad=0)) == 1
+    assert L.ganlab_conv_act_bwd_fused_supported(geom(32, 3, 32, 32, 16, ks=1, pad=0)) == 0
+    assert L.ganlab_conv_act_bwd_fused_supported(geom(32, 16, 1024, 1024, 16)) == 0
+    assert L.ganlab_conv_dgrad_mask_supported(geom(32, 32, 512, 512, 32)) == 1
+    assert L.ganlab_conv_dgrad_mask_supported(geom(32, 512, 8, 8, 512)) == 0
+    assert L.ganlab_conv_dgrad_mask_supported(geom(32, 32, 512, 512, 32, up=1)) == 0
+    assert L.ganlab_conv_dgrad_mask_supported(geom(32, 32, 512, 512, 32, ks=1, pad=0)) == 0
