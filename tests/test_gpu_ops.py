@@ -685,3 +685,82 @@ def test_activation_gradient_deferred_to_next_conv(ops, blur):
         if name in ('ba', 'bb'):
             continue        # LeakyReLU'' == 0: no second-order bias gradient
         assert_close(got.grad, t_.grad.float(), 5e-4, f'deferred act grad, R1 d/d{name}')
+
+
+FULL_SIZE_LAYERS = [
+    # the benchmark network's own layer shapes at its FULL batch (32): Cin, Cout, H(in), ks, up, pool
+    (16, 16, 1024, 3, False, False),     # north-star layer: rolling-window kernel forward / dgrad, thin wgrad
+    (16, 32, 1024, 3, False, True),      # D top block: conv + 2x2 average pool as one stride-2 kernel
+    (32, 16, 512, 3, True, False),       # G top block: nearest upsample + conv as one stride-2 kernel
+    (3, 16, 1024, 1, False, False),      # fromRGB (streaming kernels)
+    (16, 3, 1024, 1, False, False),      # toRGB
+    (256, 256, 64, 3, False, False),     # the kernel with the largest share of the step
+    (512, 512, 32, 3, False, True),      # thick stride-2 down layer, 16x16 output tiles
+    (512, 512, 8, 3, False, False),      # split-K, S = 2
+    (513, 512, 4, 3, False, False),      # split-K, S = 4, mbstd channel
+]
+
+
+@pytest.mark.parametrize('layer', FULL_SIZE_LAYERS, ids=[str(c) for c in FULL_SIZE_LAYERS])
+def test_full_size_layers_adjointness_and_linearity(ops, layer):
+    """BASELINE-size checks that need no CPU oracle (a 1024^2 batch-32 layer is 155 GFLOP): the three kernels of a layer
+    must be each other's adjoints - <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(g, x)> - and the forward must be
+    linear in x; inner products in float64 on the device.  Together with the small-size oracle parity of the same kernels
+    this pins the full-size launches (tile / strip / split-K / slot decompositions only exist at these sizes)."""
+    cin, cout, h, ks, up, pool = layer
+    n = 32
+    gen = torch.Generator(device='cuda').manual_seed(zlib.crc32(repr(layer).encode()))
+
+    def rn(*shape):
+        return torch.randn(*shape, device='cuda', generator=gen)
+    x = rn(n, cin, h, h).requires_grad_(True)
+    w = (rn(cout, cin, ks, ks) / np.sqrt(cin * ks * ks)).requires_grad_(True)
+    pad = ks // 2
+    y = ops.conv2d(x, w, None, scale=1.0, padding=pad, up=up, pool=pool)
+    g = rn(*y.shape)
+    y.backward(g)
+
+    def dot(a, b):
+        return (a.detach().double() * b.detach().double()).sum().item()
+    lhs, via_x, via_w = dot(y, g), dot(x, x.grad), dot(w, w.grad)
+    scale = np.sqrt(dot(y, y) * dot(g, g))           # |<y, g>| <= |y| |g|: errors relative to that
+    assert abs(lhs - via_x) <= 2e-6 * scale, ('dgrad is not the adjoint', lhs, via_x, scale)
+    assert abs(lhs - via_w) <= 2e-6 * scale, ('wgrad is not the adjoint', lhs, via_w, scale)
+    with torch.no_grad():
+        x2 = rn(n, cin, h, h)
+        y12 = ops.conv2d(x.detach() + 2.0 * x2, w.detach(), None, scale=1.0, padding=pad, up=up, pool=pool)
+        y2 = ops.conv2d(x2, w.detach(), None, scale=1.0, padding=pad, up=up, pool=pool)
+        err = (y12 - (y.detach() + 2.0 * y2)).abs().max().item()
+    assert err <= 2e-5 * y12.abs().max().item(), ('forward is not linear in x', err)
+
+
+@pytest.mark.parametrize('blur', [False, True])
+def test_full_size_layer_tail_fused_equals_composed(ops, blur):
+    """The generator's top layer tail at the benchmark's full size (32 x 16 x 1024^2): the fused node (statistics in the
+    bias / blur pass, LeakyReLU derivative and channel sums in the InstanceNorm backward) against the composition of the
+    separate kernels on the same inputs - outputs and all four gradients - plus the size-independent property of the
+    result: every plane has mean 0 and variance 1 before the style is applied."""
+    gen = torch.Generator(device='cuda').manual_seed(91 + int(blur))
+    n, c, r = 32, 16, 1024
+
+    def rn(*shape):
+        return torch.randn(*shape, device='cuda', generator=gen)
+    x0, b0, nw0, st0 = rn(n, c, r, r), 0.1 * rn(c), 0.3 * rn(c), rn(n, 2 * c)
+    nz, cot = rn(n, 1, r, r), rn(n, c, r, r)
+    res = []
+    for fused in (True, False):
+        x, b, nw, st = (t_.clone().requires_grad_(True) for t_ in (x0, b0, nw0, st0))
+        if fused:
+            o = ops.layer_tail(x, b, nz, nw, st, act='lrelu', blur=blur, eps=1e-8)
+        else:
+            o = ops.instnorm_style(ops.bias_act(x, b, nz, nw, act='lrelu', blur=blur), st, 1e-8)
+        o.backward(cot)
+        res.append((o.detach(), x.grad, b.grad, nw.grad, st.grad))
+        del o, x
+    for a, bb, name in zip(res[0], res[1], ('out', 'dx', 'dbias', 'dnoise_w', 'dstyle')):
+        den = bb.abs().max().item()
+        assert (a - bb).abs().max().item() <= 2e-5 * den, f'fused vs composed {name}'
+    plain = ops.layer_tail(x0, b0, nz, nw0, None, act='lrelu', blur=blur, eps=1e-8)
+    m = plain.double().mean(dim=(2, 3))
+    v = plain.double().var(dim=(2, 3), unbiased=False)
+    assert m.abs().max().item() < 1e-5 and (v - 1).abs().max().item() < 1e-4
