@@ -764,3 +764,56 @@ def test_full_size_layer_tail_fused_equals_composed(ops, blur):
     m = plain.double().mean(dim=(2, 3))
     v = plain.double().var(dim=(2, 3), unbiased=False)
     assert m.abs().max().item() < 1e-5 and (v - 1).abs().max().item() < 1e-4
+
+
+def test_full_size_critic_top_fused_backward_equals_composed(ops):
+    """The critic's top at the benchmark's full size (batch 32, 1024^2): fromRGB -> conv + LeakyReLU + blur -> pooled conv
+    + LeakyReLU -> next block's first conv, with the LeakyReLU derivatives folded into the gradient kernels (fromRGB's
+    streaming kernels, the deferred derivative in the dgrad epilogue) against the same chain with every derivative as
+    its own pass: first-order gradients of all weights and of the image, and the R1-shaped second order."""
+    from gan_lab_amd import ops as raw
+    gen = torch.Generator(device='cuda').manual_seed(123)
+    n, r = 32, 1024
+
+    def rn(*shape):
+        return torch.randn(*shape, device='cuda', generator=gen)
+    img0 = rn(n, 3, r, r)
+    ws0 = [rn(16, 3, 1, 1) / np.sqrt(3), rn(16, 16, 3, 3) / 12, rn(32, 16, 3, 3) / 12, rn(32, 32, 3, 3) / 17]
+    bs0 = [0.1 * rn(16), 0.1 * rn(16), 0.1 * rn(1, 32, 1, 1), 0.1 * rn(32)]
+    cot = rn(n, 32, r // 2, r // 2)
+
+    def run(fused):
+        img = img0.clone().requires_grad_(True)
+        ws = [w_.clone().requires_grad_(True) for w_ in ws0]
+        bs = [b_.clone().requires_grad_(True) for b_ in bs0]
+        h = ops.conv2d(img, ws[0], bs[0], act='lrelu')                                   # fromRGB
+        h = ops.conv2d(h, ws[1], bs[1], padding=1, act='lrelu', blur=True)
+        h = ops.conv2d(h, ws[2], bs[2], padding=1, act='lrelu', pool=True, defer_act_grad=fused)
+        assert bool(getattr(h, ops.ACT_DEFERRED, False)) == fused
+        out = ops.conv2d(h, ws[3], bs[3], padding=1, act='lrelu', in_act_slope=0.2 if fused else None)
+        (out * cot).sum().backward()
+        first = [img.grad.clone()] + [w_.grad.clone() for w_ in ws] + [b_.grad.clone() for b_ in bs]
+        for t_ in [img] + ws + bs:
+            t_.grad = None
+        h = ops.conv2d(img, ws[0], bs[0], act='lrelu')
+        h = ops.conv2d(h, ws[1], bs[1], padding=1, act='lrelu', blur=True)
+        h = ops.conv2d(h, ws[2], bs[2], padding=1, act='lrelu', pool=True, defer_act_grad=fused)
+        out = ops.conv2d(h, ws[3], bs[3], padding=1, act='lrelu', in_act_slope=0.2 if fused else None)
+        g, = torch.autograd.grad(ops.sum_all(out), img, create_graph=True)
+        pen = ops.sumsq_all(g)
+        pen.backward()
+        return first, pen.detach().clone(), [w_.grad.clone() for w_ in ws]
+
+    fused = run(True)
+    saved = raw.conv_act_bwd_fusable
+    raw.conv_act_bwd_fusable = lambda g: False
+    try:
+        comp = run(False)
+    finally:
+        raw.conv_act_bwd_fusable = saved
+    names = ['dimg', 'dw0', 'dw1', 'dw2', 'dw3', 'db0', 'db1', 'db2', 'db3']
+    for a, b_, name in zip(fused[0], comp[0], names):
+        assert (a - b_).abs().max().item() <= 1e-4 * b_.abs().max().item(), f'first order {name}'
+    assert abs(fused[1].item() - comp[1].item()) <= 1e-5 * abs(comp[1].item()), 'R1 penalty'
+    for a, b_, name in zip(fused[2], comp[2], names[1:5]):
+        assert (a - b_).abs().max().item() <= 1e-4 * b_.abs().max().item(), f'second order {name}'
