@@ -817,3 +817,24 @@ def test_full_size_critic_top_fused_backward_equals_composed(ops):
     assert abs(fused[1].item() - comp[1].item()) <= 1e-5 * abs(comp[1].item()), 'R1 penalty'
     for a, b_, name in zip(fused[2], comp[2], names[1:5]):
         assert (a - b_).abs().max().item() <= 1e-4 * b_.abs().max().item(), f'second order {name}'
+
+
+def test_full_size_resampling_ops_adjoint_identities(ops):
+    """32 x 16 x 1024^2: the binomial blur is self-adjoint, the 2x2 average pool and the nearest 2x upsample are adjoint up
+    to the factor 4, the pool preserves the mean and the blur preserves the sum of an interior-supported image."""
+    gen = torch.Generator(device='cuda').manual_seed(17)
+    x = torch.randn(32, 16, 1024, 1024, device='cuda', generator=gen)
+    g = torch.randn(32, 16, 1024, 1024, device='cuda', generator=gen)
+
+    def dot(a, b):
+        return (a.double() * b.double()).sum().item()
+    nrm = np.sqrt(dot(x, x) * dot(g, g))
+    assert abs(dot(ops.blur(x), g) - dot(x, ops.blur(g))) <= 2e-6 * nrm
+    gl = torch.randn(32, 16, 512, 512, device='cuda', generator=gen)
+    nrm2 = np.sqrt(dot(x, x) * dot(gl, gl))
+    assert abs(dot(ops.avg_pool2(x), gl) - 0.25 * dot(x, ops.upsample2(gl))) <= 2e-6 * nrm2
+    assert abs(ops.avg_pool2(x).double().mean().item() - x.double().mean().item()) <= 1e-7
+    xi = torch.zeros_like(x)
+    xi[:, :, 1:-1, 1:-1] = x[:, :, 1:-1, 1:-1]          # zero border: no mass leaves through the zero padding
+    sb, s0 = ops.blur(xi).double().sum().item(), xi.double().sum().item()
+    assert abs(sb - s0) <= 1e-6 * xi.double().abs().sum().item()
