@@ -95,11 +95,11 @@ def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32', c=None, r=No
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4),
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on this
-            # kernel, profiles/r01c_northstar_conv_pmc.csv: 2.24e9 read (1.04x the algorithmic 2 GiB: the 8-of-72
-            # column halo that misses L2) + 2.15e9 written; same file: MFMA pipes busy 0.74-0.76 of the kernel's
-            # cycles at an effective clock of 1.8-2.1 GHz
-            'traffic': 4.391e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+            # passes) on this kernel, profiles/r01g_northstar_conv_pmc.csv: 2.55e9 read (1.19x the algorithmic 2 GiB:
+            # the 8-of-72 column halo and the strip-boundary rows that miss L2) + 2.17e9 written;
+            # profiles/r01d_northstar_conv_pmc.csv: MFMA pipes busy 0.79-0.80 of the kernel's cycles
+            'traffic': 4.722e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
             'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
                        f'conv_fwd_roll_kernel<KS=3,16co,64px column strips,4 rows/step> {c}->{c} @{res}^2 x{batch}'
                        if (c <= 16 and res % 64 == 0) else
