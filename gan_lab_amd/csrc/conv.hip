@@ -341,7 +341,7 @@ struct FwdCfg {
   static constexpr int CO_T = 16 * MB_;
   // scalar staging keeps 3 registers per patch element in flight (global offset, LDS offset, value): 8-channel
   // chunks bound that at ~55 registers for the 4x4x16-image geometry
-  static constexpr int CI_T = (KS_ == 1) ? 32 : ((MB_ <= 2 && XMODE_ != XSCALAR) ? 16 : 8);
+  static constexpr int CI_T = (KS_ == 1) ? 32 : ((MB_ == 1 && XMODE_ != XSCALAR) ? 16 : 8);
   static constexpr int PLANE = pad_mod32(G::NI * G::IMG, 16);
   static constexpr int COP = pad_mod32(CO_T, 16);
   static constexpr int XS = CI_T * PLANE, WS = KK * CI_T * COP;
@@ -1600,7 +1600,7 @@ int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
   const long long wgs = px_tiles * ceil_div(Cout, 16 * mb);
   // K-chunk of the kernel that will run: 32 (1x1), 16 (vector-staged 16x16 tiles with <= 32 output channels per
   // workgroup), else 8; a scalar-staged fallback for unaligned pointers halves it, which keeps every split non-empty
-  const int ci_t = ks == 1 ? 32 : ((Wo >= 16 && mb <= 2) ? 16 : 8);
+  const int ci_t = ks == 1 ? 32 : ((Wo >= 16 && mb == 1) ? 16 : 8);
   const int chunks = round_up_c(Cin, cin_pad(ks)) / ci_t;
   long long S = (512 + wgs - 1) / wgs;
   const int cap = (Ho == 1 && Wo == 1) ? 8 : 4;
