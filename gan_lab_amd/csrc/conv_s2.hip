@@ -700,7 +700,7 @@ W2Plan plan_w2(int N, int Cl, int Ch, int Hl, int Wl) {
   pl.tiles_x = ceil_div(Wl, WCfg<1>::TW); pl.tiles_y = ceil_div(Hl, WCfg<1>::TH);
   pl.tiles_cl = ceil_div(Cl, 16 * pl.nba); pl.tiles_ch = ceil_div(Ch, 16);
   const long long n_tiles = (long long)pl.tiles_x * pl.tiles_y * N, base = (long long)pl.tiles_cl * pl.tiles_ch;
-  long long S = (1024 + base - 1) / base;
+  long long S = (768 + base - 1) / base;    // three workgroups per CU fit (LDS 40 KB, 150 VGPRs): one full round
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
   pl.S = (int)S;
