@@ -1675,9 +1675,10 @@ void fill_plan(WgPlan& pl, int N, int Cin, int Cout, int Ho, int Wo) {
   pl.tiles_co = ceil_div(Cout, Cfg::CO_T); pl.tiles_ci = ceil_div(Cin, Cfg::CI_T);
   const long long n_tiles = (long long)pl.tiles_x * pl.tiles_y * pl.tiles_n;
   const long long base = (long long)pl.tiles_co * pl.tiles_ci;
-  // one or two full rounds of what fits on a CU: three workgroups of the 16-channel thin configuration (43 KB of LDS,
-  // 122 VGPRs), two of the others
-  const long long target = (Cfg::WM == 1 && Cfg::NBC == 1) ? 768 : 1024;
+  // ONE full round of what fits on a CU - three workgroups of the 16-channel thin configuration (43 KB of LDS, 122
+  // VGPRs), two of the others: no tail round, and the fewest slots to reduce afterwards (same-box A/B: 1024 -> 768 resp.
+  // 512 workgroups, -1.3 and -1.2 ms per step)
+  const long long target = (Cfg::WM == 1 && Cfg::NBC == 1) ? 768 : 512;
   long long S = (target + base - 1) / base;
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
