@@ -91,6 +91,7 @@ class ProGANLearner(GANLearner):
         self._update_data_config(raise_exception=False)
         self.latent_distribution = self.config.latent_distribution
         self._family.reset_state()
+        rng.seed_from_config(self.config.random_seed)     # latents / per-layer noise: per-rank Philox streams
         self.gen_model, self.disc_model = self._build_networks()
         assert self.config.init_res <= self.config.res_samples
         if self.config.init_res > 4:
@@ -123,9 +124,13 @@ class ProGANLearner(GANLearner):
         dev = self.config.dev
         self.arena_g = ParamArena(self.gen_model.named_parameters(), dev)
         self.arena_d = ParamArena(self.disc_model.named_parameters(), dev)
-        if first:
-            parallel.broadcast_params(self.arena_g.flat)
-            parallel.broadcast_params(self.arena_d.flat)
+        # Replicas start from rank 0's values at construction AND after every growth event: the new blocks and the
+        # fresh torgb / fromrgb are drawn from each process's own torch RNG (custom_layers.Conv2dEx), which
+        # config.random_seed=-1 seeds differently per rank.  Surviving parameters are already identical on every rank
+        # (same averaged gradients, same Adam), so the broadcast only moves what diverged - but it is the whole flat
+        # arena in one collective either way (a growth event is rare; 100 MB over xGMI is < 1 ms).
+        parallel.broadcast_params(self.arena_g.flat)
+        parallel.broadcast_params(self.arena_d.flat)
         self.ewma = None
         self.gen_model_lagged = None
         if self.config.use_ewma_gen:
@@ -137,6 +142,9 @@ class ProGANLearner(GANLearner):
                 self.ewma = EwmaTracker.__new__(EwmaTracker)
                 self.ewma.rebuild(self.arena_g, old_lagged, rename={'torgb.conv2d.weight': 'prev_torgb.conv2d.weight',
                                                                     'torgb.conv2d.bias': 'prev_torgb.conv2d.bias'})
+            # built from the (already broadcast) arena + the old shadow, so identical by construction; the explicit
+            # broadcast keeps that true even if an old shadow had drifted (e.g. a rank resumed from another file)
+            parallel.broadcast_params(self.ewma.flat)
             self.lagged_params = self.ewma.lagged_params
 
     def _set_optimizer(self):
@@ -177,7 +185,9 @@ class ProGANLearner(GANLearner):
 
     def get_smoothing_ewma_beta(self, half_life):
         assert isinstance(half_life, float)
-        return ewma_beta(self.batch_size, self.config.gen_bs_mult, half_life)
+        # the half-life is in IMAGES (progan/learner.py:1124-1127): under data parallelism one G iteration sees
+        # batch_size * world_size of them
+        return ewma_beta(self.batch_size * parallel.world_size(), self.config.gen_bs_mult, half_life)
 
     @property
     def progressively_grow(self):
@@ -299,6 +309,34 @@ class ProGANLearner(GANLearner):
                                          '`Resize` in transforms list.')
         return transforms_lst
 
+    def _apply_phase_events(self, sched, train_dl=None, valid_dl=None, z_valid_dl=None):
+        """Host side of a phase boundary (progan/learner.py:560-729): ask the phase machine what happens before this
+        main iteration and do it - grow both networks (+ arenas, replica re-broadcast, fresh Adam / LR schedule,
+        EWMA re-keying, loader bump), or reset the optimisers at a stabilise / final boundary."""
+        for ev in sched.begin_iter():
+            if ev == GROW:
+                prev = self.gen_model.curr_res
+                self._grow()
+                self._bump_loader(train_dl)
+                self._bump_loader(valid_dl)
+                if z_valid_dl is not None:
+                    z_valid_dl.batch_sampler.batch_size = self.batch_size
+                if parallel.rank() == 0:
+                    print(f'\n\n\nRESOLUTION INCREASED FROM {prev}x{prev} to {self.gen_model.curr_res}x'
+                          f'{self.gen_model.curr_res}\n\nFADING IN {self.gen_model.curr_res}x'
+                          f'{self.gen_model.curr_res} RESOLUTION...\n')
+            elif ev == STABILISE:
+                self._reset_opt_and_sched()
+                if parallel.rank() == 0:
+                    print('\nSTABILIZING...\n')
+            elif ev == FINAL:
+                self._reset_opt_and_sched()
+                self._progressively_grow = False
+                if parallel.rank() == 0:
+                    print('\nSTABILIZING (FINAL)...\n')
+        self.curr_phase_num = sched.curr_phase_num
+        assert sched.curr_res == self.gen_model.curr_res and sched.batch_size == self.batch_size
+
     # ------------------------------------------------------------------------------------------------
     def train(self, train_dl, valid_dl=None, z_valid_dl=None, num_main_iters=None, num_gen_iters=None,
               num_disc_iters=None):
@@ -313,7 +351,7 @@ class ProGANLearner(GANLearner):
         self.disc_model.to(c.dev).train()
         if self.not_trained_yet:
             self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, c.bs_dict,
-                                       c.nimg_transition, num_disc_iters)
+                                       c.nimg_transition, num_disc_iters, world_size=parallel.world_size())
             self.beta = None
             if c.use_ewma_gen:
                 self.beta = self.get_smoothing_ewma_beta(half_life=EWMA_SMOOTHING_HALFLIFE) \
@@ -324,7 +362,7 @@ class ProGANLearner(GANLearner):
         else:
             if self.sched is None:      # checkpoint without phase bookkeeping: start the phases at this resolution
                 self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, c.bs_dict,
-                                           c.nimg_transition, num_disc_iters)
+                                           c.nimg_transition, num_disc_iters, world_size=parallel.world_size())
             if self.pretrained_model and getattr(self, 'train_dataiter', None) is None:
                 self._bump_loader(train_dl)         # resume at the checkpoint's resolution / batch size
                 self._bump_loader(valid_dl)
@@ -341,29 +379,7 @@ class ProGANLearner(GANLearner):
         try:
             for itr in range(num_main_iters):
                 self.set_requires_grad_disc(True)
-                for ev in sched.begin_iter():
-                    if ev == GROW:
-                        prev = self.gen_model.curr_res
-                        self._grow()
-                        self._bump_loader(train_dl)
-                        self._bump_loader(valid_dl)
-                        if z_valid_dl is not None:
-                            z_valid_dl.batch_sampler.batch_size = self.batch_size
-                        if parallel.rank() == 0:
-                            print(f'\n\n\nRESOLUTION INCREASED FROM {prev}x{prev} to {self.gen_model.curr_res}x'
-                                  f'{self.gen_model.curr_res}\n\nFADING IN {self.gen_model.curr_res}x'
-                                  f'{self.gen_model.curr_res} RESOLUTION...\n')
-                    elif ev == STABILISE:
-                        self._reset_opt_and_sched()
-                        if parallel.rank() == 0:
-                            print('\nSTABILIZING...\n')
-                    elif ev == FINAL:
-                        self._reset_opt_and_sched()
-                        self._progressively_grow = False
-                        if parallel.rank() == 0:
-                            print('\nSTABILIZING (FINAL)...\n')
-                self.curr_phase_num = sched.curr_phase_num
-                assert sched.curr_res == self.gen_model.curr_res and sched.batch_size == self.batch_size
+                self._apply_phase_events(sched, train_dl, valid_dl, z_valid_dl)
 
                 # ------------------------- TRAIN DISCRIMINATOR -------------------------
                 for disc_iter in range(num_disc_iters):
@@ -692,7 +708,8 @@ class ProGANLearner(GANLearner):
                 setattr(self, k, ck[k])
         if ck.get('nimg_transition_lst') is not None:
             self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, self.config.bs_dict,
-                                       self.config.nimg_transition, self.config.num_disc_iters)
+                                       self.config.nimg_transition, self.config.num_disc_iters,
+                                       world_size=parallel.world_size())
             self.sched.restore(self.gen_model.curr_res, ck['curr_img_num'], ck['curr_phase_num'],
                                ck['nimg_transition_lst'], self.gen_model.alpha,
                                ck.get('progressively_grow', True))

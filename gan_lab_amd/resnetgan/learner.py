@@ -36,7 +36,10 @@ class GANLearner(object):
         self._model = config.model
         self.pretrained_model = False
         dev = torch.device(config.dev)
-        if dev.type != 'cuda':
+        # GANLAB_HOST_LOGIC_ONLY=1 lets the CPU tests drive the learner's HOST logic (construction, growth events,
+        # arenas, optimiser / EWMA bookkeeping, the data-parallel parameter broadcast over gloo).  It does not add a
+        # CPU compute path: every tensor op of a step still raises in gan_lab_amd.ops for a non-GPU tensor.
+        if dev.type != 'cuda' and os.environ.get('GANLAB_HOST_LOGIC_ONLY') != '1':
             raise RuntimeError(f"gan_lab_amd runs on the MI355X only (config.dev={config.dev!r}); there is no CPU "
                                f"path - use the reference or the test oracle for CPU runs")
         _lib.lib()  # fail now, loudly, if the kernel library is missing
@@ -123,6 +126,8 @@ class GANLearner(object):
                                    nl=self.nl, num_classes=self.num_classes_disc, equalized_lr=c.use_equalized_lr)
         self.gen_model.to(c.dev)
         self.disc_model.to(c.dev)
+        from .. import rng
+        rng.seed_from_config(c.random_seed)
         assert self.gen_model.res == self.disc_model.res
         self.latent_distribution = c.latent_distribution
         self.reducer = parallel.GradReducer()

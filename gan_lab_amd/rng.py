@@ -11,6 +11,26 @@ def manual_seed(seed, rank=0):
     _STATE['offset'] = 0
 
 
+def seed_from_config(random_seed):
+    """Seed the device stream the way config.py:337-376 seeds numpy / torch: ``random_seed`` in [0, 2**32) is used as
+    is, -1 draws a fresh one.  Called by the learners at construction (the process group, if any, exists by then):
+    rank 0's seed is shared, then every rank mixes its own rank in, so that the replicas of a data-parallel run draw
+    DIFFERENT latents and per-layer noise (an effective fake batch of B * world_size) yet a fixed ``random_seed``
+    reproduces the run."""
+    import os
+    from . import parallel
+    seed = int(random_seed) if random_seed is not None else -1
+    if seed < 0:
+        seed = int.from_bytes(os.urandom(7), 'little')
+    if parallel.is_dist():
+        import torch.distributed as dist
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = int(box[0])
+    manual_seed(seed, parallel.rank())
+    return seed
+
+
 def randn(shape, device='cuda'):
     n = 1
     for s in shape:

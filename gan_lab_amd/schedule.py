@@ -7,6 +7,12 @@ batch size); the image counter advances by ``batch_size`` per D iteration; after
 resolution's fade-in a FINAL phase of unbounded length starts.  The learner asks ``begin_iter()``
 what to do before each main iteration and reports progress with ``after_d_iter()`` /
 ``end_iter()``; everything numeric (alpha, delta_alpha, batch size) is returned as plain numbers.
+
+Data parallel (new work): ``nimg_transition`` counts REAL IMAGES, and with ``world_size``
+ranks one D iteration consumes ``batch_size * world_size`` of them.  ``batch_size`` stays the per-rank
+micro-batch the kernels see; the image counter, the round-up of ``nimg_transition`` and ``delta_alpha`` use the
+global batch, so a W-rank run walks the same schedule in images as the reference run with a W-times larger batch
+(``world_size=1`` is the reference's arithmetic exactly, pinned by the trace of the real learner).
 """
 import math
 
@@ -31,13 +37,14 @@ def ewma_beta(batch_size, gen_bs_mult=1, half_life=10.):
 
 
 class PhaseSchedule(object):
-    def __init__(self, init_res, final_res, bs_dict, nimg_transition_cfg, num_disc_iters=1):
+    def __init__(self, init_res, final_res, bs_dict, nimg_transition_cfg, num_disc_iters=1, world_size=1):
         self.curr_res, self.final_res = init_res, final_res
         self.bs_dict = dict(bs_dict)
         self.nimg_transition_cfg = nimg_transition_cfg
         self.num_disc_iters = num_disc_iters
+        self.world_size = int(world_size)
         self.batch_size = self.bs_dict[init_res]
-        self.nimg_transition = round_nimg_transition(nimg_transition_cfg, self.batch_size)
+        self.nimg_transition = round_nimg_transition(nimg_transition_cfg, self.global_batch)
         self.nimg_transition_lst = [self.nimg_transition]
         self.curr_img_num = 0
         self.curr_phase_num = 0
@@ -46,6 +53,11 @@ class PhaseSchedule(object):
         self.alpha = 1
         self.delta_alpha = None
         self.alpha_tol = 1.e-8
+
+    @property
+    def global_batch(self):
+        """Real images consumed per D iteration over all ranks."""
+        return self.batch_size * self.world_size
 
     def begin_iter(self):
         """Returns the list of events to apply before this main iteration: any of GROW, STABILISE,
@@ -57,8 +69,8 @@ class PhaseSchedule(object):
             if self.curr_phase_num % 2 == 1:
                 self.curr_res *= 2
                 self.batch_size = self.bs_dict[self.curr_res]
-                self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.batch_size)
-                self.delta_alpha = delta_alpha(self.batch_size, self.nimg_transition, self.num_disc_iters)
+                self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.global_batch)
+                self.delta_alpha = delta_alpha(self.global_batch, self.nimg_transition, self.num_disc_iters)
                 self.alpha = 0
                 self.fade_in_phase = True
                 events.append(GROW)
@@ -73,7 +85,7 @@ class PhaseSchedule(object):
         return events
 
     def after_d_iter(self):
-        self.curr_img_num += self.batch_size
+        self.curr_img_num += self.global_batch
 
     def end_iter(self):
         """alpha += delta_alpha with the setter's snap-to-1 (base.py:161-170)."""
@@ -92,13 +104,13 @@ class PhaseSchedule(object):
         """Put the machine into a saved state (the fields ``save_model`` keeps, progan/learner.py:1261-1297)."""
         self.curr_res = int(curr_res)
         self.batch_size = self.bs_dict[self.curr_res]
-        self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.batch_size)
+        self.nimg_transition = round_nimg_transition(self.nimg_transition_cfg, self.global_batch)
         self.nimg_transition_lst = [math.inf if (x is None or x < 0 or x == math.inf) else x
                                     for x in nimg_transition_lst]
         self.curr_img_num, self.curr_phase_num = int(curr_img_num), int(curr_phase_num)
         self.progressively_grow = bool(progressively_grow)
         self.fade_in_phase = alpha != 1
         self.alpha = alpha if self.fade_in_phase else 1
-        self.delta_alpha = delta_alpha(self.batch_size, self.nimg_transition, self.num_disc_iters) \
+        self.delta_alpha = delta_alpha(self.global_batch, self.nimg_transition, self.num_disc_iters) \
             if self.fade_in_phase else None
         return self

@@ -54,6 +54,24 @@ def test_schedule_known_answers():
     assert ewma_beta(32, half_life=0.) == 0.
 
 
+def test_schedule_counts_global_images_under_data_parallel():
+    """W ranks at per-rank batch B walk the same schedule, in images and in alpha, as one process at batch W*B
+    (``nimg_transition`` counts real images; reference: progan/learner.py:646-653, :848)."""
+    from gan_lab_amd.schedule import PhaseSchedule
+    bs1 = {4: 8, 8: 8, 16: 4}
+    bs2 = {4: 16, 8: 16, 16: 8}
+    a = PhaseSchedule(4, 16, bs1, 100, num_disc_iters=1, world_size=2)
+    b = PhaseSchedule(4, 16, bs2, 100, num_disc_iters=1, world_size=1)
+    for _ in range(60):
+        assert a.begin_iter() == b.begin_iter()
+        a.after_d_iter(), b.after_d_iter()
+        assert (a.curr_img_num, a.curr_res, a.curr_phase_num) == (b.curr_img_num, b.curr_res, b.curr_phase_num)
+        assert a.batch_size * 2 == b.batch_size == a.global_batch
+        a.end_iter(), b.end_iter()
+        assert a.alpha == b.alpha and a.fade_in_phase == b.fade_in_phase
+    assert a.nimg_transition_lst == b.nimg_transition_lst and a.curr_res == 16
+
+
 def test_fmap_table_and_lockstep_state():
     from gan_lab_amd import progressive as P
     assert (P.FMAP_BASE, P.FMAP_MAX) == (8192, 512)
