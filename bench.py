@@ -1,28 +1,42 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the full G+D training step (1 D-iteration + 1 G-iteration),
-StyleGAN 1024^2, batch 32 per GPU, fp32, nonsaturating loss + R1 (lambda 10) + drift, stabilised phase
-at the final resolution, synthetic FFHQ-shaped data (BASELINE.json metric / configs[2]).
+"""Benchmark of the G+D training step (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      # headline: BASELINE config #3
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
              --master-port P bench.py --gpus N --steps K --warmup W)
+    python bench.py --config {2,4,5} ...                               # the other BASELINE configurations
 
-Prints ONE JSON line on rank 0.  ``roofline``: the dominant kernel family is the fp32 MFMA
-implicit-GEMM conv; its north-star instance (3x3, 16->16 channels, 1024^2, batch 32) is timed with
-device events on the launch stream and priced with its algorithmic FLOPs 2*9*16*16*1024^2*32.
-``cpu_baseline``: the CPU oracle's (oracle/, kind "port") G+D step on the host cores at a reduced
-batch - a reported baseline, not a target.
+Default (= --config 3): images/sec of the full G+D step (1 D-iteration + 1 G-iteration), StyleGAN 1024^2, batch 32
+per GPU, fp32, nonsaturating loss + R1 (lambda 10) + drift, stabilised phase at the final resolution, synthetic
+FFHQ-shaped data resident in HBM.
+  --config 2: StyleGAN 128^2, batch 8, bf16-compute convolutions (fp32 storage / masters), same losses.
+  --config 4: ProGAN 256^2: the FULL 4 -> 256 fade-in schedule runs first through ``learner.train()`` (shortened
+              ``nimg_transition``, stated; its wall time is reported as ``schedule_seconds``), then K main iterations
+              of the stabilised 256^2 phase are timed (WGAN + WGAN-GP + drift, batch 32).
+  --config 5: ResNet GAN 64^2, batch 64, WGAN + WGAN-GP; a step = one main iteration = 1 G + 5 critic iterations.
+
+Prints ONE JSON line on rank 0.
+``roofline``: the dominant kernel family is the MFMA implicit-GEMM 3x3 conv; the configuration's north-star instance
+is timed with device events on the launch stream INSIDE the timed steps and priced with its algorithmic FLOPs
+(2*9*Cin*Cout*H*W*B); ``kernel`` / ``grid`` are read back from the library (the symbol that was dispatched).
+``executed_tflops_step`` / ``frac_of_mfma_peak_step``: convolution FLOPs the step actually EXECUTES (counted in the
+launchers) per second, over the MFMA peak of the compute dtype; ``algorithmic_tflops_step`` prices the same step at
+the reference's pass count and is a label, not a roofline fraction.
+``cpu_baseline``: the CPU oracle's (oracle/, kind "port") G+D step of the same network on the host cores at a reduced
+batch, 1 warm-up + 3 timed steps, median - a reported baseline, not a target.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TFLOP_PER_IMAGE = {1024: 1.536, 128: 0.752}      # 4 G passes + 14 D passes
+# 4 G passes + 14 D passes per image and G+D step, algorithmic (reference pass count)
+ALGO_TFLOP_PER_IMAGE = {('stylegan', 1024): 1.536, ('stylegan', 128): 0.752, ('progan', 256): 1.013}
 PEAK_F32_MFMA_TFLOPS = 157.3                     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2
 PEAK_BF16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF, no sparsity)
 
@@ -30,31 +44,56 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: dense bf
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=3)
+    p.add_argument('--steps', type=int, default=None)
     p.add_argument('--warmup', type=int, default=1)
-    p.add_argument('--res', type=int, default=1024)
-    p.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    p.add_argument('--config', type=int, choices=(2, 3, 4, 5), default=3, help='BASELINE.json configuration (3 = headline)')
+    p.add_argument('--res', type=int, default=None, help='override the resolution (StyleGAN configs)')
+    p.add_argument('--batch', type=int, default=None, help='override the per-GPU batch')
+    p.add_argument('--dtype', choices=('f32', 'bf16'), default=None,
+                   help="compute dtype of the 3x3 convolutions (config 2 defaults to bf16)")
+    p.add_argument('--nimg-transition', type=int, default=4096, help='config 4: images per phase of the schedule')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-baseline-res', type=int, default=None)
     p.add_argument('--cpu-baseline-batch', type=int, default=1)
+    p.add_argument('--cpu-baseline-steps', type=int, default=3)
     p.add_argument('--no-roofline', action='store_true')
-    p.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
-                   help="compute dtype of the 3x3 convolutions; 'bf16' = BASELINE config #2 (use with --res 128 --batch 8)")
-    return p.parse_args()
+    a = p.parse_args()
+    dflt = {2: ('stylegan', 128, 8, 'bf16', 20), 3: ('stylegan', 1024, 32, 'f32', 3), 4: ('progan', 256, 32, 'f32', 10),
+            5: ('resnetgan', 64, 64, 'f32', 5)}[a.config]
+    a.model = dflt[0]
+    a.res = a.res or dflt[1]
+    a.batch = a.batch or dflt[2]
+    a.dtype = a.dtype or dflt[3]
+    a.steps = a.steps or dflt[4]
+    return a
 
 
-def build_learner(res, batch, device, dtype='f32'):
-    from gan_lab_amd.config import make_config
-    from gan_lab_amd.stylegan.learner import StyleGANLearner
-    bs_dict = {r: batch for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
-    cfg = make_config('stylegan', dev='cuda', pin_memory=False, loss='nonsaturating', gradient_penalty='r1',
-                      lda=10., res_samples=res, res_dataset=res, init_res=res, batch_size=batch, bs_dict=bs_dict,
-                      num_iters_save_model=10 ** 9, log_every=0, compute_dtype=dtype,
-                      cutoff_trunc_trick=4 if res >= 64 else None)
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
+def _quiet(fn, *a, **k):
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        learner = StyleGANLearner(cfg)
+        return fn(*a, **k)
+
+
+def build_learner(res, batch, device, dtype='f32', model='stylegan', seed=1234, **extra):
+    """Stabilised-phase learner at the final resolution (StyleGAN: nonsaturating + R1; ProGAN: WGAN + WGAN-GP)."""
+    from gan_lab_amd.config import make_config
+    bs_dict = {r: batch for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)}
+    common = dict(dev='cuda', pin_memory=False, res_samples=res, res_dataset=res, batch_size=batch, bs_dict=bs_dict,
+                  num_iters_save_model=10 ** 9, log_every=0, compute_dtype=dtype, random_seed=seed)
+    common.update(extra)
+    if model == 'stylegan':
+        from gan_lab_amd.stylegan.learner import StyleGANLearner
+        cfg = make_config('stylegan', loss='nonsaturating', gradient_penalty='r1', lda=10., init_res=res,
+                          cutoff_trunc_trick=4 if res >= 64 else None, **common)
+        learner = _quiet(StyleGANLearner, cfg)
+    else:
+        from gan_lab_amd.progan.learner import ProGANLearner
+        common.setdefault('init_res', res)
+        learner = _quiet(ProGANLearner, make_config('progan', **common))
     learner.beta = learner.get_smoothing_ewma_beta(half_life=10.)
     learner.gen_model.train()
     learner.disc_model.train()
@@ -69,19 +108,79 @@ def one_step(learner, real):
     return ld, lg
 
 
-def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32', c=None, r=None):
-    """Average launch duration of one 3x3 conv kernel instance (default: the north-star layer of the top resolution),
-    device events on the launch stream."""
-    from gan_lab_amd import ops
-    if c is None:
-        c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
-    res = r or res
+class Workload(object):
+    """What a 'step' is for one BASELINE configuration, and which conv instance its roofline prices."""
+
+    def __init__(self, a, torch):
+        self.a, self.torch = a, torch
+        self.extra = {}
+        m, res, b = a.model, a.res, a.batch
+        if m == 'stylegan':
+            self.learner = build_learner(res, b, 'cuda', a.dtype, 'stylegan')
+            self.real = torch.rand(b, 3, res, res, device='cuda') * 2 - 1
+            c = 16 if res >= 1024 else max(16, min(512, 8192 // (res // 2)))
+            self.northstar = (b, c, res)              # the top-resolution 3x3 conv (the "modulated conv" of the north star)
+            self.images_per_step = b
+            self.what = (f'StyleGAN res_samples={res} FFHQ-shaped synthetic, bs={b}/GPU '
+                         f'{"fp32" if a.dtype == "f32" else "bf16 compute / fp32 storage+master"}, nonsaturating + '
+                         f'R1(lambda=10) + drift, stabilised phase, 1 D-iter + 1 G-iter')
+        elif m == 'progan':
+            from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+            nimg = a.nimg_transition
+            self.learner = build_learner(res, b, 'cuda', a.dtype, 'progan', init_res=4, nimg_transition=nimg)
+            dl = SyntheticImageLoader(1 << 22, b, 4, device='cuda')
+            n_phases = 1 + 2 * (len(bin(res)) - len(bin(4)))          # 4 stab, then fade + stab per doubling
+            iters = n_phases * ((nimg + b * a.world - 1) // (b * a.world)) + 8
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _quiet(self.learner.train, dl, num_main_iters=iters)
+            torch.cuda.synchronize()
+            L = self.learner
+            assert L.gen_model.curr_res == res and not L.gen_model.fade_in_phase, (L.gen_model.curr_res, L.gen_model.alpha)
+            self.extra = {'schedule_seconds': round(time.perf_counter() - t0, 2), 'schedule_iterations': iters,
+                          'schedule': f'4 -> {res}, nimg_transition={nimg}, bs={b}/GPU at every resolution'}
+            self.real = torch.rand(b, 3, res, res, device='cuda') * 2 - 1
+            self.northstar = (b, max(16, min(512, 8192 // (res // 2))), res)
+            self.images_per_step = b
+            self.what = (f'ProGAN res_samples={res} CelebA-HQ-shaped synthetic, bs={b}/GPU fp32, WGAN + WGAN-GP + drift; '
+                         f'full 4->{res} fade-in schedule through learner.train() first (schedule_seconds), then the '
+                         f'stabilised {res}^2 phase timed, 1 D-iter + 1 G-iter')
+        else:
+            from gan_lab_amd.config import make_config
+            from gan_lab_amd.resnetgan.learner import GANLearner
+            from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+            cfg = make_config('resnetgan', dev='cuda', pin_memory=False, batch_size=b, res_samples=res, res_dataset=res,
+                              num_iters_save_model=10 ** 9, log_every=0, random_seed=1234)
+            self.learner = _quiet(GANLearner, cfg)
+            self.dl = SyntheticImageLoader(1 << 22, b, res, device='cuda')
+            self.nd = cfg.num_disc_iters
+            self.northstar = (b, 64, res)             # the residual blocks' 64 -> 64 3x3 conv at the top resolution
+            self.images_per_step = b * self.nd        # real images consumed per main iteration
+            self.what = (f'ResNet GAN {res}x{res} LSUN-shaped synthetic, bs={b}/GPU fp32, WGAN + WGAN-GP, one main '
+                         f'iteration = 1 G-iter + {self.nd} critic iters (learner.train())')
+
+    def step(self):
+        if self.a.model == 'resnetgan':
+            _quiet(self.learner.train, self.dl, num_main_iters=1)
+            ll = self.learner.last_losses if self.learner.log_every else {}
+            return ll.get('loss_d'), ll.get('loss_g')
+        return one_step(self.learner, self.real)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ------------------------------------------------------------------------------------------------------------------
+def measure_dominant_kernel(torch, batch, c, res, reps=5):
+    """Average launch duration of one 3x3 conv instance in an isolated loop (device events on the launch stream) and
+    the symbol / grid the library dispatched for it."""
+    from gan_lab_amd import _lib, ops
     x = torch.randn(batch, c, res, res, device='cuda')
     w = torch.randn(c, c, 3, 3, device='cuda')
     g = ops.Geom(batch, c, res, res, c, 3, 1, 0)
     bf = g.bf is not None
     for _ in range(2):
         ops.k_conv_fwd(x, w, None, g, 0.05)
+    kernel, grid = _lib.last_launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -93,19 +192,16 @@ def measure_dominant_kernel(torch, batch, res, reps=5, dtype='f32', c=None, r=No
     flops = 2.0 * 9 * c * c * res * res * batch
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(ach / peak, 4),
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-            # passes) on this kernel, profiles/r01g_northstar_conv_pmc.csv: 2.55e9 read (1.19x the algorithmic 2 GiB:
-            # the 8-of-72 column halo and the strip-boundary rows that miss L2) + 2.17e9 written;
-            # profiles/r01d_northstar_conv_pmc.csv: MFMA pipes busy 0.79-0.80 of the kernel's cycles
-            'traffic': 4.722e9 if (c == 16 and res == 1024 and batch == 32 and not bf) else None,
-            'kernel': (f'conv_fwd_bf16_kernel<64co x 8x32> {c}->{c} @{res}^2 x{batch}' if bf else
-                       f'conv_fwd_roll_kernel<KS=3,16co,64px column strips,4 rows/step> {c}->{c} @{res}^2 x{batch}'
-                       if (c <= 16 and res % 64 == 0) else
-                       f'conv_fwd_kernel<KS=3,MB={1 if c <= 16 else (2 if c <= 32 else 4)},32x8> '
-                       f'{c}->{c} @{res}^2 x{batch}'),
-            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
+    out = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+           'traffic': None, 'kernel': kernel, 'grid': grid, 'instance': f'3x3 {c}->{c} @{res}^2 x{batch}',
+           'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
+    if (c, res, batch, bf) == (16, 1024, 32, False):
+        # HBM bytes per launch of THIS kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # separate passes): 2.55e9 read (1.19x the algorithmic 2 GiB: column halo + strip-boundary rows) + 2.17e9
+        # written.  Not re-measured inside this run - the source file is named.
+        out['traffic'] = 4.722e9
+        out['traffic_source'] = 'profiles/r01g_northstar_conv_pmc.csv'
+    return out
 
 
 class InSituKernelTimer(object):
@@ -119,17 +215,20 @@ class InSituKernelTimer(object):
         self._orig = None
 
     def _match(self, g):
-        return (g.N, g.Cin, g.Hin, g.Win, g.Cout, g.ks, g.pad, g.up, g.pool) == self.key and not g.s2 and g.bf is None
+        return (g.N, g.Cin, g.Hin, g.Win, g.Cout, g.ks, g.pad, g.up, g.pool) == self.key and not g.s2
 
     def __enter__(self):
         ops, torch = self.ops, self.torch
         f0, d0 = self._orig = (ops.k_conv_fwd, ops.k_conv_dgrad)     # whatever is installed now: timers nest
 
+        def prepack(w, mode, scale, g):
+            (ops._packed_bf16(w, mode, scale) if g.bf is not None else ops._packed(w, mode, scale))
+
         def fwd(x, w, bias, g, *a, **k):
             if not self._match(g):
                 return f0(x, w, bias, g, *a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ops._packed(w, ops.PACK_FWD, a[0] if a else k['scale'])     # keep the (cached) weight packing out of the bracket
+            prepack(w, ops.PACK_FWD, a[0] if a else k['scale'], g)    # keep the (cached) weight packing out of the bracket
             e0.record()
             y = f0(x, w, bias, g, *a, **k)
             e1.record()
@@ -140,7 +239,7 @@ class InSituKernelTimer(object):
             if not self._match(g):
                 return d0(gy, w, g, scale)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ops._packed(w, ops.PACK_DGRAD, scale)
+            prepack(w, ops.PACK_DGRAD, scale, g)
             e0.record()
             gx = d0(gy, w, g, scale)
             e1.record()
@@ -161,18 +260,74 @@ class InSituKernelTimer(object):
         return sum(ts) / len(ts), len(ts)
 
 
-def cpu_baseline(torch, res, batch):
-    """The oracle's G+D step (same math, same loss config) on the host cores; bounded sample."""
+class FlopCounter(object):
+    """Convolution FLOPs the timed steps execute, by pass kind (gan_lab_amd.ops launch observer)."""
+
+    def __init__(self, ops):
+        self.ops, self.by_kind, self.launches = ops, {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}, 0
+
+    def __call__(self, kind, g):
+        self.by_kind[kind] += self.ops.conv_flops(g)
+        self.launches += 1
+
+    def __enter__(self):
+        self._prev = self.ops.set_launch_observer(self)
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.set_launch_observer(self._prev)
+        return False
+
+    @property
+    def total(self):
+        return sum(self.by_kind.values())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, on the host cores)
+# ------------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    """(model name, physical cores, logical cpus) from /proc/cpuinfo."""
+    model, cores, logical = None, set(), 0
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'processor':
+                logical += 1
+            elif k == 'model name' and model is None:
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    n_phys = len(cores) or max(1, logical // 2)
+    return model or 'unknown', min(n_phys, usable), usable
+
+
+def cpu_baseline(torch, res, batch, steps=3):
+    """The oracle's G+D step (same math, same loss config) on the host cores: 1 warm-up + ``steps`` timed, median."""
     from gan_lab_amd import progressive as P
     from gan_lab_amd.progan.architectures import StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
     from oracle import nets, step
+    import numpy as np
+    model, n_phys, usable = host_cpu()
+    torch.set_num_threads(n_phys)
     torch.manual_seed(0)
     P.StyleGAN.reset_state()
     g = StyleGenerator(final_res=res, blur_type='binomial',
                        truncation_trick_params={'beta': .995, 'psi': .7, 'cutoff_stage': 4 if res >= 64 else None})
     d = StyleDiscriminator(final_res=res, blur_type='binomial')
-    import numpy as np
     for _ in range(int(np.log2(res)) - 2):
         g.increase_scale()
         d.increase_scale()
@@ -182,15 +337,22 @@ def cpu_baseline(torch, res, batch):
     L = nets.stylegen_num_layers(gan.g)
     noise = lambda: [torch.randn(batch, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2)) for n in range(L)]  # noqa: E731
     real = torch.rand(batch, 3, res, res) * 2 - 1
-    t0 = time.perf_counter()
-    gan.d_step(torch.randn(batch, 512), real, noise())
-    gan.g_step(torch.randn(batch, 512), noise(), beta=0.999)
-    dt = time.perf_counter() - t0
-    return {'value': round(batch / dt, 5), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 G+D step of StyleGAN {res}^2 at batch {batch} (oracle/step.py FunctionalGAN, torch CPU '
-                      f'fp32, {torch.get_num_threads()} threads), {dt:.1f} s'}
+    times = []
+    for i in range(1 + steps):
+        t0 = time.perf_counter()
+        gan.d_step(torch.randn(batch, 512), real, noise())
+        gan.g_step(torch.randn(batch, 512), noise(), beta=0.999)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times[1:])
+    return {'value': round(batch / med, 5), 'unit': 'images/sec', 'cores': n_phys, 'kind': 'port',
+            'cpu_model': model, 'logical_cpus': usable, 'torch_threads': torch.get_num_threads(),
+            'step_seconds': [round(t, 2) for t in times],
+            'sample': f'G+D step of StyleGAN {res}^2 at batch {batch} (oracle/step.py FunctionalGAN, torch CPU fp32, '
+                      f'{n_phys} threads = physical cores of {model}): 1 warm-up + {steps} timed steps, median '
+                      f'{med:.1f} s'}
 
 
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
     import torch
@@ -198,6 +360,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    a.world = world
     use_dist = world > 1 or os.environ.get('GANLAB_DIST_WORLD1') == '1'   # the knob: RCCL path on one rank
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -208,14 +371,11 @@ def main():
         torch.cuda.set_device(0)
     if a.gpus != world and rank == 0 and world > 1:
         print(f'warning: --gpus {a.gpus} but WORLD_SIZE={world}', file=sys.stderr)
-    from gan_lab_amd import _lib, rng
+    from gan_lab_amd import _lib, ops as _ops
     _lib.lib()
-    rng.manual_seed(1234, rank)
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234 + rank)      # parameter init differs per rank on purpose: rank 0's values are broadcast
 
-    learner = build_learner(a.res, a.batch, 'cuda', a.dtype)
-    # synthetic FFHQ-shaped reals, resident in HBM before the timed region: U(-1,1) fp32 (B,3,R,R)
-    real = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
+    wl = Workload(a, torch)             # builds the learner (device RNG seeded from config.random_seed + rank)
 
     def barrier():
         if use_dist:
@@ -223,51 +383,53 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        one_step(learner, real)
-    from gan_lab_amd import ops as _ops
-    ns_c = 16 if a.res >= 1024 else max(16, min(512, 8192 // (a.res // 2)))
-    insitu = InSituKernelTimer(torch, _ops, a.batch, ns_c, a.res)
-    insitu_top = InSituKernelTimer(torch, _ops, a.batch, 256, 64)      # the kernel with the largest share of the step
+        wl.step()
+    nb, nc, nr = wl.northstar
+    insitu = InSituKernelTimer(torch, _ops, nb, nc, nr)
+    insitu_top = InSituKernelTimer(torch, _ops, a.batch, 256, 64)      # config 3: the kernel with the largest share
+    flops = FlopCounter(_ops)
     barrier()
     t0 = time.perf_counter()
-    with insitu, insitu_top:
+    with insitu, insitu_top, flops:
         for _ in range(a.steps):
-            ld, lg = one_step(learner, real)
+            ld, lg = wl.step()
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ld, lg = float(ld), float(lg)
+    ld, lg = (float(ld) if ld is not None else None), (float(lg) if lg is not None else None)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
     if rank == 0:
-        ips = world * a.batch * a.steps / dt
+        ips = world * wl.images_per_step * a.steps / dt
+        peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        exec_tflops = flops.total / dt / 1e12      # this rank's executed conv FLOPs per second
+        algo = ALGO_TFLOP_PER_IMAGE.get((a.model, a.res))
+        name = {'stylegan': 'StyleGAN', 'progan': 'ProGAN', 'resnetgan': 'ResNetGAN'}[a.model]
         out = {
-            'metric': 'images/sec (G+D step), StyleGAN 1024^2 bs32/GPU' if a.res == 1024 and a.batch == 32 else
-                      f'images/sec (G+D step), StyleGAN {a.res}^2 bs{a.batch}/GPU',
+            'metric': f'images/sec (G+D step), {name} {a.res}^2 bs{a.batch}/GPU',
             'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': f'StyleGAN res_samples={a.res} FFHQ-shaped synthetic, bs={a.batch}/GPU '
-                                   f'{"fp32" if a.dtype == "f32" else "bf16 compute / fp32 storage+master"}, '
-                                   f'nonsaturating + R1(lambda=10) + drift, stabilised phase, 1 D-iter + 1 G-iter',
-                       'global_batch': world * a.batch, 'per_gpu_batch': a.batch,
-                       'parallelism': f'dp{world}' if world > 1 else 'single'},
-            'achieved_tflops_step': round(ips * TFLOP_PER_IMAGE.get(a.res, 0.0), 2) if a.res in TFLOP_PER_IMAGE
-            else None,
-            'frac_of_mfma_peak_step': round(
-                ips * TFLOP_PER_IMAGE[a.res] /
-                ((PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS) * world), 4)
-            if a.res in TFLOP_PER_IMAGE else None,
+            'config': {'workload': wl.what, 'baseline_config': a.config, 'global_batch': world * a.batch,
+                       'per_gpu_batch': a.batch, 'parallelism': f'dp{world}' if world > 1 else 'single'},
+            # executed: what the launchers ran (per GPU) over the MFMA peak of one GPU - a roofline fraction of the step
+            'executed_tflops_step': round(exec_tflops, 2),
+            'frac_of_mfma_peak_step': round(exec_tflops / peak, 4),
+            'executed_conv_tflop_per_step': round(flops.total / a.steps / 1e12, 3),
+            'executed_conv_tflop_by_pass': {k: round(v / a.steps / 1e12, 3) for k, v in flops.by_kind.items()},
+            'conv_launches_per_step': flops.launches // a.steps,
+            # algorithmic: the reference's pass count (4 G + 14 D conv passes) - NOT a roofline fraction:
+            # the implementation executes fewer FLOPs (stride-2 fusion, shared D(real), no discarded weight gradients)
+            'algorithmic_tflops_step': round(ips / world * algo, 2) if algo else None,
             'loss_d': ld, 'loss_g': lg, 'peak_mem_gib': round(peak_mem, 1),
         }
-    del learner, real
+        out.update(wl.extra)
+    del wl
     torch.cuda.empty_cache()
     if rank == 0:
-        out['roofline'] = None if a.no_roofline else measure_dominant_kernel(torch, a.batch, a.res, dtype=a.dtype)
-        torch.cuda.empty_cache()
         def with_insitu(r, timer):
             ms_t, n_t = timer.mean_ms()
             if r is not None and ms_t is not None:
@@ -277,20 +439,24 @@ def main():
                 r['frac'] = round(r['achieved'] / r['peak'], 4)
                 r['launches_timed_in_step'] = n_t
             return r
-        # the same kernel instance as launched INSIDE the timed steps (device events around each launch, forward and
-        # input gradient): the figure rocprofv3's per-kernel average of the step agrees with; the isolated loop
-        # (2 warm-up + 5 launches on a cold chip) is kept beside it as isolated_*
-        out['roofline'] = with_insitu(out['roofline'], insitu)
-        if not a.no_roofline and a.res == 1024 and a.dtype == 'f32':
-            # the kernel with the largest share of the step (profiles/r01c_step_kernel_stats.csv: conv_fwd_kernel
-            # <KS=3,MB=4,32x8>, 15.6% of the step, the 64..512-channel stride-1 layers): its 256->256 @64^2 instance
-            out['roofline_top_kernel_by_time'] = with_insitu(
-                measure_dominant_kernel(torch, a.batch, a.res, c=256, r=64), insitu_top)
-            out['roofline_top_kernel_by_time']['traffic'] = None
+        # the instance as launched INSIDE the timed steps (device events around each launch, forward and input
+        # gradient): the figure rocprofv3's per-kernel average of the step agrees with; the isolated loop (2 warm-up +
+        # 5 launches on a cold chip) is kept beside it as isolated_*
+        with _ops.compute_dtype(a.dtype):
+            out['roofline'] = None if a.no_roofline else with_insitu(measure_dominant_kernel(torch, nb, nc, nr), insitu)
+        torch.cuda.empty_cache()
+        if not a.no_roofline and a.config == 3 and a.res == 1024:
+            # the kernel with the largest share of the step (profiles/*_step_kernel_stats.csv: conv_fwd_kernel
+            # <KS=3,MB=4,32x8>, the 64..512-channel stride-1 layers): its 256->256 @64^2 instance
+            out['roofline_top_kernel_by_time'] = with_insitu(measure_dominant_kernel(torch, a.batch, 256, 64), insitu_top)
             torch.cuda.empty_cache()
-        if world == 1 and not a.no_cpu_baseline:
-            cres = a.cpu_baseline_res or a.res
-            out['cpu_baseline'] = cpu_baseline(torch, cres, a.cpu_baseline_batch)
+        if world == 1 and not a.no_cpu_baseline and a.model == 'stylegan':
+            out['cpu_baseline'] = cpu_baseline(torch, a.cpu_baseline_res or a.res, a.cpu_baseline_batch,
+                                               a.cpu_baseline_steps)
+        elif world == 1 and not a.no_cpu_baseline:
+            # configs 4 / 5: the oracle step of the headline network is the one CPU yardstick this file carries
+            out['cpu_baseline'] = None
+            out['cpu_baseline_note'] = 'timed for the StyleGAN configurations only (oracle/step.py FunctionalGAN)'
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -34,6 +34,8 @@ _GP = ctypes.POINTER(ConvGeom)
 # name -> (restype, argtypes): must list every function declared in include/ganlab_hip.h
 SIGNATURES = {
     'ganlab_abi_version': (_c_int, []),
+    'ganlab_last_launch': (_c_int, [ctypes.c_char_p, _c_int, ctypes.POINTER(ctypes.c_uint)]),
+    'ganlab_conv_geom_size': (_c_int, []),
     'ganlab_conv_out_hw': (_c_int, [_GP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'ganlab_conv_pack_f32': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_conv_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
@@ -157,8 +159,19 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
+        if handle.ganlab_conv_geom_size() != ctypes.sizeof(ConvGeom):
+            raise GanlabLibraryError(f'ConvGeom mirror is {ctypes.sizeof(ConvGeom)} bytes, the library\'s '
+                                     f'ganlab_conv_geom {handle.ganlab_conv_geom_size()}: header and binding disagree')
         _LIB = handle
     return _LIB
+
+
+def last_launch():
+    """(demangled kernel symbol, workgroups) of this thread's most recent launch through the library."""
+    buf = ctypes.create_string_buffer(1024)
+    grid = ctypes.c_uint(0)
+    n = lib().ganlab_last_launch(buf, 1024, ctypes.byref(grid))
+    return (buf.value.decode() if n > 0 else None), int(grid.value)
 
 
 _ERR = {-1: 'GANLAB_EINVAL (bad argument)', -2: 'GANLAB_EWORKSPACE (workspace too small)',

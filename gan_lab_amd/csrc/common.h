@@ -12,10 +12,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // before each launch and sampled right after it; the per-thread status is collected by
 // GL_CHECK_LAUNCH() at the end of the entry point.
 static thread_local int gl_launch_status = GANLAB_OK;
-#define GL_LAUNCH(...)                                                           \
+// Diagnostic record of this thread's most recent launch (symbol + workgroup count), read back by
+// ganlab_last_launch(): bench.py names the kernel it prices from what was actually dispatched.
+extern thread_local const void* gl_last_kernel_fn;
+extern thread_local unsigned gl_last_grid;
+#define GL_LAUNCH(k, grid, ...)                                                  \
   do {                                                                           \
     (void)hipGetLastError();                                                     \
-    hipLaunchKernelGGL(__VA_ARGS__);                                             \
+    const dim3 gl_grid_ = (grid);                                                \
+    gl_last_kernel_fn = reinterpret_cast<const void*>(k);                        \
+    gl_last_grid = gl_grid_.x * gl_grid_.y * gl_grid_.z;                         \
+    hipLaunchKernelGGL(k, gl_grid_, __VA_ARGS__);                                \
     if (hipGetLastError() != hipSuccess) gl_launch_status = GANLAB_ELAUNCH;      \
   } while (0)
 static inline int gl_take_status() {

@@ -24,6 +24,13 @@
 // LDS strides are padded so the two k-halves of a 32-lane read group land on disjoint banks.
 #include "common.h"
 
+#include <cxxabi.h>
+#include <stdlib.h>
+#include <string.h>
+
+thread_local const void* gl_last_kernel_fn = nullptr;
+thread_local unsigned gl_last_grid = 0;
+
 namespace {
 
 constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
@@ -1786,6 +1793,25 @@ extern "C" int ganlab_dbg_set_phase_buf(void* buf) {
 
 
 extern "C" {
+
+int ganlab_last_launch(char* name, int cap, unsigned* grid) {
+  if (grid) *grid = gl_last_grid;
+  if (gl_last_kernel_fn == nullptr) return 0;
+  const char* mangled = hipKernelNameRefByPtr(gl_last_kernel_fn, nullptr);
+  if (mangled == nullptr) return 0;
+  int status = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  const char* s = (status == 0 && dem) ? dem : mangled;
+  const int n = (int)strlen(s);
+  if (name && cap > 0) {
+    strncpy(name, s, (size_t)cap - 1);
+    name[cap - 1] = 0;
+  }
+  free(dem);
+  return n;
+}
+
+int ganlab_conv_geom_size(void) { return (int)sizeof(ganlab_conv_geom); }
 
 int ganlab_conv_out_hw(const ganlab_conv_geom* g, int* Hout, int* Wout) {
   if (!geom_ok(g)) return GANLAB_EINVAL;

@@ -219,6 +219,32 @@ def _want_param_grads():
     return not _INPUT_GRAD_ONLY[0]
 
 
+# ---- launch observer (measurement only) -------------------------------------------------------------
+# bench.py / tools/step_layers.py count the convolution FLOPs the step actually EXECUTES (stride-2 fused layers run
+# 16 low-resolution taps instead of 4 x 9, the shared D(real) forward and the skipped weight gradients never launch)
+# by registering a callable here; every conv launcher reports (kind, Geom) to it.  None = no overhead.
+_OBSERVER = [None]
+
+
+def set_launch_observer(fn):
+    prev = _OBSERVER[0]
+    _OBSERVER[0] = fn
+    return prev
+
+
+def conv_flops(g):
+    """FLOPs one pass (forward, input gradient or weight gradient) over geometry ``g`` executes in this library."""
+    if g.s2:
+        lo_h, lo_w = (g.Hin, g.Win) if g.up else (g.Ho, g.Wo)
+        return 2.0 * 16 * g.Cin * g.Cout * lo_h * lo_w * g.N
+    return 2.0 * g.ks * g.ks * g.Cin * g.Cout * g.Ho * g.Wo * g.N
+
+
+def _note(kind, g):
+    if _OBSERVER[0] is not None:
+        _OBSERVER[0](kind, g)
+
+
 # ---------------------------------------------------------------------------------------------- #
 # kernel launchers
 # ---------------------------------------------------------------------------------------------- #
@@ -226,6 +252,7 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
     x, w = _c(x, 'conv input'), _c(w, 'conv weight')
     assert tuple(x.shape) == g.in_shape, (tuple(x.shape), g.in_shape)
     assert tuple(w.shape) == (g.Cout, g.Cin, g.ks, g.ks), (tuple(w.shape), g.Cout, g.Cin, g.ks)
+    _note('fwd', g)
     if bias is not None:
         bias = _c(bias, 'bias')
         assert bias.numel() == g.Cout
@@ -247,7 +274,11 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         # weight-gradient contraction with k as the pixel axis, x as a (1, N, k) "output gradient" and w as a
         # (1, Cout, k) "input" - no copies - and that kernel splits the pixel axis over ~1024 workgroups.
         g2 = Geom(1, g.Cout, g.Cin // 128, 128, g.N, 1, 0)
-        y = k_conv_wgrad(x.view(g2.out_shape), w.view(g2.in_shape), g2, scale).view(g.out_shape)
+        obs = set_launch_observer(None)          # already reported as this forward
+        try:
+            y = k_conv_wgrad(x.view(g2.out_shape), w.view(g2.in_shape), g2, scale).view(g.out_shape)
+        finally:
+            set_launch_observer(obs)
         if bias is not None or act != ACT_NONE:
             y = k_bias_act(y, bias, None, None, bias_scale, act, slope)
         return y
@@ -266,6 +297,7 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
 def k_conv_dgrad(gy, w, g, scale):
     gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
     assert tuple(gy.shape) == g.out_shape, (tuple(gy.shape), g.out_shape)
+    _note('dgrad', g)
     if g.bf is not None:
         wp = _packed_bf16(w, PACK_DGRAD, scale)
         gxv = _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy)
@@ -300,6 +332,7 @@ def conv_dgrad_mask_ok(g):
 def k_conv_dgrad_mask(gy, w, x, g, scale, slope):
     gy, w, x = _c(gy, 'conv grad_out'), _c(w, 'conv weight'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    _note('dgrad', g)
     gx = torch.empty_like(x)
     check(_lib.lib().ganlab_conv_dgrad_mask_f32(_p(gy), _p(_packed(w, PACK_DGRAD, scale)), _p(x), _p(gx), g.ref(), slope,
                                                 _st()), 'conv_dgrad_mask')
@@ -314,6 +347,7 @@ def conv_act_bwd_fusable(g):
 def k_conv_dgrad_act(gy, y, w, g, scale, slope):
     gy, y, w = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(w, 'conv weight')
     assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape
+    _note('dgrad', g)
     gx = _new(g.in_shape, gy)
     check(_lib.lib().ganlab_conv_dgrad_act_f32(_p(gy), _p(y), _p(_packed(w, PACK_DGRAD, scale)), _p(gx), g.ref(), slope,
                                                _st()), 'conv_dgrad_act')
@@ -323,6 +357,7 @@ def k_conv_dgrad_act(gy, y, w, g, scale, slope):
 def k_conv_fwd_mask(x, w, y, g, scale, slope):
     x, y, w = _c(x, 'conv input'), _c(y, 'conv output'), _c(w, 'conv weight')
     assert tuple(x.shape) == g.in_shape and tuple(y.shape) == g.out_shape
+    _note('fwd', g)
     out = torch.empty_like(y)
     check(_lib.lib().ganlab_conv_fwd_mask_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), _p(y), _p(out), g.ref(), slope,
                                               _st()), 'conv_fwd_mask')
@@ -332,6 +367,7 @@ def k_conv_fwd_mask(x, w, y, g, scale, slope):
 def k_conv_wgrad_act(gy, y, x, g, scale, slope, bias_scale, want_gb):
     gy, y, x = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    _note('wgrad', g)
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     gb = _new((g.Cout,), x) if want_gb else None
@@ -344,6 +380,7 @@ def k_conv_wgrad_act(gy, y, x, g, scale, slope, bias_scale, want_gb):
 def k_conv_wgrad(gy, x, g, scale):
     gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    _note('wgrad', g)
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     if g.bf is not None:

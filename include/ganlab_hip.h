@@ -39,6 +39,11 @@ extern "C" {
 
 int ganlab_abi_version(void);
 
+/* Diagnostic (no reference counterpart): demangled symbol and workgroup count of the calling thread's most recent
+ * kernel launch made by this library.  Returns the symbol's length (it is truncated to cap-1 characters), 0 when
+ * nothing was launched yet.  bench.py uses it to name the kernel its `roofline` prices from what was dispatched. */
+int ganlab_last_launch(char* name, int cap, unsigned* grid);
+
 /* Geometry of one convolution C(x, w) = scale * conv2d(up2?(x), w, stride 1, padding pad).
  * Replaces Conv2dEx.forward / LinearEx.forward (utils/custom_layers.py:202-211, :282-291) with the
  * eq-LR runtime scale folded into `scale` (the reference multiplies the input, :204), and the
@@ -50,6 +55,9 @@ typedef struct {
   int up;               /* 1: input is nearest-upsampled 2x on the fly                   */
   int pool;             /* 1: output is 2x2 average-pooled (ganlab_conv_s2_* entry points only) */
 } ganlab_conv_geom;
+
+/* sizeof(ganlab_conv_geom) as this library was compiled: a binding asserts its mirror struct against it once. */
+int ganlab_conv_geom_size(void);
 
 /* Output spatial size of a geometry: Hout = (up ? 2*Hin : Hin) + 2*pad - ks + 1. */
 int ganlab_conv_out_hw(const ganlab_conv_geom* g, int* Hout, int* Wout);

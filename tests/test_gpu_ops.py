@@ -838,3 +838,36 @@ def test_full_size_resampling_ops_adjoint_identities(ops):
     xi[:, :, 1:-1, 1:-1] = x[:, :, 1:-1, 1:-1]          # zero border: no mass leaves through the zero padding
     sb, s0 = ops.blur(xi).double().sum().item(), xi.double().sum().item()
     assert abs(sb - s0) <= 1e-6 * xi.double().abs().sum().item()
+
+
+def test_integration_snippet_forward_vs_oracle(ops):
+    """INTEGRATION.md's documented binding, executed verbatim through raw ctypes (no gan_lab_amd.ops in between), on a
+    stand-in for the reference's ``Conv2dEx`` (utils/custom_layers.py:147-211) - against the oracle's conv2d_ex."""
+    import os
+    import types
+    from oracle import ops as O
+    from test_host_logic import ROOT, integration_snippets
+    load, fwd = integration_snippets()
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(load, 'INTEGRATION.md#1', 'exec'), ns)
+        exec(compile(fwd, 'INTEGRATION.md#2', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    gen = torch.Generator().manual_seed(31)
+    for cin, cout, res, lrmul in ((16, 16, 64, None), (48, 32, 16, 0.5)):
+        x = rnd(gen, 2, cin, res, res)
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(rnd(gen, cout, cin, 3, 3))
+            conv.bias.copy_(rnd(gen, cout))
+        ws = O.conv_wscale(conv.weight, 2.0)
+        layer = types.SimpleNamespace(conv2d=conv.cuda(), equalized_lr=True, wscale=float(ws),
+                                      use_lrmul=lrmul is not None, lrmul=lrmul if lrmul is not None else 1.0)
+        y = ns['conv2d_ex_forward'](layer, gpu(x))
+        torch.cuda.synchronize()
+        ref = O.conv2d_ex(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ws, padding=1,
+                          lrmul=lrmul if lrmul is not None else 1.0)
+        assert_close(y, ref, TOL, f'INTEGRATION.md forward {cin}->{cout}@{res}')

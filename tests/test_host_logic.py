@@ -315,3 +315,36 @@ def test_splitk_and_fusion_plans_host_side():
     assert L.ganlab_conv_dgrad_mask_supported(geom(32, 512, 8, 8, 512)) == 0
     assert L.ganlab_conv_dgrad_mask_supported(geom(32, 32, 512, 512, 32, up=1)) == 0
     assert L.ganlab_conv_dgrad_mask_supported(geom(32, 32, 512, 512, 32, ks=1, pad=0)) == 0
+
+
+def integration_snippets():
+    """The ```python blocks of INTEGRATION.md §1 (load + struct + signatures) and §2 (the forward binding)."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    load = next(b for b in blocks if 'class ConvGeom' in b)
+    fwd = next(b for b in blocks if 'def conv2d_ex_forward' in b)
+    return load, fwd
+
+
+def test_integration_snippet_host_side():
+    """The documented ctypes binding, executed as written (from the repo root, like a maintainer would): the library
+    loads, the mirror struct has the header's size (9 ints - VERDICT r01 #10), the pack size query answers."""
+    load, fwd = integration_snippets()
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(load, 'INTEGRATION.md#1', 'exec'), ns)
+        exec(compile(fwd, 'INTEGRATION.md#2', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    hdr = open(os.path.join(ROOT, 'include', 'ganlab_hip.h')).read()
+    body = re.search(r'typedef struct \{(.*?)\} ganlab_conv_geom;', hdr, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = [f.strip() for part in re.findall(r'int ([^;]+);', body) for f in part.split(',')]
+    assert [n for n, _ in ns['ConvGeom']._fields_] == fields
+    assert ctypes.sizeof(ns['ConvGeom']) == ns['lib'].ganlab_conv_geom_size() == 4 * len(fields)
+    # size query of the packing (no device work): [tap][Cin padded to 16][Cout padded to 64] floats
+    n = ns['lib'].ganlab_conv_pack_f32(None, None, 16, 16, 3, 0, 1.0, None)
+    assert n >= 9 * 16 * 16 and n % 4 == 0
+    assert callable(ns['conv2d_ex_forward'])
