@@ -86,6 +86,156 @@ def moments_from_torch_adam(opt_state_dict, ordered_names):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# writing a file the REFERENCE's load_model accepts (gan_lab/progan/learner.py:1257-1360, stylegan/learner.py:452-640)
+# ---------------------------------------------------------------------------------------------------------------
+class _RefConfig(object):
+    """Pickles as ``_int.LearnerConfigCopy`` (the reference unpickles it without calling its constructor: the state
+    dict goes straight into ``__dict__``)."""
+
+    def __init__(self, state):
+        object.__setattr__(self, '__dict__', dict(state))
+
+
+class _RefIndexedOrderedDict(OrderedDict):
+    """Pickles as ``indexed.IndexedOrderedDict`` in the ``(cls, (items,))`` form both the real package's class and a
+    plain OrderedDict subclass rebuild from."""
+
+    def __reduce__(self):
+        return (self.__class__, ([[k, v] for k, v in self.items()],))
+
+
+_RefConfig.__module__, _RefConfig.__qualname__, _RefConfig.__name__ = '_int', 'LearnerConfigCopy', 'LearnerConfigCopy'
+_RefIndexedOrderedDict.__module__ = 'indexed'
+_RefIndexedOrderedDict.__qualname__ = _RefIndexedOrderedDict.__name__ = 'IndexedOrderedDict'
+
+
+class _foreign_modules(object):
+    """While pickling, ``_int`` / ``indexed`` must resolve to the stand-ins above (pickle verifies that the global it
+    writes is importable); modules already imported under those names (e.g. the real ones) are put back afterwards."""
+
+    def __enter__(self):
+        import sys
+        self._saved = {k: sys.modules.get(k) for k in ('_int', 'indexed')}
+        m1, m2 = types.ModuleType('_int'), types.ModuleType('indexed')
+        m1.LearnerConfigCopy, m2.IndexedOrderedDict = _RefConfig, _RefIndexedOrderedDict
+        sys.modules['_int'], sys.modules['indexed'] = m1, m2
+
+    def __exit__(self, *exc):
+        import sys
+        for k, v in self._saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        return False
+
+
+def torch_adam_state_dict(fused_adam, named_params, ordered_names):
+    """``FusedAdam`` flat-arena moments -> ``torch.optim.Adam.state_dict()`` (state index i = the i-th of
+    ``ordered_names``, the reference's ``most_parameters(...)`` order, progan/learner.py:1064-1095)."""
+    mom = fused_adam.export_moments(named_params)
+    group = dict(fused_adam.param_groups[0])
+    template = torch.optim.Adam([torch.zeros(1, requires_grad=True)], lr=group['lr'], betas=group['betas'],
+                                eps=group['eps'], weight_decay=group['weight_decay']).state_dict()['param_groups'][0]
+    pg = dict(template)
+    pg.update(lr=group['lr'], params=list(range(len(ordered_names))))
+    if 'initial_lr' in group:
+        pg['initial_lr'] = group['initial_lr']
+    state = {}
+    if mom['step'] > 0:
+        for i, name in enumerate(ordered_names):
+            if name in mom['exp_avg']:
+                state[i] = {'step': torch.tensor(float(mom['step'])), 'exp_avg': mom['exp_avg'][name].clone(),
+                            'exp_avg_sq': mom['exp_avg_sq'][name].clone()}
+    return {'state': state, 'param_groups': [pg]}
+
+
+def reference_checkpoint_dict(learner, g_names, d_names, extra=None):
+    """The dict ``ProGANLearner.save_model`` of the reference writes (progan/learner.py:1257-1298; ``extra``: the
+    StyleGAN additions, stylegan/learner.py:455-464), built from a product learner.  Tensors are moved to the CPU;
+    the module-valued fields (``nl``, the resamplers) are the torch modules the reference itself constructs
+    (resnetgan/learner.py:147-184)."""
+    from torch import nn
+    c = learner.config
+    cpu = lambda sd: OrderedDict((k, v.detach().cpu().clone()) for k, v in sd.items())  # noqa: E731
+    cfg_state = {k: v for k, v in vars(c).items()}
+    nl = nn.LeakyReLU(negative_slope=c.leakiness) if c.nonlinearity.casefold() == 'leaky relu' else nn.ReLU()
+    lagged = learner.materialize_lagged_generator() if c.use_ewma_gen else None
+    lagged_params = None
+    if c.use_ewma_gen and learner.lagged_params is not None:
+        lagged_params = _RefIndexedOrderedDict((k, v.detach().cpu().clone()) for k, v in learner.lagged_params.items())
+    n_grid = c.img_grid_sz ** 2
+    valid_z = learner.valid_z if learner.valid_z is not None else torch.zeros(n_grid, c.len_latent)
+    sched = learner.sched_bool and learner.scheduler_gen is not None
+    ck = {
+        'config': _RefConfig(cfg_state),
+        'curr_res': learner.gen_model.curr_res,
+        'alpha': learner.gen_model.alpha,
+        'gen_model_metadata': {'gen_model_upsampler': nn.Upsample(scale_factor=2, mode='nearest'),
+                               'num_classes_gen': learner.num_classes_gen},
+        'gen_model_state_dict': cpu(learner.gen_model.state_dict()),
+        'gen_model_lagged_state_dict': cpu(lagged.state_dict()) if lagged is not None else None,
+        'disc_model_metadata': {'disc_model_downsampler': nn.AvgPool2d(kernel_size=2, stride=2),
+                                'num_classes_disc': learner.num_classes_disc},
+        'disc_model_state_dict': cpu(learner.disc_model.state_dict()),
+        'nl': nl,
+        'sched_stop_step': learner.sched_stop_step,
+        'lr_sched': learner.lr_sched,
+        'scheduler_gen_state_dict': learner.scheduler_gen.state_dict() if sched else None,
+        'scheduler_disc_state_dict': learner.scheduler_disc.state_dict() if sched else None,
+        'optimizer': learner.optimizer,
+        'opt_gen_state_dict': torch_adam_state_dict(learner.opt_gen, list(learner.gen_model.named_parameters()), g_names),
+        'opt_disc_state_dict': torch_adam_state_dict(learner.opt_disc, list(learner.disc_model.named_parameters()),
+                                                     d_names),
+        'loss': learner.loss,
+        'gradient_penalty': learner.gradient_penalty,
+        'batch_size': learner.batch_size,
+        'curr_dataset_batch_num': learner.curr_dataset_batch_num,
+        'curr_epoch_num': learner.curr_epoch_num,
+        'tot_num_epochs': learner.tot_num_epochs,
+        'dataset_sz': getattr(learner, 'dataset_sz', None),
+        'ac': learner.ac, 'cond_gen': learner.cond_gen, 'cond_disc': learner.cond_disc,
+        'valid_z': valid_z.detach().to('cpu'),
+        'valid_label': learner.valid_label,
+        'grid_inputs_constructed': learner.grid_inputs_constructed,
+        'rand_idxs': learner.rand_idxs,
+        'gen_metrics_num': learner.gen_metrics_num,
+        'disc_metrics_num': learner.disc_metrics_num,
+        'curr_img_num': learner.curr_img_num,
+        'nimg_transition_lst': list(learner.sched.nimg_transition_lst) if learner.sched is not None else
+        [learner.config.nimg_transition],
+        'not_trained_yet': learner.not_trained_yet,
+        'ds_mean': learner.ds_mean, 'ds_std': learner.ds_std,
+        'latent_distribution': learner.latent_distribution,
+        'curr_phase_num': learner.curr_phase_num,
+        'lagged_params': lagged_params,
+        'progressively_grow': learner.progressively_grow,
+    }
+    if extra:
+        ck.update(extra)
+    return ck
+
+
+def save_atomic(obj, path, foreign=False):
+    """``torch.save`` to ``path`` through a temporary file in the same directory + ``os.replace`` (a reader never
+    sees a torn file)."""
+    import os
+    path = str(path)
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    tmp = f'{path}.tmp{os.getpid()}'
+    try:
+        if foreign:
+            with _foreign_modules():
+                torch.save(obj, tmp)
+        else:
+            torch.save(obj, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 ARCH_FIELDS = ('model', 'res_samples', 'len_latent', 'blur_type', 'nonlinearity', 'use_equalized_lr', 'normalize_z',
                'use_pixelnorm', 'mbstd_group_size', 'num_classes', 'len_dlatent', 'mapping_num_fcs', 'use_noise',
                'use_instancenorm')

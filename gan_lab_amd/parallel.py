@@ -74,6 +74,12 @@ class GradReducer(object):
         self.finish()
 
 
+def barrier(group=None):
+    """All ranks wait here (no-op for a single process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
 def broadcast_params(flat, src=0, group=None):
     """Make every replica start from rank `src`'s parameters."""
     if is_dist():

@@ -444,9 +444,10 @@ class ProGANLearner(GANLearner):
         except KeyboardInterrupt:
             # progan/learner.py:986-1013: Ctrl-C saves the latest checkpoint before the run ends
             self.set_requires_grad_disc(True)
-            if not self.not_trained_yet and parallel.rank() == 0:
+            if not self.not_trained_yet:
                 self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
-                print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
+                if parallel.rank() == 0:
+                    print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
             raise
         self.set_requires_grad_disc(True)
 
@@ -632,37 +633,85 @@ class ProGANLearner(GANLearner):
         self.gen_model_lagged = g
         return g
 
-    def save_model(self, save_path):
-        """Checkpoint (plain data; key names follow progan/learner.py:1257-1298)."""
-        save_path = str(save_path)
-        os.makedirs(os.path.dirname(save_path) or '.', exist_ok=True)
+    # -- checkpoints ---------------------------------------------------------------------------------------------
+    def _param_name_sets(self):
+        """Names the optimisers cover, in the reference's ``most_parameters`` order (progan/learner.py:1064-1095)."""
+        fade = self.gen_model.fade_in_phase
+        return ([k for k, _ in self.gen_model.named_parameters() if fade or k not in _EXCL_G],
+                [k for k, _ in self.disc_model.named_parameters() if fade or k not in _EXCL_D])
+
+    def _extra_checkpoint_fields(self):
+        """Family-specific additions to the checkpoint dict (StyleGAN: truncation-trick state)."""
+        return {}
+
+    def _restore_extra_fields(self, ck):
+        pass
+
+    def _sched_steps(self):
+        """Main iterations the live LambdaLR has stepped through (a fresh scheduler's ``_step_count`` is 1)."""
+        return max(self.scheduler_gen._step_count - 1, 0) if (self.sched_bool and self.scheduler_gen is not None) else 0
+
+    def save_model(self, save_path, reference_format=False):
+        """Checkpoint.  Default: this package's plain-data format (tensors + builtin types only; key names follow
+        progan/learner.py:1257-1298).  ``reference_format=True``: the dict the reference's own ``save_model`` writes -
+        same key set, ``config`` / ``lagged_params`` pickled under the reference's class names, torch-Adam optimiser
+        state dicts, the ``nl`` / resampler modules - so the reference's ``load_model`` (:1305-1448) reads it
+        (``checkpoint.reference_checkpoint_dict``).  Under data parallelism only rank 0 writes (replicas are identical),
+        through a temporary file + ``os.replace``; every rank waits for the file to be complete."""
+        from .. import checkpoint as ckpt
+        if self.not_trained_yet and reference_format:
+            raise Exception('Please train your model for atleast 1 iteration before saving.')
+        if parallel.rank() == 0:
+            g_names, d_names = self._param_name_sets()
+            if reference_format:
+                ck = ckpt.reference_checkpoint_dict(self, g_names, d_names, extra=self._extra_checkpoint_fields())
+                ckpt.save_atomic(ck, save_path, foreign=True)
+            else:
+                ckpt.save_atomic(self._plain_checkpoint_dict(), save_path)
+        parallel.barrier()
+
+    def _plain_checkpoint_dict(self):
+        cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}  # noqa: E731
         lagged = self.materialize_lagged_generator() if self.config.use_ewma_gen else None
-        torch.save({
+        tcpu = lambda v: None if v is None else v.detach().cpu()  # noqa: E731
+        ck = {
             'config': {k: v for k, v in vars(self.config).items() if not k.startswith('_') and
                        isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))},
             'curr_res': self.gen_model.curr_res,
             'alpha': self.gen_model.alpha,
-            'gen_model_state_dict': {k: v.detach().cpu() for k, v in self.gen_model.state_dict().items()},
-            'disc_model_state_dict': {k: v.detach().cpu() for k, v in self.disc_model.state_dict().items()},
-            'gen_model_lagged_state_dict': None if lagged is None else
-            {k: v.detach().cpu() for k, v in lagged.state_dict().items()},
+            'gen_model_state_dict': cpu(self.gen_model.state_dict()),
+            'disc_model_state_dict': cpu(self.disc_model.state_dict()),
+            'gen_model_lagged_state_dict': None if lagged is None else cpu(lagged.state_dict()),
             'opt_gen_state_dict': self.opt_gen.export_moments(self.gen_model.named_parameters()),
             'opt_disc_state_dict': self.opt_disc.export_moments(self.disc_model.named_parameters()),
-            'batch_size': self.batch_size, 'sched_stop_step': self.sched_stop_step,
+            'batch_size': self.batch_size,
+            # LambdaLR bookkeeping: steps taken by the live scheduler are folded in, so a 'linear decay' schedule resumes
+            # where it stopped (the reference keeps the scheduler state dicts for this, :1249-1252)
+            'sched_stop_step': (self.sched_stop_step or 0) + self._sched_steps() if self.sched_bool else
+            self.sched_stop_step,
+            'lr_sched': self.lr_sched, 'optimizer': self.optimizer,
             'loss': self.loss, 'gradient_penalty': self.gradient_penalty,
             'latent_distribution': self.latent_distribution,
             'curr_dataset_batch_num': self.curr_dataset_batch_num, 'curr_epoch_num': self.curr_epoch_num,
+            'tot_num_epochs': self.tot_num_epochs, 'dataset_sz': getattr(self, 'dataset_sz', None),
             'progressively_grow': self.progressively_grow,
             'curr_img_num': self.curr_img_num,
             'curr_phase_num': self.curr_phase_num,
             'nimg_transition_lst': list(self.sched.nimg_transition_lst) if self.sched else None,
             'not_trained_yet': self.not_trained_yet,
-        }, save_path)
+            'ds_mean': tcpu(self.ds_mean), 'ds_std': tcpu(self.ds_std),
+            'valid_z': tcpu(self.valid_z), 'valid_label': tcpu(self.valid_label), 'rand_idxs': tcpu(self.rand_idxs),
+            'grid_inputs_constructed': self.grid_inputs_constructed,
+            'gen_metrics_num': self.gen_metrics_num, 'disc_metrics_num': self.disc_metrics_num,
+        }
+        ck.update({k: (tcpu(v) if torch.is_tensor(v) else v) for k, v in self._extra_checkpoint_fields().items()})
+        return ck
 
     def load_model(self, load_path, dev_of_saved_model='cpu'):
         """Restore networks (replaying ``increase_scale`` up to the saved resolution, progan/learner.py:
-        1348-1360), EWMA shadow, Adam moments and the phase machine.  Reads this package's plain-data
-        checkpoints AND files written by the reference's own ``save_model`` (``checkpoint.py``)."""
+        1348-1360), EWMA shadow, Adam moments, the phase machine, dataset statistics and validation-grid state.  Reads
+        this package's plain-data checkpoints AND files written by the reference's own ``save_model``
+        (``checkpoint.py``)."""
         from .. import checkpoint as ckpt
         ck = ckpt.load_checkpoint(load_path, dev_of_saved_model)
         ref = ckpt.is_reference_format(ck)
@@ -690,22 +739,34 @@ class ProGANLearner(GANLearner):
                 for k, v in lag.items():
                     if k in self.lagged_params:
                         self.lagged_params[k].copy_(v.to(self.config.dev))
+        self._restore_extra_fields(ck)
         for attr in ('loss', 'gradient_penalty'):
             if ck.get(attr) is not None:
                 setattr(self, attr, ck[attr])
         self._set_optimizer()
-        g_names = [k for k, _ in self.gen_model.named_parameters() if fade or k not in _EXCL_G]
-        d_names = [k for k, _ in self.disc_model.named_parameters() if fade or k not in _EXCL_D]
+        g_names, d_names = self._param_name_sets()
         mg, md = ck.get('opt_gen_state_dict'), ck.get('opt_disc_state_dict')
         if ref:
             mg, md = ckpt.moments_from_torch_adam(mg, g_names), ckpt.moments_from_torch_adam(md, d_names)
         if mg is not None and mg.get('exp_avg'):
             self.opt_gen.import_moments(self.gen_model.named_parameters(), mg)
             self.opt_disc.import_moments(self.disc_model.named_parameters(), md)
-        for k in ('sched_stop_step', 'curr_dataset_batch_num', 'curr_epoch_num', 'tot_num_epochs', 'curr_img_num',
-                  'curr_phase_num', 'not_trained_yet', 'latent_distribution'):
+        for k in ('sched_stop_step', 'curr_dataset_batch_num', 'curr_epoch_num', 'tot_num_epochs', 'dataset_sz',
+                  'curr_img_num', 'curr_phase_num', 'not_trained_yet', 'latent_distribution', 'grid_inputs_constructed',
+                  'gen_metrics_num', 'disc_metrics_num', 'rand_idxs', 'valid_label'):
             if ck.get(k) is not None:
                 setattr(self, k, ck[k])
+        # (reference-written files: ``sched_stop_step`` is taken as stored.  The reference also stores the LambdaLR
+        # state dicts but its ``_set_scheduler`` overwrites them with the fresh scheduler's before loading them back
+        # (:1055-1062), so its own resume restarts the step count at ``sched_stop_step`` too.)
+        if ck.get('valid_z') is not None:
+            self.valid_z = ck['valid_z'].to(self.config.dev)
+        # dataset statistics: the pretrained model's by default (:1431-1436), also pushed into a live data config
+        if ck.get('ds_mean') is not None and ck.get('ds_std') is not None:
+            self.ds_mean, self.ds_std = ck['ds_mean'].float().cpu(), ck['ds_std'].float().cpu()
+            if self._is_data_configed and self.data_config is not None:
+                self.data_config.ds_mean = self.ds_mean.squeeze().tolist()
+                self.data_config.ds_std = self.ds_std.squeeze().tolist()
         if ck.get('nimg_transition_lst') is not None:
             self.sched = PhaseSchedule(self.gen_model.curr_res, self.gen_model.final_res, self.config.bs_dict,
                                        self.config.nimg_transition, self.config.num_disc_iters,
@@ -719,4 +780,6 @@ class ProGANLearner(GANLearner):
         if self.config.use_ewma_gen:
             self.beta = self.get_smoothing_ewma_beta(half_life=EWMA_SMOOTHING_HALFLIFE) \
                 if COMPUTE_EWMA_VIA_HALFLIFE else EWMA_SMOOTHING_BETA
+        self.scheduler_gen = self.scheduler_disc = None
+        self.train_dataiter = None
         self.pretrained_model = True

@@ -53,7 +53,11 @@ class GANLearner(object):
         self.cond_gen = self.cond_disc = self.ac = False
         self.num_classes_gen = self.num_classes_disc = 0
         if config.use_auxiliary_classifier or config.class_condition:
-            raise NotImplementedError('class conditioning / auxiliary classifier: SURVEY.md §8f item 4 (next)')
+            # SURVEY.md §8f item 4.  No variant of these options runs in the reference (every combination raises in its
+            # constructor or first iteration: tests/golden/probe_conditional.py -> tests/golden/conditional_probe.json),
+            # so there is no behaviour to be in parity with.
+            raise NotImplementedError('class_condition / use_auxiliary_classifier: no variant of these options runs in '
+                                      'the reference (tests/golden/conditional_probe.json); not provided')
         if not (config.res_samples <= config.res_dataset):
             raise ValueError(f'Resolution of generated images (config.res_samples = {config.res_samples}) must be '
                              f'less than\nor equal to resolution of dataset (config.res_dataset = '
@@ -276,33 +280,41 @@ class GANLearner(object):
         except KeyboardInterrupt:
             # resnetgan/learner.py: Ctrl-C saves the latest checkpoint before the run ends
             self.set_requires_grad_disc(True)
-            if not self.not_trained_yet and parallel.rank() == 0:
+            if not self.not_trained_yet:
                 self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
-                print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
+                if parallel.rank() == 0:
+                    print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
             raise
 
     def save_model(self, save_path):
         """Checkpoint as plain data (key names follow resnetgan/learner.py:1076-1140)."""
         if self.not_trained_yet:
             raise Exception('Please train your model for atleast 1 iteration before saving.')
-        save_path = str(save_path)
-        os.makedirs(os.path.dirname(save_path) or '.', exist_ok=True)
-        torch.save({
+        from .. import checkpoint as ckpt
+        tcpu = lambda v: None if v is None else v.detach().cpu()  # noqa: E731
+        sched_steps = max(self.scheduler_gen._step_count - 1, 0) if (self.sched_bool and self.scheduler_gen) else 0
+        ck = {
             'config': {k: v for k, v in vars(self.config).items() if not k.startswith('_') and
                        isinstance(v, (int, float, str, bool, dict, list, tuple, type(None)))},
             'gen_model_state_dict': {k: v.detach().cpu() for k, v in self.gen_model.state_dict().items()},
             'disc_model_state_dict': {k: v.detach().cpu() for k, v in self.disc_model.state_dict().items()},
             'opt_gen_state_dict': self.opt_gen.export_moments(self.gen_model.named_parameters()),
             'opt_disc_state_dict': self.opt_disc.export_moments(self.disc_model.named_parameters()),
-            'sched_stop_step': self.sched_stop_step, 'lr_sched': self.lr_sched, 'optimizer': self.optimizer,
+            'sched_stop_step': (self.sched_stop_step or 0) + sched_steps if self.sched_bool else self.sched_stop_step,
+            'lr_sched': self.lr_sched, 'optimizer': self.optimizer,
             'loss': self.loss, 'gradient_penalty': self.gradient_penalty, 'batch_size': self.batch_size,
             'curr_dataset_batch_num': self.curr_dataset_batch_num, 'curr_epoch_num': self.curr_epoch_num,
             'tot_num_epochs': self.tot_num_epochs, 'curr_img_num': self.curr_img_num,
             'not_trained_yet': self.not_trained_yet,
-        }, save_path)
+            'ds_mean': tcpu(self.ds_mean), 'ds_std': tcpu(self.ds_std), 'valid_z': tcpu(self.valid_z),
+        }
+        if parallel.rank() == 0:            # replicas are identical: one writer, atomically; everyone waits for the file
+            ckpt.save_atomic(ck, save_path)
+        parallel.barrier()
 
     def load_model(self, load_path, dev_of_saved_model='cpu'):
-        ck = torch.load(str(load_path), map_location=dev_of_saved_model, weights_only=False)
+        from .. import checkpoint as ckpt
+        ck = ckpt.load_checkpoint(load_path, dev_of_saved_model)
         self.gen_model.load_state_dict(ck['gen_model_state_dict'])
         self.disc_model.load_state_dict(ck['disc_model_state_dict'])
         self.gen_model.to(self.config.dev)
@@ -314,6 +326,10 @@ class GANLearner(object):
         for k in ('sched_stop_step', 'batch_size', 'curr_dataset_batch_num', 'curr_epoch_num', 'tot_num_epochs',
                   'curr_img_num', 'not_trained_yet'):
             setattr(self, k, ck[k])
+        if ck.get('ds_mean') is not None and ck.get('ds_std') is not None:
+            self.ds_mean, self.ds_std = ck['ds_mean'].float().cpu(), ck['ds_std'].float().cpu()
+        if ck.get('valid_z') is not None:
+            self.valid_z = ck['valid_z'].to(self.config.dev)
         self.pretrained_model = True
 
     # -- gradient penalty (resnetgan/learner.py:780-827) ------------------------------------------------

@@ -39,6 +39,41 @@ class StyleGANLearner(ProGANLearner):
                                   mbstd_group_size=c.mbstd_group_size)
         return gen, disc
 
+    # -- checkpoint additions (stylegan/learner.py:455-464 on save, :547-556 / :603-607 on load) ------------------
+    def _extra_checkpoint_fields(self):
+        g = self.gen_model
+        lag_w = None
+        if self.config.use_ewma_gen:
+            # the reference stores the EWMA generator's copy; that copy is a deepcopy of the generator made by the last
+            # _update_gen_lagged (or at construction) - the same tensor unless training moved on since
+            lag = self.gen_model_lagged
+            lag_w = lag.w_ewma if (lag is not None and lag.w_ewma is not None) else g.w_ewma
+        cpu = lambda v: None if v is None else v.detach().to('cpu')  # noqa: E731
+        return {'use_truncation_trick': g.use_truncation_trick, 'trunc_cutoff_stage': g.trunc_cutoff_stage,
+                'w_eval_psi': g.w_eval_psi, 'w_ewma_beta': g.w_ewma_beta, 'w_ewma': cpu(g.w_ewma),
+                'w_ewma_lagged': cpu(lag_w), 'trained_with_noise': g._trained_with_noise,
+                'pct_mixing_reg': g.pct_mixing_reg}
+
+    def _restore_extra_fields(self, ck):
+        if 'w_ewma_beta' not in ck:
+            return
+        g, dev = self.gen_model, self.config.dev
+        g.w_ewma_beta = ck['w_ewma_beta']
+        g._w_eval_psi = ck['w_eval_psi']
+        g._trunc_cutoff_stage = ck['trunc_cutoff_stage']
+        g.use_truncation_trick = ck['use_truncation_trick']
+        g.w_ewma = None if ck['w_ewma'] is None else ck['w_ewma'].to(dev)
+        g._trained_with_noise = g._use_noise = ck['trained_with_noise']
+        g.pct_mixing_reg = ck['pct_mixing_reg']
+        g._use_mixing_reg = True if g.pct_mixing_reg else False
+        if self.config.use_ewma_gen:
+            # exactly the reference's load order: the EWMA generator is a copy made while the generator still holds
+            # checkpoint['w_ewma'] (:586-594), then the GENERATOR's w_ewma is overwritten with checkpoint['w_ewma_lagged']
+            # (:605)
+            self.materialize_lagged_generator().to(dev)
+            if ck.get('w_ewma_lagged') is not None:
+                g.w_ewma = ck['w_ewma_lagged'].to(dev)
+
     # -- style-mixing figure (stylegan/learner.py:306-431): the pixel content, without the matplotlib layout ------
     STYLE_MIX_STAGES = (1, 4, 8)    # coarse / middle / fine: generator layer at which source B's w takes over
 

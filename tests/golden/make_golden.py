@@ -521,6 +521,71 @@ def golden_checkpoint():
     save('ref_progan_ckpt_expect.npz', **out)
 
 
+def _ref_stylegan_setup(num_main_iters=9):
+    """The ProGAN Namespace of ``_ref_progan_setup`` turned into a StyleGAN one (config.py:291-325 fields)."""
+    cfg, bs = _ref_progan_setup(num_main_iters=num_main_iters)
+    ns.sb.FMAP_BASE, ns.sb.FMAP_MAX = FMAP_BASE, FMAP_MAX
+    cfg.model = 'StyleGAN'
+    for k, v in dict(init_res=4, len_dlatent=LEN_LATENT, mapping_num_fcs=NUM_FCS, mapping_lrmul=.01, use_noise=True,
+                     use_pixelnorm=False, use_instancenorm=True, pct_mixing_reg=.9, beta_trunc_trick=.9,
+                     psi_trunc_trick=.7, cutoff_trunc_trick=1, loss='nonsaturating', gradient_penalty='r1').items():
+        setattr(cfg, k, v)
+    with open(os.path.join(os.environ['HOME'], '.config.p'), 'wb') as f:
+        pickle.dump(cfg, f)
+    return cfg, bs
+
+
+def golden_checkpoint_stylegan():
+    """A checkpoint written by the REAL reference ``StyleGANLearner.save_model`` (stylegan/learner.py:432-501) after 9
+    main iterations of its own ``train`` (4x4 stabilised -> 8x8 mid fade-in, truncation trick on: cutoff stage 1,
+    psi 0.7, w-average beta 0.9), and what the reference's OWN ``load_model`` (:503-640) makes of it: a second
+    reference learner loads the file and its eval-mode generator / EWMA generator (truncation applied, explicit
+    noise) are evaluated - including the ``w_ewma`` each of them ends up with."""
+    cfg, bs = _ref_stylegan_setup(num_main_iters=9)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    learner = ns.sl.StyleGANLearner(cfg)
+    import torchvision.transforms as tvt
+    gen = torch.Generator().manual_seed(7)
+    dl = _FakeDL(64, bs, 4, tvt.Resize, gen)
+    learner.train(dl, num_main_iters=cfg.num_main_iters)
+    learner.valid_z = torch.zeros(16, LEN_LATENT)
+    path = os.path.join(HERE, 'ref_stylegan_ckpt.tar')
+    learner.save_model(path)
+    print(f'wrote ref_stylegan_ckpt.tar: {os.path.getsize(path) / 1024:.1f} KiB')
+    # the reference's own reader.  It calls torch.load(path, map_location=...) as torch 1.x allowed; torch >= 2.6
+    # defaults to weights_only=True, which refuses the pickled config / module objects the file holds.
+    L2 = ns.sl.StyleGANLearner(cfg)
+    import functools
+    _orig_load = torch.load
+    torch.load = functools.partial(_orig_load, weights_only=False)
+    try:
+        L2.load_model(path)
+    finally:
+        torch.load = _orig_load
+    g, gl = L2.gen_model, L2.gen_model_lagged
+    res = g.curr_res
+    z = torch.randn(4, LEN_LATENT, generator=gen)
+    noise = [torch.randn(4, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2), generator=gen) for n in range(len(g.gen_layers))]
+    out = dict(z=T(z), curr_res=np.int64(res), alpha=np.float64(g.alpha), fade_in=np.bool_(g.fade_in_phase),
+               curr_img_num=np.int64(L2.curr_img_num), curr_phase_num=np.int64(L2.curr_phase_num),
+               batch_size=np.int64(L2.batch_size), use_truncation_trick=np.bool_(g.use_truncation_trick),
+               trunc_cutoff_stage=np.int64(g.trunc_cutoff_stage), w_eval_psi=np.float64(g.w_eval_psi),
+               w_ewma_beta=np.float64(g.w_ewma_beta), w_ewma=T(g.w_ewma), w_ewma_lagged_model=T(gl.w_ewma),
+               w_ewma_saved=T(learner.gen_model.w_ewma), pct_mixing_reg=np.float64(g.pct_mixing_reg),
+               ds_mean=T(L2.ds_mean), ds_std=T(L2.ds_std), valid_z=T(L2.valid_z))
+    out.update({f'noise{i}': T(n) for i, n in enumerate(noise)})
+    g.eval()
+    gl.eval()
+    with torch.no_grad():
+        out['img'] = T(g(z, noise=noise))
+        out['img_lagged'] = T(gl(z, noise=noise))
+        g.use_truncation_trick = False
+        out['img_no_trunc'] = T(g(z, noise=noise))
+        g.use_truncation_trick = True
+    save('ref_stylegan_ckpt_expect.npz', **out)
+
+
 def golden_schedule():
     """Host-logic trace of the REAL reference ProGANLearner.train over a 4 -> 8 -> 16 schedule
     (BASELINE config #1 shape: 64 random images, batch 4): per main iteration the resolution, phase,
@@ -727,6 +792,7 @@ if __name__ == '__main__':
         'schedule': golden_schedule,
         'data': golden_data,
         'checkpoint': golden_checkpoint,
+        'checkpoint_sg': golden_checkpoint_stylegan,
         'resnet64': lambda: golden_resnet(64, 'resnet64', fmap_g=2, fmap_d=2),
         'resnet32': lambda: golden_resnet(32, 'resnet32', fmap_g=8, fmap_d=8),
     }

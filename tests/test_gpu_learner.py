@@ -250,3 +250,72 @@ def test_training_is_bitwise_reproducible():
     diff = [k for k in a if not torch.equal(a[k], b[k])]
     assert not diff, f'{len(diff)} of {len(a)} tensors differ between two identical runs, e.g. {diff[:3]}'
     assert la == lb
+
+
+def test_load_reference_written_stylegan_checkpoint(tmp_path):
+    """tests/golden/ref_stylegan_ckpt.tar was written by the reference's own StyleGANLearner.save_model
+    (stylegan/learner.py:432-501: 9 main iterations, 4x4 -> 8x8 mid fade-in, truncation trick on).  The expectations
+    come from the reference's OWN load_model (:503-640) of that file: truncation state, the ``w_ewma`` the generator and
+    the EWMA generator end up with, and their eval-mode images (truncation applied) on fixed latents / noise."""
+    import os
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.stylegan.learner import StyleGANLearner
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    here = os.path.join(os.path.dirname(__file__), 'golden')
+    E = load_golden('ref_stylegan_ckpt_expect.npz')
+    bs = 4
+    cfg = make_config('stylegan', dev='cuda', pin_memory=False, res_samples=16, res_dataset=16, init_res=4,
+                      batch_size=bs, len_latent=16, len_dlatent=16, mapping_num_fcs=2, nimg_transition=22,
+                      beta_trunc_trick=.9, psi_trunc_trick=.7, cutoff_trunc_trick=1, loss='nonsaturating',
+                      gradient_penalty='r1', num_iters_save_model=10 ** 9, log_every=1,
+                      bs_dict={4: bs, 8: bs, 16: bs // 2, 32: bs, 64: bs, 128: bs, 256: bs, 512: bs // 2,
+                               1024: bs // 4})
+    cfg.lr_fctr_dict = {4: 1, 8: 1.25, 16: 1.5, 32: 1, 64: 1, 128: 1.5, 256: 2, 512: 3, 1024: 3}
+    from gan_lab_amd import progressive as P
+    P.FMAP_BASE, P.FMAP_MAX = 64, 16
+    try:
+        L = StyleGANLearner(cfg)
+        L.load_model(os.path.join(here, 'ref_stylegan_ckpt.tar'))
+        g = L.gen_model
+        assert g.curr_res == int(E['curr_res']) == 8 and g.fade_in_phase == bool(E['fade_in'])
+        assert abs(g.alpha - float(E['alpha'])) < 1e-12
+        assert L.curr_img_num == int(E['curr_img_num']) and L.curr_phase_num == int(E['curr_phase_num'])
+        assert g.use_truncation_trick == bool(E['use_truncation_trick'])
+        assert g.trunc_cutoff_stage == int(E['trunc_cutoff_stage'])
+        assert g.w_eval_psi == float(E['w_eval_psi']) and g.w_ewma_beta == float(E['w_ewma_beta'])
+        assert g.pct_mixing_reg == float(E['pct_mixing_reg'])
+        assert_close(g.w_ewma.cpu(), E['w_ewma'], 1e-6, 'generator w_ewma after load')
+        assert_close(L.gen_model_lagged.w_ewma.cpu(), E['w_ewma_lagged_model'], 1e-6, 'EWMA generator w_ewma after load')
+        assert_close(L.ds_mean, E['ds_mean'], 0, 'ds_mean')
+        assert_close(L.ds_std, E['ds_std'], 0, 'ds_std')
+        assert_close(L.valid_z.cpu(), E['valid_z'], 0, 'valid_z')
+        z = t(E['z']).cuda()
+        noise = [t(E[f'noise{i}']).cuda() for i in range(len(g.gen_layers))]
+        g.eval()
+        lag = L.gen_model_lagged.eval()
+        with torch.no_grad():
+            assert_close(g(z, noise=noise).cpu(), E['img'], 1e-3, 'G(z) eval, truncation trick')
+            assert_close(lag(z, noise=noise).cpu(), E['img_lagged'], 1e-3, 'EWMA G(z) eval, truncation trick')
+            g.use_truncation_trick = False
+            assert_close(g(z, noise=noise).cpu(), E['img_no_trunc'], 1e-3, 'G(z) eval, no truncation')
+            g.use_truncation_trick = True
+        # resume training from it, then write / re-read this package's own format with the truncation state in it
+        g.train()
+        L.train(SyntheticImageLoader(4096, 4, 4), num_main_iters=3)
+        assert np.isfinite(L.last_losses['loss_d'])
+        path = tmp_path / 'stylegan_model.tar'
+        L.save_model(path)
+        L2 = StyleGANLearner(cfg)
+        L2.load_model(path)
+        assert torch.equal(L2.gen_model.w_ewma, L.gen_model.w_ewma) and L2.gen_model.trunc_cutoff_stage == 1
+        assert torch.equal(L2.arena_g.flat, L.arena_g.flat) and torch.equal(L2.ds_mean, L.ds_mean)
+        # and the reference-format writer runs on the device learner too (read back by this package's reader)
+        L.save_model(tmp_path / 'ref_format.tar', reference_format=True)
+        from gan_lab_amd import checkpoint as ckpt
+        ck = ckpt.load_checkpoint(tmp_path / 'ref_format.tar')
+        assert ckpt.is_reference_format(ck) and 'w_ewma_lagged' in ck and ck['opt_gen_state_dict']['state']
+        L3 = StyleGANLearner(cfg)
+        L3.load_model(tmp_path / 'ref_format.tar')
+        assert torch.equal(L3.arena_d.flat, L.arena_d.flat)
+    finally:
+        P.FMAP_BASE, P.FMAP_MAX = 8192, 512

@@ -348,3 +348,25 @@ def test_integration_snippet_host_side():
     n = ns['lib'].ganlab_conv_pack_f32(None, None, 16, 16, 3, 0, 1.0, None)
     assert n >= 9 * 16 * 16 and n % 4 == 0
     assert callable(ns['conv2d_ex_forward'])
+
+
+def test_conditional_variants_row_is_closed_by_the_probe(monkeypatch):
+    """tests/golden/probe_conditional.py ran the REAL reference with class_condition /
+    use_auxiliary_classifier (ProGAN, StyleGAN, ResNet GAN; several loss / penalty settings) - every variant raises in
+    the reference's own constructor or first training iteration, so there is nothing to be in parity with and the
+    product learners refuse the options loudly."""
+    import json
+    probe = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'conditional_probe.json')))
+    assert len(probe['variants']) >= 9 and probe['any_variant_runs'] is False
+    for v in probe['variants']:
+        assert v['exception'] and v['where'], v                      # each failure is located in a reference file:line
+        assert v['stage'] in ('constructor', 'train')
+    models = {v['variant'].split(':')[0] for v in probe['variants']}
+    assert models == {'ProGAN', 'StyleGAN', 'ResNet GAN'}
+    monkeypatch.setenv('GANLAB_HOST_LOGIC_ONLY', '1')
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.progan.learner import ProGANLearner
+    for kw in (dict(class_condition=True), dict(use_auxiliary_classifier=True)):
+        cfg = make_config('progan', dev='cpu', pin_memory=False, res_samples=8, res_dataset=8, num_classes=3, **kw)
+        with pytest.raises(NotImplementedError, match='conditional_probe'):
+            ProGANLearner(cfg)
