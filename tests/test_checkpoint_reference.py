@@ -21,10 +21,19 @@ pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference/gan_lab'),
 
 @pytest.fixture(scope='module')
 def ref():
+    """tests/golden/make_golden.py with the reference imported through its stubs - and everything it put on
+    ``sys.path`` / into ``sys.modules`` (the reference's top-level ``_int``, ``utils``, ``progan`` ... packages, the
+    ``torchvision`` / ``indexed`` stand-ins) taken out again afterwards, so later tests see a clean interpreter."""
+    path0, mods0 = list(sys.path), set(sys.modules)
     sys.path.insert(0, GOLDEN)
     with contextlib.redirect_stdout(io.StringIO()):
         import make_golden as MG
-    return MG
+    yield MG
+    sys.path[:] = path0
+    for name in set(sys.modules) - mods0:
+        f = getattr(sys.modules[name], '__file__', None) or ''
+        if '/root/reference' in f or f.startswith(GOLDEN) or name.split('.')[0] in ('torchvision', 'indexed'):
+            del sys.modules[name]
 
 
 def _product_learner(kind, monkeypatch, tmp_path):
