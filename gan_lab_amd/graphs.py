@@ -51,6 +51,12 @@ class GraphedGenerator(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._forward()
+        if follow_weight_updates:
+            # The capture inserted packed-weight tensors into the cache that live in the graph's private pool and that
+            # no kernel has written yet (capture records, it does not execute): an eager forward of the same module
+            # before the first replay would convolve with uninitialised weights, and later ones would alias buffers
+            # every replay rewrites.  Drop them - eager calls re-pack into ordinary allocations.
+            ops.bump_weight_epoch()
 
     def _forward(self):
         with torch.no_grad():

@@ -192,7 +192,17 @@ def test_graphed_generator_matches_eager(kind, capsys):
     L.train(dl, num_main_iters=2)
     g = L.gen_model
     g.eval()
+    z0 = torch.randn(2, 16).cuda()
+    n0 = [torch.randn(2, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2)).cuda() for n in range(len(g.gen_layers))] \
+        if kind == 'stylegan' else None
+    with torch.no_grad():
+        before = (g(z0, noise=n0) if n0 is not None else g(z0)).clone()
     gg = GraphedGenerator(g, batch=1)
+    # an EAGER forward between the capture and the first replay must not pick up the packed-weight tensors the capture
+    # left in the cache (graph-pool memory no kernel has written yet)
+    with torch.no_grad():
+        after = g(z0, noise=n0) if n0 is not None else g(z0)
+    assert torch.equal(before, after)
     gen = torch.Generator().manual_seed(0)
     for it in range(3):
         z = torch.randn(1, 16, generator=gen).cuda()
