@@ -59,3 +59,10 @@ __device__ __forceinline__ float gl_block_sum_256(float v, float* red) {
 }
 
 __device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---- wgrad_roll.hip: rolling-window weight gradient of the thin 3x3 layers (used by ganlab_conv_wgrad_f32) ----------
+bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int pad, int up, const void* x,
+                             const void* gy);
+int gl_wgrad_roll_slots(int N, int Cin, int Cout, int H, int W);
+int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, int Cin, int Cout, int H, int W,
+                         hipStream_t st);

@@ -2001,17 +2001,34 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   f.a.in = in; f.a.gy = gy; f.a.part = (float*)workspace;
   f.a.Cout = g->Cout; f.a.Ho = ho; f.a.Wo = wo;
   f.pl = &pl; f.st = gl_stream(stream);
-  const int rc = g->ks == 1 ? wg_select<1>(pl, f) : wg_select<3>(pl, f);
-  if (rc != GANLAB_OK) return rc;
+  int slots = pl.slots;
+  // thin 3x3 layers on 64-pixel-aligned planes: the rolling-window kernel (wgrad_roll.hip), one slot per workgroup
+  // (GANLAB_WGRAD_ROLL=0 keeps the tile kernel: same-box A/B measurements)
+  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  const bool roll_on = !(roll_env && roll_env[0] == '0');
+  bool rolled = false;
+  if (roll_on && gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy)) {
+    const int rs = gl_wgrad_roll_slots(g->N, g->Cin, g->Cout, g->Hin, g->Win);
+    if (workspace_bytes >= (size_t)(rs + 32) * nw * sizeof(float)) {
+      const int rc = gl_wgrad_roll_launch(x, gy, (float*)workspace, g->N, g->Cin, g->Cout, g->Hin, g->Win, f.st);
+      if (rc != GANLAB_OK) return rc;
+      slots = rs;
+      rolled = true;
+    }
+  }
+  if (!rolled) {
+    const int rc = g->ks == 1 ? wg_select<1>(pl, f) : wg_select<3>(pl, f);
+    if (rc != GANLAB_OK) return rc;
+  }
   // two-stage when there are many slots and few outputs (thin layers: 4096 slots x 2304 weights)
   const unsigned nblk = (unsigned)((nw + 255) / 256);
-  const int groups = pl.slots >= 64 ? 32 : 1;
+  const int groups = slots >= 64 ? 32 : 1;
   float* ws = (float*)workspace;
   if (groups == 1) {
-    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, f.st, (const float*)ws, gw, nw, pl.slots, 1, scale);
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, f.st, (const float*)ws, gw, nw, slots, 1, scale);
   } else {
-    float* stage2 = ws + (long long)pl.slots * nw;
-    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk, groups), dim3(256), 0, f.st, (const float*)ws, stage2, nw, pl.slots,
+    float* stage2 = ws + (long long)slots * nw;
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk, groups), dim3(256), 0, f.st, (const float*)ws, stage2, nw, slots,
               groups, 1.0f);
     GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, f.st, (const float*)stage2, gw, nw, groups, 1, scale);
   }

@@ -1,0 +1,267 @@
+// Rolling-window weight gradient for the THIN 3x3 layers (<= 32 channels on either side, W % 64 == 0, H % 4 == 0):
+//   gw[co][ci][ky][kx] = sum_{n,y,x} gy[n,co,y,x] * xin[n,ci,y+ky-1,x+kx-1]        (wgrad of custom_layers.py:202-211)
+//
+// Why a second weight-gradient kernel.  conv_wgrad_kernel (conv.hip) stages one 32x8-pixel tile of BOTH operands per
+// 144 MFMAs per wave: the halo'd input patch is 40x10 = 1.56x the tile, so a 16 -> 16 layer moves (64 + 100) bytes per
+// pixel for 4608 FLOP - 28 FLOP/byte against a ridge of 25 (157.3 TFLOP/s over ~6.3 TB/s): MFMA pipes and HBM are both
+// near saturation and neither hides the other (0.55 of the MFMA peak at 1024^2).  Here a workgroup owns a 64-pixel
+// column strip and walks DOWN it four rows per step, like conv_fwd_roll_kernel:
+//   * input rows live in a ring of 6 LDS row slots; every input element is fetched ONCE per workgroup (plus the
+//     8-of-72 column halo): (64 + 72) bytes per pixel;
+//   * wave w owns output-gradient row 4t + w of the step: the contraction index of the MFMA is the PIXEL, and the
+//     k -> pixel map is transposed (lane k-group holds pixels 4k .. 4k+3 of a 16-pixel block, MFMA q takes pixel
+//     4k + q), so ONE ds_read_b128 feeds four MFMAs' A operands and one ds_read_b128 + one ds_read_b64 feed the B
+//     operands of twelve (three horizontal taps x four pixels): 0.2 LDS instructions per MFMA instead of 1.1;
+//   * the x rows sit one float to the right in LDS (column c'' = vx - ox0 + 5), which is what makes those six B values
+//     an aligned 16-byte + 8-byte pair; row pitches 88 / 72 floats make both reads bank-conflict free
+//     (MI355X_MICROARCH.md, LDS table: ds_read_b128 is served in 4 groups of 16 lanes over 64 banks);
+//   * nine tap accumulators per wave (36 registers), so consecutive MFMAs never wait on each other's 40-cycle
+//     accumulator latency; the four waves' sums are added through LDS at the end: ONE slot per workgroup, and the
+//     existing fixed-order slot reduction finishes (deterministic).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WR_TW = 64, WR_ROWS = 4, WR_SLOTS = 6;
+constexpr int WR_XP = 88, WR_XSLOT = 16 * WR_XP;        // x row slot: [ci 16][88]; column c'' = vx - ox0 + 5 (1 .. 72 used)
+constexpr int WR_GP = 72, WR_GROW = 16 * WR_GP;         // gy row: [co 16][72]; column = vx - ox0 (0 .. 63 used)
+constexpr int WR_XQ = 18;                               // float4 per (row, ci): vx = ox0 - 4 .. ox0 + 67
+constexpr int WR_XITEMS = WR_ROWS * 16 * WR_XQ;         // 1152 float4 per 4-row group
+constexpr int WR_XPT = (WR_XITEMS + 255) / 256;         // 5
+constexpr int WR_GPT = 4;                               // gy: 4 rows x 16 co x 16 float4 = 1024 items, row k = item i
+constexpr int WR_SMEM = WR_SLOTS * WR_XSLOT + WR_ROWS * WR_GROW;   // 13056 floats = 52224 B: three workgroups per CU
+constexpr int WR_OOB = (int)0x80000000;
+
+struct WRArgs {
+  const float* x;
+  const float* gy;
+  float* part;            // [slots = gridDim.x][Cout][Cin][9]
+  int N, Cin, Cout, H, W;
+  int cols, strips, spu;  // 64-pixel columns per image, row strips per column, steps (of 4 rows) per strip
+  int tiles_ci, tiles_co, S;
+  int units;              // N * cols * strips
+};
+
+__global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[WR_SMEM];
+  float* ring = smem;
+  float* gbuf = smem + WR_SLOTS * WR_XSLOT;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  int bid = blockIdx.x;
+  const int split = bid % p.S;
+  bid /= p.S;
+  const int ci_t = bid % p.tiles_ci, co_t = bid / p.tiles_ci;
+  const int ci0 = ci_t * 16, co0 = co_t * 16;
+  const int plane = p.H * p.W;
+
+  // staging items of a 4-row x group: (k = row in group, ci, q = float4 column)
+  int xch[WR_XPT], xlo[WR_XPT], xk[WR_XPT], xcol[WR_XPT];
+#pragma unroll
+  for (int i = 0; i < WR_XPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % WR_XQ, t = e / WR_XQ;
+    const int ci = t & 15, k = t >> 4;
+    xch[i] = (e < WR_XITEMS && ci0 + ci < p.Cin) ? (ci0 + ci) * plane * 4 : WR_OOB;
+    xlo[i] = ci * WR_XP + 4 * q + 1;
+    xk[i] = k;
+    xcol[i] = 4 * q - 4;
+  }
+  // gy items: thread = (co = tid >> 4, q = tid & 15), item i = row i of the step
+  const int gco = tid >> 4, gq = tid & 15;
+  const int gch = (co0 + gco < p.Cout) ? (co0 + gco) * plane * 4 : WR_OOB;
+  const int glo = gco * WR_GP + 4 * gq;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = wn * WR_GROW + (lane & 15) * WR_GP + 4 * (lane >> 4);
+  const int b_off = (lane & 15) * WR_XP + 4 * (lane >> 4);
+
+  float4 xr[WR_XPT], gr[WR_GPT];
+
+  for (int u = split; u < p.units; u += p.S) {
+    const int col = u % p.cols;
+    const int t2 = u / p.cols;
+    const int strip = t2 % p.strips, n = t2 / p.strips;
+    const int ox0 = col * WR_TW, y0 = strip * p.spu * WR_ROWS;
+    const int nsteps = min(p.spu, p.H / WR_ROWS - strip * p.spu);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (long long)n * p.Cin * plane), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.gy + (long long)n * p.Cout * plane), 0, (unsigned)(p.Cout * plane * 4), 0x00020000);
+
+    // rows rel0 .. rel0 + nrows - 1 of the strip (rel row r = image row y0 - 1 + r) -> registers; everything outside the
+    // image, past nrows or in the channel padding reads as zero (out-of-range descriptor offsets)
+    auto load_x = [&](int rel0, int nrows) {
+#pragma unroll
+      for (int i = 0; i < WR_XPT; ++i) {
+        const int vy = y0 - 1 + rel0 + xk[i], vx = ox0 + xcol[i];
+        const bool ok = xch[i] != WR_OOB && xk[i] < nrows && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+        const int off = ok ? xch[i] + (vy * p.W + vx) * 4 : WR_OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    };
+    auto store_x = [&](int rel0, int nrows) {
+#pragma unroll
+      for (int i = 0; i < WR_XPT; ++i) {
+        if (tid + i * 256 < WR_XITEMS && xk[i] < nrows) {
+          float* d = ring + ((rel0 + xk[i]) % WR_SLOTS) * WR_XSLOT + xlo[i];
+          d[0] = xr[i].x;
+          *reinterpret_cast<float2*>(d + 1) = float2{xr[i].y, xr[i].z};
+          d[3] = xr[i].w;
+        }
+      }
+    };
+    auto load_g = [&](int t, bool on) {
+#pragma unroll
+      for (int i = 0; i < WR_GPT; ++i) {
+        const int off = (on && gch != WR_OOB) ? gch + ((y0 + 4 * t + i) * p.W + ox0 + 4 * gq) * 4 : WR_OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off, 0, 0);
+        gr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    };
+    auto store_g = [&]() {
+#pragma unroll
+      for (int i = 0; i < WR_GPT; ++i) *reinterpret_cast<float4*>(gbuf + i * WR_GROW + glo) = gr[i];
+    };
+
+    __syncthreads();                       // the previous unit's last step has been read
+    load_x(0, 4);
+    load_g(0, true);
+    store_x(0, 4);
+    store_g();
+    load_x(4, 2);
+    store_x(4, 2);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+      const bool more = t + 1 < nsteps;
+      int sb[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) sb[ky] = ((4 * t + wn + ky) % WR_SLOTS) * WR_XSLOT + b_off;
+      // software pipeline over the 12 (g, ky) sub-steps: operands of sub-step s+1 are read while the 12 MFMAs of s issue
+      float4 av[2];
+      float4 b4[2];
+      float2 b2[2];
+      auto fetch_b = [&](int s, int buf) {
+        const int g = s / 3, ky = s % 3;
+        const float* src = ring + sb[ky] + 16 * g;
+        b4[buf] = *reinterpret_cast<const float4*>(src + 4);
+        b2[buf] = *reinterpret_cast<const float2*>(src + 8);
+      };
+      av[0] = *reinterpret_cast<const float4*>(gbuf + a_off);
+      fetch_b(0, 0);
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        const int g = s / 3, ky = s % 3, cur = s & 1;
+        if (s + 1 < 12) fetch_b(s + 1, cur ^ 1);
+        if (ky == 0 && g + 1 < 4) av[(g + 1) & 1] = *reinterpret_cast<const float4*>(gbuf + a_off + 16 * (g + 1));
+        // rows 4t+6 .. 4t+9 and the next four gy rows: issued one sub-step into the loop (MFMAs already queued)
+        if (s == 1) {
+          load_x(4 * t + 6, more ? 4 : 0);
+          load_g(t + 1, more);
+        }
+        // pin the operand reads of sub-step s+1 (and the global prefetch) IN FRONT of this sub-step's MFMAs: left to
+        // itself the scheduler sinks them to their first use, i.e. the loads to the barrier (their latency then sits
+        // between the barrier and the LDS stores of every step) and the reads to a lgkmcnt(0) in front of every MFMA group
+        __builtin_amdgcn_sched_barrier(0);
+        const float a[4] = {av[g & 1].x, av[g & 1].y, av[g & 1].z, av[g & 1].w};
+        const float e[6] = {b4[cur].x, b4[cur].y, b4[cur].z, b4[cur].w, b2[cur].x, b2[cur].y};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], e[q + kx], acc[ky * 3 + kx], 0, 0, 0);
+      }
+      __syncthreads();                     // rows 4t .. 4t+5 and the gy rows of this step are no longer read
+      if (more) {
+        store_x(4 * t + 6, 4);             // = the slots of rows 4t .. 4t+3
+        store_g();
+      }
+      __syncthreads();
+    }
+  }
+
+  // add the four waves' accumulators through LDS (fixed order) and write this workgroup's slot
+  __syncthreads();
+  float* red = smem;                       // [wave 4][tap 9][256]
+#pragma unroll
+  for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(red + (wn * 9 + t) * 256 + lane * 4) = acc[t];
+  __syncthreads();
+  // slot index = split: one slot per workgroup of this (co_t, ci_t) pair; the pairs write disjoint (co, ci) ranges
+  float* dst = p.part + (long long)split * p.Cout * p.Cin * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float s = (red[(0 * 9 + t) * 256 + tid] + red[(1 * 9 + t) * 256 + tid]) +
+                    (red[(2 * 9 + t) * 256 + tid] + red[(3 * 9 + t) * 256 + tid]);
+    const int l = tid >> 2, r = tid & 3;
+    const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + (l & 15);
+    if (co < p.Cout && ci < p.Cin) dst[((long long)co * p.Cin + ci) * 9 + t] = s;
+  }
+}
+
+inline bool wr_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+// Thin 3x3 "same" convolutions on 64-pixel-aligned planes.  Pointers may be null (workspace / plan queries).
+bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int pad, int up, const void* x,
+                             const void* gy) {
+  if (ks != 3 || pad != 1 || up || N <= 0 || Cin <= 0 || Cout <= 0) return false;
+  if (Cin > 32 || Cout > 32) return false;
+  if (H % WR_ROWS != 0 || W % WR_TW != 0 || H < 8) return false;
+  if ((long long)Cin * H * W * 4 >= 0x7fffffffLL || (long long)Cout * H * W * 4 >= 0x7fffffffLL) return false;
+  if ((x && !wr_aligned16(x)) || (gy && !wr_aligned16(gy))) return false;
+  return true;
+}
+
+static void wr_plan(WRArgs& a) {
+  a.cols = a.W / WR_TW;
+  const int steps = a.H / WR_ROWS;
+  a.tiles_ci = (a.Cin + 15) / 16;
+  a.tiles_co = (a.Cout + 15) / 16;
+  const int base = a.tiles_ci * a.tiles_co;
+  const int target = (768 + base - 1) / base;          // one full round of three workgroups per CU
+  // Steps per unit: long strips amortise a unit's un-overlapped prologue (six row loads before the first MFMA), short
+  // ones balance the units over the workgroups.  Measured (tools/wgrad_bench.py, MI355X): 64 is best while every
+  // workgroup still gets >= 2.5 units (16 -> 16 at 1024^2: 0.746 of peak vs 0.735 at 16), 16 otherwise.
+  int spu = 16;
+  if (const char* e = getenv("GANLAB_WR_SPU")) {       // tuning knob (tools/wgrad_bench.py)
+    spu = atoi(e) > 0 ? atoi(e) : 16;
+  } else {
+    for (int cand = 64; cand > 16; cand >>= 1) {
+      const long long units = (long long)a.N * a.cols * ((steps + cand - 1) / cand);
+      if (steps >= cand && 2 * units >= 5LL * target) { spu = cand; break; }
+    }
+  }
+  a.spu = steps < spu ? steps : spu;
+  a.strips = (steps + a.spu - 1) / a.spu;
+  a.units = a.N * a.cols * a.strips;
+  int S = target;
+  if (S > a.units) S = a.units;
+  a.S = S < 1 ? 1 : S;
+}
+
+// number of partial-sum slots ([Cout][Cin][9] floats each) the launch writes
+int gl_wgrad_roll_slots(int N, int Cin, int Cout, int H, int W) {
+  WRArgs a{};
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  wr_plan(a);
+  return a.S;
+}
+
+int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, int Cin, int Cout, int H, int W,
+                         hipStream_t st) {
+  WRArgs a{};
+  a.x = x; a.gy = gy; a.part = part;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  wr_plan(a);
+  const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
+  GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return GL_CHECK_LAUNCH();
+}

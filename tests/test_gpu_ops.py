@@ -53,6 +53,12 @@ CONV_CASES = [
     (2, 72, 8, 8, 200, 3, 1, False, False, 'lrelu'),   # 9 K-chunks: S is cut back so no workgroup gets an empty range
     (8, 256, 16, 16, 128, 3, 1, False, True, 'lrelu'), # 16x16 tiles on the vector-staged kernel, S = 4
     (32, 512, 16, 16, 512, 3, 1, False, True, None),   # the benchmark's 16x16 layer, S = 2
+    # rolling-window weight gradient (wgrad_roll.hip: thin layers, W % 64 == 0, H % 4 == 0)
+    (3, 12, 40, 64, 10, 3, 1, False, True, None),      # channel padding on both sides, 10 steps in one strip
+    (2, 32, 16, 64, 24, 3, 1, False, True, 'lrelu'),   # 2 x 2 channel-tile pairs, ragged co tile
+    (1, 5, 72, 192, 32, 3, 1, False, False, None),     # three columns, 18 steps = two strips (16 + 2)
+    (2, 16, 8, 128, 16, 3, 1, False, True, None),      # two steps only: prologue + one prefetch
+    (2, 16, 68, 64, 16, 3, 1, False, False, None),     # 17 steps: a strip of one step
 ]
 
 
