@@ -66,3 +66,7 @@ bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int
 int gl_wgrad_roll_slots(int N, int Cin, int Cout, int H, int W);
 int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, int Cin, int Cout, int H, int W,
                          hipStream_t st);
+bool gl_wgrad_s2_roll_supported(int N, int Cl, int Ch, int Hl, int Wl, const void* low, const void* high);
+int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl);
+int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, int N, int Cl, int Ch, int Hl, int Wl,
+                            hipStream_t st);

@@ -20,6 +20,8 @@
 // next K-chunk prefetched into registers during the MFMA phase (same scheme as conv.hip).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -778,18 +780,34 @@ int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const g
   a.N = g->N; a.Cl = Cl; a.Ch = Ch; a.Hl = hl; a.Wl = wl;
   a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.tiles_cl = pl.tiles_cl; a.tiles_ch = pl.tiles_ch; a.S = pl.S;
   hipStream_t st = gl_stream(stream);
-  const unsigned wgrid = (unsigned)((long long)pl.tiles_cl * pl.tiles_ch * pl.S);
-  if (pl.nba == 2) GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<2>>, dim3(wgrid), dim3(256), 0, st, a);
-  else GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<1>>, dim3(wgrid), dim3(256), 0, st, a);
+  int slots = pl.slots;
+  // planes whose low-resolution width is a multiple of 32: the rolling-window kernel (wgrad_roll.hip), same slot
+  // layout; GANLAB_WGRAD_ROLL=0 keeps the tile kernel (same-box A/B measurements)
+  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  bool rolled = false;
+  if (!(roll_env && roll_env[0] == '0') && gl_wgrad_s2_roll_supported(g->N, Cl, Ch, hl, wl, a.low, a.high)) {
+    const int rs = gl_wgrad_s2_roll_slots(g->N, Cl, Ch, hl, wl);
+    if (workspace_bytes >= (size_t)(rs + 32) * nk * sizeof(float)) {
+      const int rc = gl_wgrad_s2_roll_launch(a.low, a.high, a.part, g->N, Cl, Ch, hl, wl, st);
+      if (rc != GANLAB_OK) return rc;
+      slots = rs;
+      rolled = true;
+    }
+  }
+  if (!rolled) {
+    const unsigned wgrid = (unsigned)((long long)pl.tiles_cl * pl.tiles_ch * pl.S);
+    if (pl.nba == 2) GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<2>>, dim3(wgrid), dim3(256), 0, st, a);
+    else GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<1>>, dim3(wgrid), dim3(256), 0, st, a);
+  }
   float* ws = (float*)workspace;
-  float* stage2 = ws + (long long)pl.slots * nk;
+  float* stage2 = ws + (long long)slots * nk;
   // slots -> 32 groups -> 1 with the wide reduce kernel (16*Cl*Ch threads); the fold kernel has only Cl*Ch threads
   // (512 for the 16 -> 32 layer), so every slot it still had to add up cost it 16 serial strided reads per thread
   const float* folded_src = ws;
-  int fold_groups = pl.slots;
+  int fold_groups = slots;
   if (fold_groups >= 64) {
     GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 32), dim3(256), 0, st, (const float*)ws,
-              stage2, nk, pl.slots, 32);
+              stage2, nk, slots, 32);
     folded_src = stage2;
     fold_groups = 32;
   }

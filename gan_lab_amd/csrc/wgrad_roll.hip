@@ -205,6 +205,205 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
   }
 }
 
+// ================================================================================================================
+// The same rolling window for the 16-tap weight gradient of the stride-2 fused layers (conv_s2.hip, "W"):
+//   gK4[a][b][cl][ch] = sum_{n,Y,X} low[n,cl,Y,X] * high_pad[n,ch,2Y+a-1,2X+b-1]      a, b in 0..3
+// (down layer: low = gy, high = x; up layer: low = x, high = gy; conv_s2.hip folds gK4 back onto the 3x3 parameter).
+// The tile kernel there stages a 40x12 high-resolution patch per 32x8... 16x4 low-resolution tile: 1.875x the tile's
+// own pixels, every tile - its arithmetic intensity sits on the ridge as well (0.60-0.70 of the MFMA peak).
+//   * column strip = 32 low-resolution pixels (64 high-resolution columns + halo = the same 18 float4 per row and
+//     channel as above), step = 2 low rows = 4 new high rows: the SAME 6-slot ring bookkeeping (rel rows 4t .. 4t+5);
+//   * wave a owns tap row a (4 x NBA accumulators): for low row j of the step it reads high rel row 4t + 2j + a;
+//   * a high row is stored split by column parity, E[e] = high[2(X0+e)] at [0, 36) and O'[o] = high[2(X0+o)-1] at
+//     [36, 72) of its 72-float channel row: tap b of low pixel X0+x reads E[x] (b=1), E[x+1] (b=3), O'[x] (b=0),
+//     O'[x+1] (b=2), so with the transposed k -> pixel map (lane k-group = pixels 4k .. 4k+3) the five values per plane
+//     are an aligned ds_read_b128 + ds_read_b64: 6 LDS instructions per 32 MFMAs.
+// ================================================================================================================
+constexpr int W2_TWL = 32, W2_RL = 2;
+constexpr int W2_HP = 72, W2_HSLOT = 16 * W2_HP;        // high row slot [ch 16][E 36 | O' 36]
+constexpr int W2_LP = 40;                               // low row: [cl][40], 32 used
+constexpr int W2_LQ = 8;                                // float4 per (low row, cl)
+
+struct W2RArgs {
+  const float* low;
+  const float* high;
+  float* part;            // [slots][16 taps][Cl][Ch]
+  int N, Cl, Ch, Hl, Wl;
+  int cols, strips, spu;
+  int tiles_cl, tiles_ch, S;
+  int units;
+};
+
+template <int NBA>
+__global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
+  constexpr int CL_T = 16 * NBA, LROW = CL_T * W2_LP;
+  constexpr int LITEMS = W2_RL * CL_T * W2_LQ, LPT = LITEMS / 256;      // 256 / 512 float4 per step: 1 / 2 per thread
+  static_assert(LITEMS % 256 == 0, "low staging items");
+  __shared__ __attribute__((aligned(16))) float smem[WR_SLOTS * W2_HSLOT + W2_RL * LROW];
+  float* ring = smem;
+  float* lbuf = smem + WR_SLOTS * W2_HSLOT;
+  const int tid = threadIdx.x, lane = tid & 63, wa = tid >> 6;          // wa = tap row a of this wave
+  int bid = blockIdx.x;
+  const int split = bid % p.S;
+  bid /= p.S;
+  const int ch_t = bid % p.tiles_ch, cl_t = bid / p.tiles_ch;
+  const int ch0 = ch_t * 16, cl0 = cl_t * CL_T;
+  const int H = 2 * p.Hl, W = 2 * p.Wl, hplane = H * W, lplane = p.Hl * p.Wl;
+
+  int xch[WR_XPT], xlo[WR_XPT], xk[WR_XPT], xq[WR_XPT];
+#pragma unroll
+  for (int i = 0; i < WR_XPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % WR_XQ, t = e / WR_XQ;
+    const int ch = t & 15, k = t >> 4;
+    xch[i] = (e < WR_XITEMS && ch0 + ch < p.Ch) ? (ch0 + ch) * hplane * 4 : WR_OOB;
+    xlo[i] = ch * W2_HP + 2 * q;          // E pair at xlo - 2, O' pair at 36 + xlo - 1, 36 + xlo
+    xk[i] = k;
+    xq[i] = q;
+  }
+  int lch[LPT], llo[LPT], lrow[LPT], lq[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % W2_LQ, t = e / W2_LQ;
+    const int cl = t % CL_T, j = t / CL_T;
+    lch[i] = (cl0 + cl < p.Cl) ? (cl0 + cl) * lplane * 4 : WR_OOB;
+    llo[i] = j * LROW + cl * W2_LP + 4 * q;
+    lrow[i] = j;
+    lq[i] = q;
+  }
+
+  f32x4 acc[4][NBA];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m) acc[b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = (lane & 15) * W2_LP + 4 * (lane >> 4);
+  const int b_off = (lane & 15) * W2_HP + 4 * (lane >> 4);
+  float4 xr[WR_XPT], lr[LPT];
+
+  for (int u = split; u < p.units; u += p.S) {
+    const int col = u % p.cols;
+    const int t2 = u / p.cols;
+    const int strip = t2 % p.strips, n = t2 / p.strips;
+    const int X0 = col * W2_TWL, Y0 = strip * p.spu * W2_RL;
+    const int nsteps = min(p.spu, p.Hl / W2_RL - strip * p.spu);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.high + (long long)n * p.Ch * hplane), 0, (unsigned)(p.Ch * hplane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.low + (long long)n * p.Cl * lplane), 0, (unsigned)(p.Cl * lplane * 4), 0x00020000);
+
+    // high rel rows rel0 .. rel0 + nrows - 1 (rel row r = high row 2*Y0 - 1 + r)
+    auto load_h = [&](int rel0, int nrows) {
+#pragma unroll
+      for (int i = 0; i < WR_XPT; ++i) {
+        const int vy = 2 * Y0 - 1 + rel0 + xk[i], vx = 2 * X0 - 4 + 4 * xq[i];
+        const bool ok = xch[i] != WR_OOB && xk[i] < nrows && (unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W;
+        const int off = ok ? xch[i] + (vy * W + vx) * 4 : WR_OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, off, 0, 0);
+        xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    };
+    auto store_h = [&](int rel0, int nrows) {
+#pragma unroll
+      for (int i = 0; i < WR_XPT; ++i) {
+        if (tid + i * 256 < WR_XITEMS && xk[i] < nrows) {
+          float* d = ring + ((rel0 + xk[i]) % WR_SLOTS) * W2_HSLOT + xlo[i];
+          if (xq[i] > 0) {
+            *reinterpret_cast<float2*>(d - 2) = float2{xr[i].x, xr[i].z};      // E[2q-2], E[2q-1]
+            d[36 - 1] = xr[i].y;                                               // O'[2q-1]
+          }
+          d[36] = xr[i].w;                                                     // O'[2q]
+        }
+      }
+    };
+    auto load_l = [&](int t, bool on) {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) {
+        const int off = (on && lch[i] != WR_OOB) ? lch[i] + ((Y0 + W2_RL * t + lrow[i]) * p.Wl + X0 + 4 * lq[i]) * 4
+                                                 : WR_OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_l, off, 0, 0);
+        lr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+      }
+    };
+    auto store_l = [&]() {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) *reinterpret_cast<float4*>(lbuf + llo[i]) = lr[i];
+    };
+
+    __syncthreads();
+    load_h(0, 4);
+    load_l(0, true);
+    store_h(0, 4);
+    store_l();
+    load_h(4, 2);
+    store_h(4, 2);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+      const bool more = t + 1 < nsteps;
+      int sb[W2_RL];
+#pragma unroll
+      for (int j = 0; j < W2_RL; ++j) sb[j] = ((4 * t + 2 * j + wa) % WR_SLOTS) * W2_HSLOT + b_off;
+      // 4 sub-steps s = (j, g): 16 low pixels of row j each, 32 (NBA = 2) MFMAs per sub-step
+      float4 av[2][NBA], e4[2], o4[2];
+      float2 e2[2], o2[2];
+      auto fetch = [&](int s, int buf) {
+        const int j = s >> 1, g = s & 1;
+        const float* src = ring + sb[j] + 16 * g;
+        e4[buf] = *reinterpret_cast<const float4*>(src);
+        e2[buf] = *reinterpret_cast<const float2*>(src + 4);
+        o4[buf] = *reinterpret_cast<const float4*>(src + 36);
+        o2[buf] = *reinterpret_cast<const float2*>(src + 40);
+#pragma unroll
+        for (int m = 0; m < NBA; ++m)
+          av[buf][m] = *reinterpret_cast<const float4*>(lbuf + j * LROW + m * 16 * W2_LP + a_off + 16 * g);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int s = 0; s < 2 * W2_RL; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < 2 * W2_RL) fetch(s + 1, cur ^ 1);
+        if (s == 0) {
+          load_h(4 * t + 6, more ? 4 : 0);
+          load_l(t + 1, more);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // see conv_wgrad_roll_kernel: keep the prefetches in front of the MFMAs
+        const float eE[5] = {e4[cur].x, e4[cur].y, e4[cur].z, e4[cur].w, e2[cur].x};
+        const float eO[5] = {o4[cur].x, o4[cur].y, o4[cur].z, o4[cur].w, o2[cur].x};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bv[4] = {eO[q], eE[q], eO[q + 1], eE[q + 1]};
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int m = 0; m < NBA; ++m) {
+              const float a = q == 0 ? av[cur][m].x : (q == 1 ? av[cur][m].y : (q == 2 ? av[cur][m].z : av[cur][m].w));
+              acc[b][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[b], acc[b][m], 0, 0, 0);
+            }
+        }
+      }
+      __syncthreads();
+      if (more) {
+        store_h(4 * t + 6, 4);
+        store_l();
+      }
+      __syncthreads();
+    }
+  }
+  // every wave owns its own tap row: taps 4a + b of this workgroup's slot; D rows = cl (lane>>4)*4+r, col = ch (lane&15)
+  float* dst = p.part + (long long)split * 16 * p.Cl * p.Ch;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = cl0 + m * 16 + (lane >> 4) * 4 + r, ch = ch0 + (lane & 15);
+        if (cl < p.Cl && ch < p.Ch) dst[((long long)(wa * 4 + b) * p.Cl + cl) * p.Ch + ch] = acc[b][m][r];
+      }
+}
+
 inline bool wr_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -263,5 +462,59 @@ int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, in
   wr_plan(a);
   const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
   GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return GL_CHECK_LAUNCH();
+}
+
+// ---- stride-2 (16-tap) variant --------------------------------------------------------------------------------------
+bool gl_wgrad_s2_roll_supported(int N, int Cl, int Ch, int Hl, int Wl, const void* low, const void* high) {
+  if (N <= 0 || Cl <= 0 || Ch <= 0) return false;
+  if (Wl % W2_TWL != 0 || Hl % W2_RL != 0 || Hl < 4) return false;
+  if ((long long)Ch * Hl * Wl * 16 >= 0x7fffffffLL || (long long)Cl * Hl * Wl * 4 >= 0x7fffffffLL) return false;
+  if ((low && !wr_aligned16(low)) || (high && !wr_aligned16(high))) return false;
+  return true;
+}
+
+static void w2r_plan(W2RArgs& a) {
+  a.cols = a.Wl / W2_TWL;
+  const int steps = a.Hl / W2_RL;
+  const int nba = a.Cl > 16 ? 2 : 1;
+  a.tiles_cl = (a.Cl + 16 * nba - 1) / (16 * nba);
+  a.tiles_ch = (a.Ch + 15) / 16;
+  const long long base = (long long)a.tiles_cl * a.tiles_ch;
+  const int target = (int)((768 + base - 1) / base);
+  int spu = 16;
+  if (const char* e = getenv("GANLAB_WR_SPU")) {
+    spu = atoi(e) > 0 ? atoi(e) : 16;
+  } else {
+    for (int cand = 64; cand > 16; cand >>= 1) {
+      const long long units = (long long)a.N * a.cols * ((steps + cand - 1) / cand);
+      if (steps >= cand && 2 * units >= 5LL * target) { spu = cand; break; }
+    }
+  }
+  a.spu = steps < spu ? steps : spu;
+  a.strips = (steps + a.spu - 1) / a.spu;
+  a.units = a.N * a.cols * a.strips;
+  int S = target;
+  if (S > a.units) S = a.units;
+  a.S = S < 1 ? 1 : S;
+}
+
+int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl) {
+  W2RArgs a{};
+  a.N = N; a.Cl = Cl; a.Ch = Ch; a.Hl = Hl; a.Wl = Wl;
+  w2r_plan(a);
+  return a.S;
+}
+
+int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, int N, int Cl, int Ch, int Hl, int Wl,
+                            hipStream_t st) {
+  W2RArgs a{};
+  a.low = low; a.high = high; a.part = part;
+  a.N = N; a.Cl = Cl; a.Ch = Ch; a.Hl = Hl; a.Wl = Wl;
+  w2r_plan(a);
+  const long long grid = (long long)a.tiles_cl * a.tiles_ch * a.S;
+  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  if (a.Cl > 16) GL_LAUNCH(conv_s2_wgrad_roll_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_s2_wgrad_roll_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }

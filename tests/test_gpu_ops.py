@@ -376,6 +376,11 @@ S2_CASES = [
     (2, 64, 16, 16, 32, 'up'),
     (1, 128, 16, 16, 64, 'up'),
     (1, 96, 20, 24, 48, 'up'),
+    # rolling-window 16-tap weight gradient (wgrad_roll.hip): low-resolution width a multiple of 32
+    (3, 24, 24, 128, 40, 'pool'),     # channel padding on both operands, two columns, 6 steps
+    (1, 40, 6, 64, 12, 'up'),         # three steps, NBA = 2 with a ragged low-channel tile
+    (2, 16, 68, 32, 16, 'up'),        # NBA = 1, 34 steps = two strips (32 + 2)
+    (2, 64, 36, 64, 64, 'pool'),      # 2 x 4 channel-tile pairs
 ]
 
 

@@ -13,11 +13,15 @@ import torch.nn.functional as F  # noqa: E402
 from gan_lab_amd import _lib, ops  # noqa: E402
 
 
-def ref_wgrad(gy, x, pad=1):
+def ref_wgrad(gy, x, pad=1, up=False, pool=False):
     """float64 on the CPU (small cases only)."""
     gy, x = gy.double().cpu(), x.double().cpu()
     w = torch.zeros(gy.shape[1], x.shape[1], 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x, w, padding=pad).backward(gy)
+    xin = F.interpolate(x, scale_factor=2, mode='nearest') if up else x
+    y = F.conv2d(xin, w, padding=pad)
+    if pool:
+        y = F.avg_pool2d(y, 2)
+    y.backward(gy)
     return w.grad
 
 
@@ -59,13 +63,33 @@ def main():
             err = ((out - ref).abs().max() / ref.abs().max()).item()
             print(f'{"roll" if roll else "tile"} N{n} {ci}->{co} {h}x{w}: rel err {err:.2e}', flush=True)
             worst = max(worst, err)
+    # stride-2 fused layers: (N, Cin, Cout, H, W of the INPUT, up / pool)
+    s2 = [(2, 16, 32, 16, 64, 'pool'), (2, 32, 16, 8, 32, 'up'), (3, 24, 40, 24, 128, 'pool'), (1, 40, 12, 6, 64, 'up'),
+          (2, 64, 64, 36, 64, 'pool'), (2, 16, 16, 68, 32, 'up')]
+    for n, ci, co, h, w, kind in s2:
+        up, pool = kind == 'up', kind == 'pool'
+        x = torch.randn(n, ci, h, w, device='cuda')
+        g = ops.Geom(n, ci, h, w, co, 3, 1, int(up), int(pool))
+        assert g.s2, (n, ci, co, h, w, kind)
+        gy = torch.randn(*g.out_shape, device='cuda')
+        ref = ref_wgrad(gy, x, 1, up, pool)
+        for roll in (True, False):
+            out = run(gy, x, g, roll).double().cpu()
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            print(f'{"roll" if roll else "tile"} s2-{kind} N{n} {ci}->{co} in {h}x{w}: rel err {err:.2e}', flush=True)
+            worst = max(worst, err)
     assert worst < 1e-5, worst
     if a.big:
-        for n, ci, co, r in ((32, 16, 16, 1024), (32, 32, 32, 512), (32, 16, 16, 512), (8, 32, 32, 256)):
+        cases = [(32, 16, 16, 1024, ''), (32, 32, 32, 512, ''),
+                 (32, 16, 32, 1024, 'pool'), (32, 32, 64, 512, 'pool'), (32, 64, 128, 256, 'pool'),
+                 (32, 128, 256, 128, 'pool'), (32, 256, 512, 64, 'pool'), (32, 32, 16, 512, 'up'),
+                 (32, 64, 32, 256, 'up'), (32, 512, 256, 32, 'up')]
+        for n, ci, co, r, kind in cases:
+            up, pool = kind == 'up', kind == 'pool'
             x = torch.randn(n, ci, r, r, device='cuda')
-            gy = torch.randn(n, co, r, r, device='cuda')
-            g = ops.Geom(n, ci, r, r, co, 3, 1, 0)
-            flops = 2.0 * 9 * ci * co * r * r * n
+            g = ops.Geom(n, ci, r, r, co, 3, 1, int(up), int(pool))
+            gy = torch.randn(*g.out_shape, device='cuda')
+            flops = ops.conv_flops(g)
             a_, b_ = run(gy, x, g, True), run(gy, x, g, False)
             err = ((a_ - b_).abs().max() / b_.abs().max()).item()
             res = {}
@@ -78,7 +102,7 @@ def main():
                     res.setdefault(name, []).append(ms)
             for name, roll, spu in variants:
                 ms = min(res[name])
-                print(f'{name:14s} N{n} {ci}->{co} @{r}^2: {ms:.3f} ms (min of 3x10)  '
+                print(f'{name:14s} N{n} {ci}->{co} @{r}^2 {kind}: {ms:.3f} ms (min of 3x10)  '
                       f'{flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 157.3:.3f} of peak; roll-vs-tile diff '
                       f'{err:.1e}', flush=True)
     os.environ.pop('GANLAB_WGRAD_ROLL', None)
