@@ -355,6 +355,11 @@ def cpu_baseline(torch, res, batch, steps=3):
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 on the way
+    # (RCCL prints a version banner there when its communicator is created, libraries print notices) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -459,7 +464,8 @@ def main():
             out['cpu_baseline_note'] = 'timed for the StyleGAN configurations only (oracle/step.py FunctionalGAN)'
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -151,7 +151,7 @@ def _without_tie_channels(k, hip, ex, scale):
     B*H*W terms.  Signature: the whole excess error of a conv weight / bias gradient sits in one or two output
     channels.  Returns (error with the worst <= MAX_TIE_CHANNELS output channels left out, those channels)."""
     e = (hip.double() - ex).abs()
-    if k.endswith('bias'):
+    if k.endswith('bias') or k.endswith('noise_weight'):     # one value per output channel of the layer
         per = e.flatten()
     elif k.endswith('conv2d.weight') or k.endswith('linear.weight'):
         per = e.flatten(1).max(dim=1).values
