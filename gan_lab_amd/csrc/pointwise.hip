@@ -3,6 +3,8 @@
 // (cdna_hip_programming.md G13) and a grid capped at ~8 blocks/CU with a grid-stride loop (G11).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kMaxBlocks = 256 * 8;
@@ -12,6 +14,29 @@ inline unsigned ew_blocks(long long n_items) {
   if (b < 1) b = 1;
   if (b > kMaxBlocks) b = kMaxBlocks;
   return (unsigned)b;
+}
+
+// Chunk c of `chunks` over a plane of hw4 float4: CONTIGUOUS ranges of whole 256-float4 rows (a block streams one
+// 4 KB .. 64 KB run instead of 4 KB pieces 256 KB apart: +5..12 % on the 1R1W / 2R1W passes, tools/pw_probe.py)
+struct ChunkRange { long long begin, end, stride; };
+__device__ __forceinline__ ChunkRange chunk_range(long long hw4, int chunks, int c, int contig) {
+  ChunkRange r;
+  if (contig) {
+    const long long rows = (hw4 + 255) / 256, per = (rows + chunks - 1) / chunks;
+    r.begin = (long long)c * per * 256;
+    r.end = r.begin + per * 256;
+    if (r.end > hw4) r.end = hw4;
+    r.stride = 256;
+  } else {      // legacy interleaved form (A/B: GANLAB_PW_CONTIG=0)
+    r.begin = (long long)c * 256;
+    r.end = hw4;
+    r.stride = (long long)chunks * 256;
+  }
+  return r;
+}
+inline int pw_contig() {
+  static const int v = [] { const char* e = getenv("GANLAB_PW_CONTIG"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
 }
 
 #define GRID_STRIDE(i, n) \
@@ -297,7 +322,8 @@ __global__ __launch_bounds__(256) void bias_act_stats_kernel(const float* __rest
                                                              const float* __restrict__ noise,
                                                              const float* __restrict__ noise_w, float* __restrict__ y,
                                                              double* __restrict__ spart, int C, long long hw4,
-                                                             int chunks, float bias_scale, int act, float slope) {
+                                                             int chunks, float bias_scale, int act, float slope,
+                                                             int contig) {
   __shared__ double dred[2][4];
   const long long pl = blockIdx.y;
   const int c = (int)(pl % C);
@@ -308,7 +334,8 @@ __global__ __launch_bounds__(256) void bias_act_stats_kernel(const float* __rest
   const float4* np = noise ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
   float4* yp = reinterpret_cast<float4*>(y) + pl * hw4;
   double ds = 0.0, dss = 0.0;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < hw4; i += (long long)chunks * 256) {
+  const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
+  for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
     float v[4], nz[4] = {0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<float4*>(v) = xp[i];
     if (np) *reinterpret_cast<float4*>(nz) = np[i];
@@ -573,6 +600,37 @@ __global__ void instnorm_style_fwd_kernel(const float* __restrict__ x, const flo
   }
 }
 
+// Large planes (HW a multiple of 1024 * U): one block per (plane, chunk of 256 * U float4) - the plane's four scalars are
+// read once per block, the index math is 32-bit, and every thread keeps U independent 16-byte loads in flight (the
+// grid-stride form above spends a 64-bit division per float4 and has one load in flight per thread).
+template <int U>
+__global__ __launch_bounds__(256) void instnorm_style_fwd_chunk_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd,
+                                                                       const float* __restrict__ style,
+                                                                       float* __restrict__ y, int C, int chunks,
+                                                                       long long HW) {
+  const unsigned pl = blockIdx.x / (unsigned)chunks, ch = blockIdx.x % (unsigned)chunks;
+  const int c = (int)(pl % (unsigned)C);
+  const long long n = pl / (unsigned)C;
+  const float m = mean[pl], r = rstd[pl];
+  const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
+  const float yb = style ? style[(n * 2 + 1) * C + c] : 0.f;
+  const float a = r * ys;
+  const long long base = (long long)pl * (HW / 4) + (long long)ch * (256 * U) + threadIdx.x;
+  const float4* xs = reinterpret_cast<const float4*>(x) + base;
+  float4* yd = reinterpret_cast<float4*>(y) + base;
+  float4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = xs[u * 256];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float4 w = v[u];
+    w.x = (w.x - m) * a + yb; w.y = (w.y - m) * a + yb; w.z = (w.z - m) * a + yb; w.w = (w.w - m) * a + yb;
+    yd[u * 256] = w;
+  }
+}
+
 template <int T>
 __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ gy,
                                                                   const float* __restrict__ x,
@@ -661,7 +719,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ style, const float* __restrict__ s1,
     const float* __restrict__ s2, const float* __restrict__ noise, float* __restrict__ gz, float* __restrict__ part,
-    int N, int C, long long hw4, int chunks, int act, float slope, int want_b, int want_nw) {
+    int N, int C, long long hw4, int chunks, int act, float slope, int want_b, int want_nw, int contig) {
   __shared__ float red[4];
   const long long pl = blockIdx.y;
   const int c = (int)(pl % C);
@@ -675,7 +733,8 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
   const float4* pn = (want_nw && noise) ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
   float4* po = reinterpret_cast<float4*>(gz) + pl * hw4;
   float sb = 0.f, snw = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < hw4; i += (long long)chunks * 256) {
+  const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
+  for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
     float g[4], v[4], o[4];
     *reinterpret_cast<float4*>(g) = pg[i];
     *reinterpret_cast<float4*>(v) = px[i];
@@ -1171,7 +1230,7 @@ int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const flo
   const int chunks = act_stats_chunks(hw4);
   float* part = reinterpret_cast<float*>(workspace);
   GL_LAUNCH(instnorm_bwd_apply_act_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, gy, x, mean,
-            rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0);
+            rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part, gb, C, N * chunks, bias_scale);
   if (gnw)
     GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part + (size_t)C * N * chunks, gnw, C,
@@ -1190,7 +1249,7 @@ int ganlab_bias_act_stats_f32(const float* x, const float* bias, const float* no
   const int chunks = act_stats_chunks(hw4);
   double* sp = reinterpret_cast<double*>(workspace);
   GL_LAUNCH(bias_act_stats_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, x, bias, noise, noise_w,
-            y, sp, C, hw4, chunks, bias_scale, act, slope);
+            y, sp, C, hw4, chunks, bias_scale, act, slope, pw_contig());
   GL_LAUNCH(act_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, (const double*)sp, mean,
             rstd, planes, chunks, 1.0 / (double)HW, eps);
   return GL_CHECK_LAUNCH();
@@ -1270,7 +1329,16 @@ int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long lon
 int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float* rstd, const float* style,
                                   float* y, int N, int C, long long HW, void* stream) {
   if (!x || !mean || !rstd || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
-  if ((HW & 3) == 0)
+  // U = 2 float4 per thread measured best (tools/pw_probe.py: 5.8 vs 5.1 TB/s for the grid-stride form at 32x16x1024^2;
+  // U = 4 equal, U = 8 5.4); GANLAB_PW_CHUNK=0 selects the grid-stride kernel (A/B)
+  static const int chunk_u = [] { const char* e = getenv("GANLAB_PW_CHUNK"); return e ? atoi(e) : 2; }();
+  if (chunk_u > 0 && HW % (1024 * 8) == 0 && (long long)N * C * (HW / (1024 * chunk_u)) < 0x7fffffffLL) {
+    const int chunks = (int)(HW / (1024 * chunk_u));
+    const unsigned grid = (unsigned)((long long)N * C * chunks);
+    if (chunk_u == 8) GL_LAUNCH(instnorm_style_fwd_chunk_kernel<8>, dim3(grid), dim3(256), 0, ST, x, mean, rstd, style, y, C, chunks, HW);
+    else if (chunk_u == 2) GL_LAUNCH(instnorm_style_fwd_chunk_kernel<2>, dim3(grid), dim3(256), 0, ST, x, mean, rstd, style, y, C, chunks, HW);
+    else GL_LAUNCH(instnorm_style_fwd_chunk_kernel<4>, dim3(grid), dim3(256), 0, ST, x, mean, rstd, style, y, C, chunks, HW);
+  } else if ((HW & 3) == 0)
     GL_LAUNCH(instnorm_style_fwd_kernel<4>, dim3(ew_blocks((long long)N * C * HW / 4)), dim3(256), 0, ST,
                        x, mean, rstd, style, y, N, C, HW);
   else

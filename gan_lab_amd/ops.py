@@ -219,6 +219,32 @@ def _want_param_grads():
     return not _INPUT_GRAD_ONLY[0]
 
 
+# ---- "no gradient towards this leaf" ----------------------------------------------------------------
+# The mirror case: ``loss_d.backward()`` of the D step.  The real batch is a leaf with requires_grad (R1 needs
+# d D/d x with create_graph=True), so the sweep would also produce d loss/d x - one input-gradient kernel of the
+# first layer over the widest tensor of the network - which nobody reads.  ``with ops.no_grad_towards(x):`` makes the
+# first layer's backward skip it (a Python autograd.Function cannot see that the engine will discard an output).
+_NO_GRAD_TOWARDS = [None]
+
+
+class no_grad_towards(object):
+    def __init__(self, leaf):
+        self.ptr = leaf.data_ptr() if leaf is not None else None
+
+    def __enter__(self):
+        self._prev = _NO_GRAD_TOWARDS[0]
+        _NO_GRAD_TOWARDS[0] = self.ptr
+
+    def __exit__(self, *exc):
+        _NO_GRAD_TOWARDS[0] = self._prev
+        return False
+
+
+def _wants_input_grad(ctx, x):
+    return ctx.needs_input_grad[0] and not (_NO_GRAD_TOWARDS[0] is not None and x.grad_fn is None and
+                                            x.data_ptr() == _NO_GRAD_TOWARDS[0])
+
+
 # ---- launch observer (measurement only) -------------------------------------------------------------
 # bench.py / tools/step_layers.py count the convolution FLOPs the step actually EXECUTES (stride-2 fused layers run
 # 16 low-resolution taps instead of 4 x 9, the shared D(real) forward and the skipped weight gradients never launch)
@@ -950,7 +976,7 @@ class _ConvBiasAct(Function):
         act = ACT_NONE if ctx.defer else ctx.act
         if act != ACT_NONE and not ctx.blur and ctx.in_slope is None and conv_act_bwd_fusable(ctx.g):
             # fromRGB: no separate  gz = gy * lrelu'(y)  pass - its gradient kernels take (gy, y)
-            gx = _ConvDgradAct.apply(gy, y, w, ctx.g, ctx.s, ctx.slope) if ctx.needs_input_grad[0] else None
+            gx = _ConvDgradAct.apply(gy, y, w, ctx.g, ctx.s, ctx.slope) if _wants_input_grad(ctx, x) else None
             gw = None
             if params and (ctx.needs_input_grad[1] or want_b):
                 gw, gb = _ConvWgradAct.apply(gy, y, x, ctx.g, ctx.s, ctx.slope, ctx.bias_scale, bool(want_b))
@@ -968,7 +994,7 @@ class _ConvBiasAct(Function):
                 if want_b:
                     gb = _ChanSum.apply(gz, None, ctx.bias_scale)
         gx = None
-        if ctx.needs_input_grad[0]:
+        if _wants_input_grad(ctx, x):
             gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.in_slope is None else \
                 _ConvDgradMask.apply(gz, w, x, ctx.g, ctx.s, ctx.in_slope)
         gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and params) else None

@@ -218,6 +218,7 @@ class ProGANLearner(GANLearner):
             xgenb = self._gen_forward(zb, **(gen_kwargs or {}))
         xb = self.fade_in_real(xb)
         gp = self.gradient_penalty
+        xr = None
         if self.share_gp_forward and gp in ('r1', 'r2'):
             # R1 penalises the gradient at the real batch itself (R2: at the fake batch): D(real) of the
             # adversarial term and D(real) of the penalty are the SAME forward, so evaluate it once and
@@ -233,7 +234,8 @@ class ProGANLearner(GANLearner):
                 loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
         if self.eps:
             loss = loss + bp.drift_loss(d_real, c.eps_drift)
-        loss.backward()
+        with ops.no_grad_towards(xr):          # d loss / d (real batch) is nobody's input: skip that kernel
+            loss.backward()
         self.reducer.start(self.arena_d.gflat)   # RCCL mean all-reduce, overlaps what follows
         if not defer_update:
             self._finish_d_update()
