@@ -44,6 +44,7 @@ struct WRArgs {
   int cols, strips, spu;  // 64-pixel columns per image, row strips per column, steps (of 4 rows) per strip
   int tiles_ci, tiles_co, S;
   int units;              // N * cols * strips
+  int xcd;                // XCD-aware block mapping (A/B knob)
 };
 
 __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
@@ -51,7 +52,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
   float* ring = smem;
   float* gbuf = smem + WR_SLOTS * WR_XSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-  int bid = blockIdx.x;
+  // optional (see wr_plan): blocks b and b + 8 share an XCD - give each XCD a contiguous range of logical ids, so that
+  // workgroups walking neighbouring column strips (consecutive `split`) share one L2
+  int bid = p.xcd ? gl_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int split = bid % p.S;
   bid /= p.S;
   const int ci_t = bid % p.tiles_ci, co_t = bid / p.tiles_ci;
@@ -232,6 +235,7 @@ struct W2RArgs {
   int cols, strips, spu;
   int tiles_cl, tiles_ch, S;
   int units;
+  int xcd;
 };
 
 template <int NBA>
@@ -243,7 +247,9 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
   float* ring = smem;
   float* lbuf = smem + WR_SLOTS * W2_HSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wa = tid >> 6;          // wa = tap row a of this wave
-  int bid = blockIdx.x;
+  // optional (see wr_plan): blocks b and b + 8 share an XCD - give each XCD a contiguous range of logical ids, so that
+  // workgroups walking neighbouring column strips (consecutive `split`) share one L2
+  int bid = p.xcd ? gl_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int split = bid % p.S;
   bid /= p.S;
   const int ch_t = bid % p.tiles_ch, cl_t = bid / p.tiles_ch;
@@ -444,6 +450,11 @@ static void wr_plan(WRArgs& a) {
   int S = target;
   if (S > a.units) S = a.units;
   a.S = S < 1 ? 1 : S;
+  // XCD-aware mapping is OFF: it cuts the L2-miss traffic (FETCH_SIZE x2: 1.47-1.63x -> 1.14-1.16x the algorithmic
+  // bytes, profiles/r02_wgrad_roll_pmc.txt) but the thin layers ran 8-10 % SLOWER with it in a same-process A/B
+  // (tools/wgrad_bench.py; thick layers: no difference) - the halo lines the neighbours miss are served by the
+  // Infinity Cache anyway.  GANLAB_WR_XCD=1 turns it on.
+  { const char* e = getenv("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
 }
 
 // number of partial-sum slots ([Cout][Cin][9] floats each) the launch writes
@@ -497,6 +508,11 @@ static void w2r_plan(W2RArgs& a) {
   int S = target;
   if (S > a.units) S = a.units;
   a.S = S < 1 ? 1 : S;
+  // XCD-aware mapping is OFF: it cuts the L2-miss traffic (FETCH_SIZE x2: 1.47-1.63x -> 1.14-1.16x the algorithmic
+  // bytes, profiles/r02_wgrad_roll_pmc.txt) but the thin layers ran 8-10 % SLOWER with it in a same-process A/B
+  // (tools/wgrad_bench.py; thick layers: no difference) - the halo lines the neighbours miss are served by the
+  // Infinity Cache anyway.  GANLAB_WR_XCD=1 turns it on.
+  { const char* e = getenv("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
 }
 
 int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl) {

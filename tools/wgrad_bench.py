@@ -47,7 +47,7 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--big', action='store_true')
-    ap.add_argument('--spu', type=int, nargs='*', default=[16])
+    ap.add_argument('--spu', type=int, nargs='*', default=[0])
     a = ap.parse_args()
     torch.manual_seed(0)
     small = [(2, 16, 16, 8, 64), (3, 12, 10, 40, 64), (2, 16, 16, 64, 128), (2, 32, 24, 16, 64), (1, 5, 32, 72, 192),
@@ -93,16 +93,19 @@ def main():
             a_, b_ = run(gy, x, g, True), run(gy, x, g, False)
             err = ((a_ - b_).abs().max() / b_.abs().max()).item()
             res = {}
-            variants = [('tile', False, None)] + [(f'roll spu={s_}', True, s_) for s_ in a.spu]
+            variants = [('tile', False, None, '1')] + [(f'roll spu={s_} xcd={xc}', True, s_, xc) for s_ in a.spu
+                                                       for xc in ('0', '1')]
             for rnd in range(3):
-                for name, roll, spu in variants:
-                    if spu is not None:
+                for name, roll, spu, xc in variants:
+                    os.environ.pop('GANLAB_WR_SPU', None)
+                    if spu:
                         os.environ['GANLAB_WR_SPU'] = str(spu)
+                    os.environ['GANLAB_WR_XCD'] = xc
                     ms = timeit(lambda: run(gy, x, g, roll), 10)
                     res.setdefault(name, []).append(ms)
-            for name, roll, spu in variants:
+            for name, roll, spu, xc in variants:
                 ms = min(res[name])
-                print(f'{name:14s} N{n} {ci}->{co} @{r}^2 {kind}: {ms:.3f} ms (min of 3x10)  '
+                print(f'{name:20s} N{n} {ci}->{co} @{r}^2 {kind}: {ms:.3f} ms (min of 3x10)  '
                       f'{flops / ms / 1e9:.1f} TFLOP/s = {flops / ms / 1e9 / 157.3:.3f} of peak; roll-vs-tile diff '
                       f'{err:.1e}', flush=True)
     os.environ.pop('GANLAB_WGRAD_ROLL', None)
