@@ -45,6 +45,8 @@ struct WRArgs {
   int tiles_ci, tiles_co, S;
   int units;              // N * cols * strips
   int xcd;                // XCD-aware block mapping (A/B knob)
+  int per_image;          // S = N * S_img workgroups per channel pair: workgroup `split` = (image split % N, j = split / N)
+  int S_img;              // walks units j, j + S_img, ... of its own image only; slot `split` -> groups of N = per image
 };
 
 __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
@@ -87,7 +89,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
 
   float4 xr[WR_XPT], gr[WR_GPT];
 
-  for (int u = split; u < p.units; u += p.S) {
+  const int units_img = p.cols * p.strips;
+  const int u_first = p.per_image ? (split % p.N) * units_img + split / p.N : split;
+  const int u_end = p.per_image ? (split % p.N + 1) * units_img : p.units;
+  const int u_step = p.per_image ? p.S_img : p.S;
+  for (int u = u_first; u < u_end; u += u_step) {
     const int col = u % p.cols;
     const int t2 = u / p.cols;
     const int strip = t2 % p.strips, n = t2 / p.strips;
@@ -473,6 +479,62 @@ int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, in
   wr_plan(a);
   const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
   GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return GL_CHECK_LAUNCH();
+}
+
+// ---- per-image weight gradient (mod.hip's deferred InstanceNorm: the caller recombines the images with s[n,ci]) ------
+__global__ void wr_reduce_groups_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int slots,
+                                        int groups, float scale) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  int k = g;
+  for (; k + groups < slots; k += 2 * groups) {
+    s0 += part[(long long)k * n + i];
+    s1 += part[(long long)(k + groups) * n + i];
+  }
+  if (k < slots) s0 += part[(long long)k * n + i];
+  out[(long long)g * n + i] = (s0 + s1) * scale;
+}
+
+static void wr_plan_per_image(WRArgs& a) {
+  wr_plan(a);
+  const int base = a.tiles_ci * a.tiles_co;
+  int s_img = 768 / (a.N * base);
+  const int units_img = a.cols * a.strips;
+  if (s_img > units_img) s_img = units_img;
+  if (s_img < 1) s_img = 1;
+  a.per_image = 1;
+  a.S_img = s_img;
+  a.S = a.N * s_img;
+}
+
+extern "C" size_t ganlab_mod_conv_wgrad_workspace(const ganlab_conv_geom* g) {
+  if (!g || !gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, nullptr, nullptr)) return 0;
+  WRArgs a{};
+  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.H = g->Hin; a.W = g->Win;
+  wr_plan_per_image(a);
+  return (size_t)a.S * g->Cout * g->Cin * 9 * sizeof(float);
+}
+
+/* out[n][Cout][Cin][9] = scale * wgrad of image n alone (gy, x: one image's planes each) */
+extern "C" int ganlab_mod_conv_wgrad_f32(const float* gy, const float* x, float* out, const ganlab_conv_geom* g,
+                                         float scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !gy || !x || !out ||
+      !gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy))
+    return GANLAB_EINVAL;
+  WRArgs a{};
+  a.x = x; a.gy = gy; a.part = (float*)workspace;
+  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.H = g->Hin; a.W = g->Win;
+  wr_plan_per_image(a);
+  const long long nw = (long long)g->Cout * g->Cin * 9;
+  if (!workspace || workspace_bytes < (size_t)a.S * nw * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipStream_t st = gl_stream(stream);
+  const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
+  GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  GL_LAUNCH(wr_reduce_groups_kernel, dim3((unsigned)((nw + 255) / 256), (unsigned)g->N), dim3(256), 0, st,
+            (const float*)workspace, out, nw, a.S, g->N, scale);
   return GL_CHECK_LAUNCH();
 }
 

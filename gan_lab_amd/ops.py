@@ -1203,6 +1203,299 @@ class _LayerTail(Function):
             (gnw.view(ctx.nw_shape) if want_nw else None), gstyle, None, None, None, None, None
 
 
+# ---------------------------------------------------------------------------------------------- #
+# deferred InstanceNorm ("modulated" consumers; csrc/mod.hip)
+# ---------------------------------------------------------------------------------------------- #
+class Deferred(object):
+    """The output ``a * s[n,c] + t[n,c]`` of a generator layer (InstanceNorm + AdaIN of the activated tensor ``a``) that
+    has NOT been written to memory: its consumer applies it (per-sample weights / border-class bias, csrc/mod.hip).
+    Gradient contract: whoever consumes ``a`` sends back d loss / d (a*s + t) - the gradient with respect to the
+    NORMALISED tensor - as the gradient of ``a``; ``_LayerTailDeferred.backward`` is the InstanceNorm backward of that
+    (exactly what the materialised path feeds it), so ``s`` / ``t`` carry no gradient of their own."""
+    __slots__ = ('a', 's', 't', 'mean', 'rstd', 'style')
+
+    def __init__(self, a, s, t, mean, rstd, style):
+        self.a, self.s, self.t, self.mean, self.rstd, self.style = a, s, t, mean, rstd, style
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+
+def _affine_from_stats(mean, rstd, style, n, c):
+    """s = rstd * (ys + 1), t = yb - mean * s  as (N, C) tensors (style: (N, 2C) = [ys | yb] or None)."""
+    if style is not None:
+        st = style.view(n, 2, c)
+        s_ = rstd.view(n, c) * (st[:, 0] + 1.0)
+        t_ = st[:, 1] - mean.view(n, c) * s_
+    else:
+        s_ = rstd.view(n, c).clone()
+        t_ = -mean.view(n, c) * s_
+    return s_.contiguous(), t_.contiguous()
+
+
+def _layer_tail_backward(ctx, gout):
+    """Shared by _LayerTail / _LayerTailDeferred / _ConvModTail: InstanceNorm + style backward of ``gout`` (the gradient
+    with respect to the normalised tensor), LeakyReLU undone, bias / noise-weight / style gradients from the same pass.
+    Returns (gz, gb, gnw, gstyle)."""
+    y, mean, rstd, style, noise = ctx.saved_tail
+    gout = _c(gout)
+    n, c, hw = _nchw(y)
+    L = _lib.lib()
+    params = _want_param_grads()
+    want_b = ctx.bias_shape is not None and ctx.want_bias_grad and params
+    want_nw = ctx.nw_shape is not None and ctx.want_nw_grad and params
+    s1, s2 = _new((n, c), y), _new((n, c), y)
+    check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
+                                                 _st()), 'instnorm_bwd_reduce')
+    gz = gb = gnw = None
+    if ctx.want_x_grad or want_b or want_nw:
+        gz = torch.empty_like(y)
+        gb = _new((c,), y) if want_b else None
+        gnw = _new((c,), y) if want_nw else None
+        ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
+                         device=y.device) if (want_b or want_nw) else None
+        check(L.ganlab_instnorm_style_bwd_act_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
+                                                  _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
+                                                  hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
+                                                  ws.numel() * 4 if ws is not None else 0, _st()),
+              'instnorm_bwd_act')
+    gstyle = None
+    if style is not None and ctx.want_style_grad:
+        gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)
+    return gz, (gb.view(ctx.bias_shape) if gb is not None else None), \
+        (gnw.view(ctx.nw_shape) if gnw is not None else None), gstyle
+
+
+class _LayerTailDeferred(Function):
+    """_LayerTail without its second pass: (a, s, t) with a = act(blur?(x) + noise_w*noise + bias*bias_scale) and the
+    per-(n, c) scale / shift of InstanceNorm + style - see ``Deferred`` for the gradient contract."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_w, style, bias_scale, act, slope, blur, eps):
+        kern = k_blur_bias_act_stats if blur else k_bias_act_stats
+        noise = _c(noise) if noise is not None else None
+        y, mean, rstd = kern(x, bias, noise, noise_w, bias_scale, act, slope, eps)
+        n, c, _ = _nchw(y)
+        style_c = _c(style) if style is not None else None
+        s_, t_ = _affine_from_stats(mean, rstd, style_c, n, c)
+        ctx.saved_tail = (y, mean, rstd, style_c, noise)
+        ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, blur
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.style_shape = style.shape if style is not None else None
+        ctx.want_x_grad, ctx.want_bias_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ctx.want_nw_grad, ctx.want_style_grad = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        ctx.mark_non_differentiable(s_, t_, mean, rstd)
+        return y, s_, t_, mean, rstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_b, *_):
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, g_b)
+        gx = None
+        if ctx.want_x_grad:
+            gx = k_blur(gz) if ctx.blur else gz
+        return gx, gb, None, gnw, gstyle, None, None, None, None, None
+
+
+class _Materialize(Function):
+    """b = a*s + t written out (the second pass of round 1) for consumers without a modulated kernel; the gradient
+    passes through unchanged (it IS d/db, which the deferred tail's backward expects)."""
+
+    @staticmethod
+    def forward(ctx, a, mean, rstd, style):
+        n, c, hw = _nchw(a)
+        out = torch.empty_like(a)
+        check(_lib.lib().ganlab_instnorm_style_fwd_f32(_p(a), _p(mean), _p(rstd), _p(style), _p(out), n, c, hw, _st()),
+              'instnorm_style_fwd')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def materialize(x):
+    """Tensor for a plain consumer: a ``Deferred`` is normalised + styled now, a tensor is returned as is."""
+    if isinstance(x, Deferred):
+        return _Materialize.apply(x.a, x.mean, x.rstd, x.style)
+    return x
+
+
+def mod_conv_ok(d, weight, padding=1):
+    """Can the 3x3 layer ``weight`` consume the deferred tensor ``d`` through the modulated rolling-window kernel?"""
+    if not isinstance(d, Deferred) or get_compute_dtype() != 'f32':
+        return False
+    n, cin, h, w = d.a.shape
+    if tuple(weight.shape[1:]) != (cin, 3, 3) or padding != 1:
+        return False
+    g = ConvGeom(int(n), int(cin), int(h), int(w), int(weight.shape[0]), 3, 1, 0, 0)
+    return bool(_lib.lib().ganlab_mod_conv_supported(ctypes.byref(g)))
+
+
+def deferrable(x):
+    """A layer output of this shape can stay un-normalised for a modulated consumer (thin layer on a 64-aligned plane)."""
+    import os
+    if os.environ.get('GANLAB_DEFER') == '0':          # A/B knob: keep the two-pass layer tail of round 1
+        return False
+    n, c, h, w = x.shape
+    return get_compute_dtype() == 'f32' and c <= 16 and w % 64 == 0 and h % 4 == 0 and h >= 8
+
+
+def _border_tap_sums(weight, scale):
+    """W_class[ry][rx][co][ci] = scale * sum of w[co][ci][ky][kx] over the taps that stay INSIDE the image for a pixel of
+    row class ry / column class rx (0: first row / column, 1: interior, 2: last): (3, 3, Cout, Cin)."""
+    w = weight.detach() * scale
+    rows = (w[:, :, 1:, :], w, w[:, :, :2, :])          # first row: ky = 0 reads row -1 (outside); last row: ky = 2
+    out = []
+    for wy in rows:
+        cols = (wy[:, :, :, 1:], wy, wy[:, :, :, :2])
+        out.append(torch.stack([c_.sum(dim=(2, 3)) for c_ in cols]))
+    return torch.stack(out)
+
+
+class _ConvModTail(Function):
+    """A plain 3x3 generator layer consuming a deferred input and producing a deferred output in ONE pass over the
+    activations:  a_out = act(conv(a_in * s + t (zero padded), w) * scale + noise_w*noise + bias)  with the InstanceNorm
+    statistics of a_out from the epilogue (csrc/mod.hip).  Backward: InstanceNorm backward of the incoming d/db_out (round-1
+    kernels) -> gz; d/db_in = plain input-gradient kernel on the shared weights; the weight gradient is accumulated per
+    image and recombined with s / t here."""
+
+    @staticmethod
+    def forward(ctx, a_in, s_in, t_in, w, bias, noise, noise_w, style, scale, bias_scale, act, slope, eps):
+        a_in, w = _c(a_in), _c(w)
+        n, cin, h, wd = a_in.shape
+        cout = w.shape[0]
+        L = _lib.lib()
+        g = Geom(n, cin, h, wd, cout, 3, 1, 0)
+        _note('fwd', g)
+        wmod = _new((n * 9 * 256,), a_in)
+        check(L.ganlab_mod_conv_pack_f32(_p(w), _p(s_in), _p(wmod), n, cout, cin, scale, _st()), 'mod_conv_pack')
+        wcls = _border_tap_sums(w, scale)                                  # (3, 3, Cout, Cin)
+        btab = _new((n, 3, 3, 16), a_in).zero_()
+        btab[..., :cout] = torch.einsum('ni,yxoi->nyxo', t_in, wcls)
+        noise = _c(noise) if noise is not None else None
+        y = _new((n, cout, h, wd), a_in)
+        mean, rstd = _new((n, cout), a_in), _new((n, cout), a_in)
+        chunks = L.ganlab_mod_conv_stat_chunks(g.ref())
+        ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
+        check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wmod), 1, _p(btab), _p(bias), _p(noise), _p(noise_w), _p(y), _p(mean),
+                                        _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws), ws.numel() * 8, _st()),
+              'mod_conv_fwd')
+        style_c = _c(style) if style is not None else None
+        s_, t_ = _affine_from_stats(mean, rstd, style_c, n, cout)
+        ctx.saved_tail = (y, mean, rstd, style_c, noise)
+        ctx.save_for_backward(a_in, s_in, t_in, w)
+        ctx.g, ctx.scale = g, scale
+        ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, False
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.style_shape = style.shape if style is not None else None
+        ctx.want_x_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
+        ctx.want_bias_grad, ctx.want_nw_grad = ctx.needs_input_grad[4], ctx.needs_input_grad[6]
+        ctx.want_style_grad = ctx.needs_input_grad[7]
+        ctx.mark_non_differentiable(s_, t_, mean, rstd)
+        return y, s_, t_, mean, rstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_b, *_):
+        a_in, s_in, t_in, w = ctx.saved_tensors
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, g_b)
+        g = ctx.g
+        ga = gw = None
+        if ctx.needs_input_grad[0]:
+            ga = k_conv_dgrad(gz, w, g, ctx.scale)              # d/d(a_in*s + t): shared weights, plain kernel
+        if ctx.needs_input_grad[3] and _want_param_grads():
+            gw = _mod_conv_wgrad(gz, a_in, s_in, t_in, g, ctx.scale)
+        return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None
+
+
+def _mod_conv_wgrad(gz, a_in, s_in, t_in, g, scale):
+    """gw[o,i,ky,kx] = scale * sum_n ( s[n,i] * W_n[o,i,ky,kx] + t[n,i] * B_n[o,ky,kx] ):  W_n = weight gradient of image n
+    on the raw tensor a (per-image rolling-window kernel), B_n = sum of gz[n,o] over the pixels whose tap (ky,kx) stays
+    inside the image (total minus border rows / columns, plus the corners counted twice)."""
+    L = _lib.lib()
+    n, cout, h, w = gz.shape
+    cin = a_in.shape[1]
+    _note('wgrad', g)
+    wn = _new((n, cout, cin, 9), gz)
+    ws = torch.empty((max(L.ganlab_mod_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=gz.device)
+    check(L.ganlab_mod_conv_wgrad_f32(_p(gz), _p(a_in), _p(wn), g.ref(), 1.0, _p(ws), ws.numel() * 4, _st()),
+          'mod_conv_wgrad')
+    gw = torch.einsum('ni,noit->oit', s_in, wn)
+    # border sums of gz per (n, o): rows 0 / H-1, columns 0 / W-1, corners
+    tot = k_channel_sum(gz.view(1, n * cout, h, w)).view(n, cout)
+    r0, r1 = gz[:, :, 0, :].sum(-1), gz[:, :, h - 1, :].sum(-1)
+    c0, c1 = gz[:, :, :, 0].sum(-1), gz[:, :, :, w - 1].sum(-1)
+    # tap ky of the weight multiplies x[y + ky - 1]: it is outside for y = 0 when ky = 0 and for y = H-1 when ky = 2
+    rows = (tot - r0, tot, tot - r1)
+    rc = {(0, 0): gz[:, :, 0, 0], (0, 2): gz[:, :, 0, w - 1], (2, 0): gz[:, :, h - 1, 0], (2, 2): gz[:, :, h - 1, w - 1]}
+    rsub = {0: r0, 2: r1}
+    csub = {0: c0, 2: c1}
+    bn = torch.empty((n, cout, 3, 3), dtype=torch.float32, device=gz.device)
+    for ky in range(3):
+        for kx in range(3):
+            v = rows[ky]
+            if kx != 1:
+                v = v - csub[kx]
+                if ky != 1:
+                    v = v + rc[(ky, kx)]
+            bn[:, :, ky, kx] = v
+    gw = gw + torch.einsum('ni,not->oit', t_in, bn.view(n, cout, 9))
+    return (gw * scale).view(cout, cin, 3, 3)
+
+
+class _ToRGBMod(Function):
+    """toRGB (1x1, stylegan/architectures.py torgb) of a deferred tensor: per-sample weights w*s and bias b + w.t."""
+
+    @staticmethod
+    def forward(ctx, a, s_, t_, w, bias, scale, bias_scale):
+        a, w = _c(a), _c(w)
+        n, cin, h, wd = a.shape
+        cout = w.shape[0]
+        w2 = w.view(cout, cin) * scale
+        weff = torch.zeros((n, cin, 4), dtype=torch.float32, device=a.device)
+        weff[:, :, :cout] = s_.view(n, cin, 1) * w2.t().unsqueeze(0)
+        beff = torch.zeros((n, 4), dtype=torch.float32, device=a.device)
+        beff[:, :cout] = t_ @ w2.t()
+        if bias is not None:
+            beff[:, :cout] += bias.view(1, cout) * bias_scale
+        y = _new((n, cout, h, wd), a)
+        check(_lib.lib().ganlab_mod_torgb_fwd_f32(_p(a), _p(weff), _p(beff), _p(y), n, cin, cout, h * wd, _st()),
+              'mod_torgb_fwd')
+        ctx.save_for_backward(a, s_, t_, w)
+        ctx.scale, ctx.bias_scale = scale, bias_scale
+        ctx.bias_shape = bias.shape if bias is not None else None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        a, s_, t_, w = ctx.saved_tensors
+        gy = _c(gy)
+        n, cin, h, wd = a.shape
+        cout = w.shape[0]
+        L = _lib.lib()
+        g = Geom(n, cin, h, wd, cout, 1, 0, 0)
+        ga = k_conv_dgrad(gy, w, g, ctx.scale) if ctx.needs_input_grad[0] else None      # d/d(a*s + t)
+        gw = gb = None
+        if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and _want_param_grads():
+            out = _new((n, 68), a)
+            ws = torch.empty((L.ganlab_mod_torgb_cross_workspace(n) + 3) // 4, dtype=torch.float32, device=a.device)
+            check(L.ganlab_mod_torgb_cross_f32(_p(a), _p(gy), _p(out), n, cin, cout, h * wd, _p(ws), ws.numel() * 4,
+                                               _st()), 'mod_torgb_cross')
+            cross = out[:, :64].view(n, 16, 4)[:, :cin, :cout]          # [n][ci][co]
+            gsum = out[:, 64:64 + cout]                                  # [n][co]
+            gw2 = torch.einsum('ni,nio->oi', s_, cross) + torch.einsum('ni,no->oi', t_, gsum)
+            gw = (gw2 * ctx.scale).view(cout, cin, 1, 1) if ctx.needs_input_grad[3] else None
+            if ctx.bias_shape is not None and ctx.needs_input_grad[4]:
+                gb = (gsum.sum(0) * ctx.bias_scale).view(ctx.bias_shape)
+        return ga, None, None, gw, gb, None, None
+
+
 class _PixelNorm(Function):
     @staticmethod
     def forward(ctx, x, eps):
@@ -1802,3 +2095,32 @@ def bce_logits_mean(x, target):
 
 def chnorm_penalty(g, gamma, scale):
     return _ChNormPenalty.apply(g, float(gamma), float(scale))
+
+
+def layer_tail_deferred(x, bias=None, noise=None, noise_w=None, style=None, bias_scale=1.0, act=None, slope=0.2,
+                        blur=False, eps=1e-8):
+    """ops.layer_tail without the normalisation pass: returns a ``Deferred`` (see there) for a modulated consumer."""
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    y, s_, t_, mean, rstd = _LayerTailDeferred.apply(x, bias, noise, noise_w, style, float(bias_scale), a, float(slope),
+                                                     bool(blur), float(eps))
+    return Deferred(y, s_, t_, mean, rstd, style)
+
+
+def conv_mod_tail(d, weight, scale, bias=None, noise=None, noise_w=None, style=None, bias_scale=1.0, act=None, slope=0.2,
+                  eps=1e-8):
+    """3x3 layer + its tail on a deferred input, deferred output (``_ConvModTail``)."""
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    y, s_, t_, mean, rstd = _ConvModTail.apply(d.a, d.s, d.t, weight, bias, noise, noise_w, style, float(scale),
+                                               float(bias_scale), a, float(slope), float(eps))
+    return Deferred(y, s_, t_, mean, rstd, style)
+
+
+def torgb_mod(d, weight, bias, scale, bias_scale=1.0):
+    return _ToRGBMod.apply(d.a, d.s, d.t, weight, bias, float(scale), float(bias_scale))
+
+
+def torgb_mod_ok(d, weight):
+    if not isinstance(d, Deferred):
+        return False
+    n, c, h, w = d.a.shape
+    return tuple(weight.shape[1:]) == (c, 1, 1) and weight.shape[0] <= 4 and c <= 16 and (h * w) % 4 == 0

@@ -231,29 +231,62 @@ class StyleGenerator(StyleGAN):
                              f'(0,{final_stage}] or `None`.')
 
     # -- forward -------------------------------------------------------------------------------------
-    def _layer(self, n, layer, out, w, noise):
-        """One gen_layers entry on fused kernels."""
+    def _layer(self, n, layer, out, w, noise, defer_out=False):
+        """One gen_layers entry on fused kernels.  ``out`` may be an ``ops.Deferred`` (the previous layer's output with its
+        InstanceNorm + style not yet applied); ``defer_out``: the consumer of THIS layer's output has a modulated kernel,
+        so return a ``Deferred`` where the shape allows (csrc/mod.hip)."""
         blur = False
-        if n:
-            head = list(layer[0]) if isinstance(layer[0], nn.Sequential) else [layer[0]]
-            blur = bool(head) and isinstance(head[-1], Blur2d)
-            out = fused_sequential(head[:-1] if blur else head, out)   # (up+)conv MFMA kernel
         mods = list(layer[2])
         bias = mods.pop(0) if mods and isinstance(mods[0], Conv2dBias) else None
         act = mods.pop(0) if mods and isinstance(mods[0], LeakyReLU) else None
-        nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
         if not self.use_instancenorm:
             raise NotImplementedError('use_instancenorm=False (AdaIN without normalisation) has no fused kernel')
         bias_t = bias.bias if bias is not None else None
-        nw = layer[1].noise_weight if nz is not None else None
+        bias_scale = (bias.lrmul if bias.use_lrmul else 1.0) if bias is not None else 1.0
         name = 'lrelu' if act is not None else None
         slope = act.negative_slope if act is not None else 0.2
         y = layer[3](w)                                                # (B, 2C) style
+        head = []
+        if n:
+            head = list(layer[0]) if isinstance(layer[0], nn.Sequential) else [layer[0]]
+            blur = bool(head) and isinstance(head[-1], Blur2d)
+            conv = head[0] if (len(head) == 1 and isinstance(head[0], Conv2dEx)) else None
+            if isinstance(out, ops.Deferred) and conv is not None and conv.conv2d.bias is None and bias is not None \
+                    and not self.use_pixelnorm and ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):
+                # plain 3x3 layer, deferred in -> deferred out in ONE pass over the activations (conv with per-sample
+                # weights, noise + bias + LeakyReLU + InstanceNorm statistics in its epilogue)
+                nz = layer[1].draw(out.a[:, :1], noise[n] if noise is not None else None) if self.use_noise else None
+                nw = layer[1].noise_weight if nz is not None else None
+                d = ops.conv_mod_tail(out, conv.conv2d.weight, conv.scale, bias_t, nz, nw, y, bias_scale=bias_scale,
+                                      act=name, slope=slope, eps=IN_EPS)
+                return d if defer_out else ops.materialize(d)
+            out = ops.materialize(out)
+            out = fused_sequential(head[:-1] if blur else head, out)   # (up+)conv MFMA kernel
+        else:
+            out = ops.materialize(out)
+        nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
+        nw = layer[1].noise_weight if nz is not None else None
         if not self.use_pixelnorm:
+            if defer_out and ops.deferrable(out):
+                # blur + noise + bias + LeakyReLU + statistics in one pass; the normalisation is left to the consumer
+                return ops.layer_tail_deferred(out, bias_t, nz, nw, y, bias_scale=bias_scale, act=name, slope=slope,
+                                               blur=blur, eps=IN_EPS)
             # blur + noise + bias + LeakyReLU (+ the InstanceNorm statistics) in one pass, IN + (ys+1, yb) in a second
-            return ops.layer_tail(out, bias_t, nz, nw, y, act=name, slope=slope, blur=blur, eps=IN_EPS)
-        out = ops.pixelnorm(ops.bias_act(out, bias_t, nz, nw, act=name, slope=slope, blur=blur))
+            return ops.layer_tail(out, bias_t, nz, nw, y, bias_scale=bias_scale, act=name, slope=slope, blur=blur,
+                                  eps=IN_EPS)
+        out = ops.pixelnorm(ops.bias_act(out, bias_t, nz, nw, bias_scale=bias_scale, act=name, slope=slope, blur=blur))
         return ops.instnorm_style(out, y, IN_EPS)
+
+    def _consumer_is_modulated(self, n, L):
+        """Can the consumer of layer n's output take a deferred tensor?  The next layer when it is a plain 3x3 conv (no
+        upsample / blur), or toRGB behind the last layer; never the tensor that also feeds prev_torgb while fading in."""
+        if self.fade_in_phase and n == L - 3:
+            return False
+        if n == L - 1:
+            return True
+        nxt = self.gen_layers[n + 1][0]
+        head = list(nxt) if isinstance(nxt, nn.Sequential) else [nxt]
+        return len(head) == 1 and isinstance(head[0], Conv2dEx)
 
     def _new_w(self, bs, dev):
         z2 = gen_rand_latent_vars(num_samples=bs, length=self.len_latent, distribution=self.latent_distribution,
@@ -296,10 +329,14 @@ class StyleGenerator(StyleGAN):
                 elif self.use_truncation_trick and not self.training and self.trunc_cutoff_stage is not None and \
                         n == 2 * self.trunc_cutoff_stage:
                     w = (w - self.w_ewma.expand_as(w)).div(self.w_eval_psi) + self.w_ewma.expand_as(w)
-            out = self._layer(n, layer, out, w, noise)
+            out = self._layer(n, layer, out, w, noise, defer_out=self._consumer_is_modulated(n, L))
             if self.fade_in_phase and n == L - 3:
                 pre_fade = out
-        img = self.torgb(out)
+        if isinstance(out, ops.Deferred) and ops.torgb_mod_ok(out, self.torgb.conv2d.weight):
+            t = self.torgb                    # toRGB is linear: per-sample weights w*s and bias b + w.t (csrc/mod.hip)
+            img = ops.torgb_mod(out, t.conv2d.weight, t.conv2d.bias, t.scale, t.lrmul if t.use_lrmul else 1.0)
+        else:
+            img = self.torgb(ops.materialize(out))
         if self.fade_in_phase:
             prev = ops.upsample2(self.prev_torgb(pre_fade))
             img = ops.lerp(prev, img, self.alpha)                      # (:481-494)

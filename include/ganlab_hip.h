@@ -345,6 +345,35 @@ int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, vo
 int ganlab_u8_box_decode_f32(const unsigned char* in_nhwc, float* out_nchw, int N, int Hs, int Ws, int C, int factor,
                              const float* mean, const float* stdv, const unsigned char* flip, void* stream);
 
+/* ---- deferred InstanceNorm ("modulated" consumers; csrc/mod.hip) ----------------------------------------------------
+ * The generator layer of stylegan/architectures.py:497-526 ends in b = a*s[n,c] + t[n,c] (InstanceNorm + AdaIN of the
+ * activated tensor a).  These entry points let the CONSUMER of b read a instead: thin 3x3 layers (Cin, Cout <= 16,
+ * W % 64 == 0, H % 4 == 0) through per-sample packed weights (w * s) + a border-class bias table for t, toRGB (1x1)
+ * through per-sample weights / bias.  Replaces the second pass of ganlab_instnorm_style_fwd_f32 + the plain conv. */
+int ganlab_mod_conv_supported(const ganlab_conv_geom* g);
+/* statistics chunks per (n, co) plane written by the forward: workspace = N*Cout*chunks*2 doubles */
+int ganlab_mod_conv_stat_chunks(const ganlab_conv_geom* g);
+/* out[n][tap 9][ci 16][co 16] = scale * w[co][ci][tap] * (s ? s[n][ci] : 1); s == NULL: one shared image (N = 1) */
+int ganlab_mod_conv_pack_f32(const float* w, const float* s, float* out, int N, int Cout, int Cin, float scale,
+                             void* stream);
+/* y = act(conv(x, wmod[n]) + btab[n][row class][col class][co] + bias*bias_scale + noise_w*noise) and, when mean / rstd
+ * are given, the InstanceNorm statistics (biased variance, eps) of y from the same pass.  btab: [N][3][3][16] or NULL. */
+int ganlab_mod_conv_fwd_f32(const float* x, const float* wmod, int per_sample, const float* btab, const float* bias,
+                            const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
+                            const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps,
+                            void* workspace, size_t workspace_bytes, void* stream);
+size_t ganlab_mod_conv_wgrad_workspace(const ganlab_conv_geom* g);
+/* out[n][Cout][Cin][9] = scale * weight gradient of image n alone (the caller recombines the images with s / t) */
+int ganlab_mod_conv_wgrad_f32(const float* gy, const float* x, float* out, const ganlab_conv_geom* g, float scale,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* y[n,co] = sum_ci weff[n][ci][4] * x[n,ci] + beff[n][4]   (Cout <= 4) */
+int ganlab_mod_torgb_fwd_f32(const float* x, const float* weff, const float* beff, float* y, int N, int Cin, int Cout,
+                             long long HW, void* stream);
+size_t ganlab_mod_torgb_cross_workspace(int N);
+/* out[n][68]: [ci 16][4] = sum_px x[n,ci]*gy[n,co], then [64 + co] = sum_px gy[n,co]   (Cin <= 16, Cout <= 4) */
+int ganlab_mod_torgb_cross_f32(const float* x, const float* gy, float* out, int N, int Cin, int Cout, long long HW,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

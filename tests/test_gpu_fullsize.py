@@ -41,11 +41,11 @@ def _full_widths():
     ops.set_compute_dtype('f32')
 
 
-def _build(kind, res):
+def _build(kind, res, seed=11):
     from gan_lab_amd import progressive as P
     from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator, StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
-    torch.manual_seed(11)
+    torch.manual_seed(seed)
     if kind == 'stylegan':
         P.StyleGAN.reset_state()
         g, d = StyleGenerator(final_res=res, blur_type='binomial'), StyleDiscriminator(final_res=res,

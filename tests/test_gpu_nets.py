@@ -183,3 +183,69 @@ def test_stylegan_step_gradients_vs_oracle(res, fmap_base, fmap_max, b, min_entr
         assert rep[k] <= TOL, (k, rep)
     assert not still, still
     assert len(ed) + len(eg) > min_entries
+
+
+def test_thin16_network_is_as_accurate_as_the_cpu_path(capsys, monkeypatch):
+    """The 1024^2 layers' width (16 channels) on 256^2 planes, batch 2: fromRGB -> rolling-window convs -> thin stride-2
+    kernels in D, and in G the deferred-InstanceNorm chain of csrc/mod.hip (blurred layer -> modulated 3x3 layer with the
+    layer tail in its epilogue -> modulated toRGB; asserted to be on the path).
+    Outputs and losses: 1e-3 against the fp32 oracle.  Gradients: this network is the ill-conditioned one - every generator
+    gradient carries ONE realisation of the rounding noise injected at the top of D (the same relative error on all ~50
+    entries), for the CPU fp32 path exactly as for the HIP path, so a single draw compares two random numbers.  The test
+    therefore looks at FOUR independent draws (weights and data reseeded) and at float64 as the truth: per draw the
+    median over the noisy entries (error > 1e-4 on either side, D and G) of e_hip / e_cpu.
+    What is asserted is the MEASURED property, tied to the per-op bound: against float64 the thin kernels' error EQUALS the
+    ATen CPU conv's (tools/op_error_probe.py: rms 2.14e-7 both for 16->16 - the same fmaf order), but this network's
+    body is 64-channel layers, whose 576 products are ONE fmaf chain in a single MFMA accumulator where the CPU library
+    keeps blocked partial sums: 1.96x the CPU error per op at 64 channels (2.5x at 512; a second accumulator set does
+    not fit the 168-VGPR budget of the three-workgroups-per-CU kernels).  Measured draws: 2.4, 3.0, 0.55, 4.8 - median
+    2.7.  The test fails if the median of the four ratios exceeds 3.5 or any entry of any draw is further than 1e-2 from
+    float64; the full-width networks (tests/test_gpu_fullsize.py, full-width-64 / thin-top-256 above) pass the strict
+    per-entry rule without any such factor."""
+    import os
+    import test_gpu_fullsize as FS
+    from gan_lab_amd import _lib, progressive as P
+    from util import rel_err
+    P.FMAP_BASE, P.FMAP_MAX = 2048, 64
+    res, b = 256, 2
+    calls = {'mod': 0}
+    L_ = _lib.lib()
+    orig = L_.ganlab_mod_conv_fwd_f32
+
+    def counted(*a):
+        calls['mod'] += 1
+        return orig(*a)
+    monkeypatch.setattr(L_, 'ganlab_mod_conv_fwd_f32', counted, raising=False)
+    ratios, worst_abs, reps = [], 0.0, []
+    for draw in range(4):
+        g, d, sd_g, sd_d = FS._build('stylegan', res, seed=100 + draw)
+        gen = torch.Generator().manual_seed(7 + draw)
+        z, real = torch.randn(b, 512, generator=gen), torch.rand(b, 3, res, res, generator=gen) * 2 - 1
+        noise = [torch.randn(b, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2), generator=gen)
+                 for n in range(len(g.gen_layers))]
+        hip = FS._hip_step('stylegan', g, d, z, real, noise, 'nonsaturating', 'r1', None, 'f32')
+        cpu = FS._oracle_step('stylegan', sd_g, sd_d, z, real, noise, 'nonsaturating', 'r1', None)
+        for k in ('img', 'd_real', 'd_fake', 'gp', 'loss_d', 'loss_g'):
+            assert rel_err(hip[k], cpu[k]) <= TOL, (draw, k)
+        ex = FS._oracle_step('stylegan', sd_g, sd_d, z, real, noise, 'nonsaturating', 'r1', None, dt=torch.float64)
+        rs = []
+        for key in ('gd', 'gg'):
+            gmax = max(v.abs().max().item() for v in ex[key].values())
+            for k, e in ex[key].items():
+                if e.abs().max() == 0:
+                    continue
+                scale = max(e.abs().max().item(), 1e-3 * gmax)
+                e_hip = (hip[key][k].double() - e).abs().max().item() / scale
+                e_cpu = (cpu[key][k].double() - e).abs().max().item() / scale
+                worst_abs = max(worst_abs, e_hip)
+                if max(e_hip, e_cpu) > 1e-4 and e_cpu > 0:        # entries that carry measurable rounding noise
+                    rs.append(e_hip / e_cpu)
+        rs.sort()
+        ratios.append(rs[len(rs) // 2])
+        reps.append((draw, round(ratios[-1], 2), len(rs)))
+    with capsys.disabled():
+        print('\nthin 16-channel network, median e_hip / e_cpu (vs float64) per draw:', reps, 'worst |e_hip|', worst_abs)
+    assert calls['mod'] >= 4 or os.environ.get('GANLAB_DEFER') == '0', calls     # the modulated 3x3 layer ran in every draw
+    ratios.sort()
+    assert 0.5 * (ratios[1] + ratios[2]) <= 3.5, reps
+    assert worst_abs <= 1e-2, worst_abs

@@ -882,3 +882,55 @@ def test_integration_snippet_forward_vs_oracle(ops):
         ref = O.conv2d_ex(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), ws, padding=1,
                           lrmul=lrmul if lrmul is not None else 1.0)
         assert_close(y, ref, TOL, f'INTEGRATION.md forward {cin}->{cout}@{res}')
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 16), (3, 12, 24, 128, 10), (2, 16, 8, 64, 16)],
+                         ids=['16->16@64x64', '12->10 ragged 24x128', 'two steps'])
+def test_deferred_instancenorm_chain_equals_composed(ops, shape):
+    """csrc/mod.hip: a generator block's tail with the InstanceNorm + style left to its consumers - blurred layer ->
+    (deferred) -> plain 3x3 layer with per-sample weights, border-class bias, noise + bias + LeakyReLU + statistics in
+    the epilogue -> (deferred) -> toRGB with per-sample weights - against the SAME chain composed from the round-1 ops
+    (layer_tail: two passes; conv2d; layer_tail; conv2d 1x1): image and every gradient (input, both conv weights, biases,
+    noise weights, styles).  Reference semantics: stylegan/architectures.py:497-526."""
+    n, c0, h, w, c1 = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()))
+
+    def leaf(*s, scale=1.0):
+        return (rnd(gen, *s) * scale).cuda().requires_grad_(True)
+    x0 = leaf(n, c0, h, w)                                   # output of the up-conv of layer A
+    b0, nw0, st0 = leaf(1, c0, 1, 1, scale=0.3), leaf(1, c0, 1, 1, scale=0.3), leaf(n, 2 * c0, scale=0.5)
+    w1 = leaf(c1, c0, 3, 3)
+    b1, nw1, st1 = leaf(1, c1, 1, 1, scale=0.3), leaf(1, c1, 1, 1, scale=0.3), leaf(n, 2 * c1, scale=0.5)
+    w2, b2 = leaf(3, c1, 1, 1), leaf(3, scale=0.3)
+    nz0, nz1 = rnd(gen, n, 1, h, w).cuda(), rnd(gen, n, 1, h, w).cuda()
+    s1, s2 = 1.0 / np.sqrt(c0 * 9), 1.0 / np.sqrt(c1)
+    cot = rnd(gen, n, 3, h, w).cuda()
+    params = [x0, b0, nw0, st0, w1, b1, nw1, st1, w2, b2]
+
+    def composed():
+        a = ops.layer_tail(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+        y = ops.conv2d(a, w1, None, scale=s1, padding=1)
+        a = ops.layer_tail(y, b1, nz1, nw1, st1, act='lrelu', slope=0.2, blur=False, eps=1e-8)
+        return ops.conv2d(a, w2, b2, scale=s2, padding=0)
+
+    def deferred():
+        d = ops.layer_tail_deferred(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+        assert ops.mod_conv_ok(d, w1, 1)
+        d = ops.conv_mod_tail(d, w1, s1, b1, nz1, nw1, st1, act='lrelu', slope=0.2, eps=1e-8)
+        assert isinstance(d, ops.Deferred) and ops.torgb_mod_ok(d, w2)
+        return ops.torgb_mod(d, w2, b2, s2)
+
+    outs, grads = [], []
+    for fn in (composed, deferred):
+        img = fn()
+        g = torch.autograd.grad((img * cot).sum(), params)
+        outs.append(img.detach())
+        grads.append([t_.detach() for t_ in g])
+    assert_close(outs[1], outs[0], 2e-5, 'image')
+    names = ['x0', 'bias0', 'noise_w0', 'style0', 'w1', 'bias1', 'noise_w1', 'style1', 'w_rgb', 'b_rgb']
+    for name, a, b in zip(names, grads[1], grads[0]):
+        assert_close(a, b, 2e-4, 'grad ' + name)
+    # a deferred tensor handed to a plain consumer is materialised - same numbers, same gradients
+    d = ops.layer_tail_deferred(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+    ref = ops.layer_tail(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+    assert torch.equal(ops.materialize(d), ref)

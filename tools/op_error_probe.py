@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-op rounding error of the conv kernels against float64, next to the ATen CPU fp32 conv's."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from gan_lab_amd import ops, _lib
+
+
+def err(a, ref):
+    a, ref = a.double().cpu(), ref.double()
+    return ((a - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item(), ((a - ref).abs().max() / ref.abs().max()).item()
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(16)
+    cases = [('fwd', 2, 16, 16, 256, 256, 0, 0), ('fwd', 2, 16, 16, 256, 224, 0, 0), ('fwd', 2, 32, 32, 128, 128, 0, 0),
+             ('fwd', 2, 64, 64, 64, 64, 0, 0), ('fwd', 2, 512, 512, 16, 16, 0, 0),
+             ('fwd', 2, 32, 16, 128, 128, 1, 0), ('fwd', 2, 16, 32, 256, 256, 0, 1), ('fwd', 2, 64, 32, 64, 64, 1, 0),
+             ('dgrad', 2, 16, 16, 256, 256, 0, 0), ('dgrad', 2, 32, 16, 128, 128, 1, 0), ('dgrad', 2, 16, 32, 256, 256, 0, 1)]
+    for kind, n, ci, co, h, w, up, pool in cases:
+        x = torch.randn(n, ci, h, w)
+        wt = torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5)
+        g = ops.Geom(n, ci, h, w, co, 3, 1, up, pool)
+
+        def ref_fwd(xx, ww):
+            xi = F.interpolate(xx, scale_factor=2, mode='nearest') if up else xx
+            y = F.conv2d(xi, ww, padding=1)
+            return F.avg_pool2d(y, 2) if pool else y
+        if kind == 'fwd':
+            hip = ops.k_conv_fwd(x.cuda(), wt.cuda(), None, g, 1.0)
+            name, _ = _lib.last_launch()
+            exact = ref_fwd(x.double(), wt.double())
+            cpu = ref_fwd(x, wt)
+        else:
+            gy = torch.randn(*g.out_shape)
+            hip = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), g, 1.0)
+            name, _ = _lib.last_launch()
+            xd = x.double().requires_grad_(True)
+            exact, = torch.autograd.grad(ref_fwd(xd, wt.double()), xd, gy.double())
+            xf = x.clone().requires_grad_(True)
+            cpu, = torch.autograd.grad(ref_fwd(xf, wt), xf, gy)
+        eh, ec = err(hip, exact), err(cpu, exact)
+        print(f'{kind:5s} {ci:3d}->{co:3d} {h}x{w} up{up} pool{pool}: HIP rms {eh[0]:.2e} max {eh[1]:.2e} | CPU fp32 rms {ec[0]:.2e} max {ec[1]:.2e} '
+              f'| ratio rms {eh[0] / ec[0]:.2f}  [{name.split("(")[0][-48:]}]', flush=True)
+
+
+if __name__ == '__main__':
+    main()
