@@ -784,6 +784,7 @@ if __name__ == '__main__':
                                          gp='wgan-gp', seed=4),
         'pg_fade8': lambda: golden_nets('progan', 8, True, 0.6, 'progan_fade8', loss='wgan', gp='wgan-gp',
                                         seed=5),
+        'sg_r2_8': lambda: golden_nets('stylegan', 8, False, 1.0, 'stylegan_r2_8', gp='r2', seed=6),
         'mixing': golden_mixing,
         'step_sg': lambda: golden_step('stylegan', 16, 'step_stylegan16', 'nonsaturating', 'r1'),
         'step_sg_fade': lambda: golden_step('stylegan', 8, 'step_stylegan8_fade', 'nonsaturating', 'r1',

@@ -41,7 +41,7 @@ def _restore_widths():
     P.FMAP_BASE, P.FMAP_MAX = 8192, 512
 
 
-NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'progan_stab16', 'progan_fade8']
+NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16', 'progan_fade8']
 
 
 @pytest.mark.parametrize('name', NETS)

@@ -101,7 +101,7 @@ def test_noise_and_losses(G):
 
 
 # ---------------------------------------------------------------------------------------------- #
-NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'progan_stab16',
+NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16',
         'progan_fade8']
 
 
