@@ -1234,11 +1234,11 @@ def _affine_from_stats(mean, rstd, style, n, c):
     return s_.contiguous(), t_.contiguous()
 
 
-def _layer_tail_backward(ctx, gout):
+def _layer_tail_backward(ctx, saved_tail, gout):
     """Shared by _LayerTail / _LayerTailDeferred / _ConvModTail: InstanceNorm + style backward of ``gout`` (the gradient
     with respect to the normalised tensor), LeakyReLU undone, bias / noise-weight / style gradients from the same pass.
     Returns (gz, gb, gnw, gstyle)."""
-    y, mean, rstd, style, noise = ctx.saved_tail
+    y, mean, rstd, style, noise = saved_tail
     gout = _c(gout)
     n, c, hw = _nchw(y)
     L = _lib.lib()
@@ -1279,7 +1279,9 @@ class _LayerTailDeferred(Function):
         n, c, _ = _nchw(y)
         style_c = _c(style) if style is not None else None
         s_, t_ = _affine_from_stats(mean, rstd, style_c, n, c)
-        ctx.saved_tail = (y, mean, rstd, style_c, noise)
+        # (save_for_backward, not attributes: y is an OUTPUT of this node - holding it on ctx would be a reference
+        # cycle that only Python's cyclic collector breaks, i.e. 2 GiB tensors freed late and a growing allocator)
+        ctx.save_for_backward(y, mean, rstd, style_c, noise)
         ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, blur
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
@@ -1292,7 +1294,7 @@ class _LayerTailDeferred(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_b, *_):
-        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, g_b)
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors, g_b)
         gx = None
         if ctx.want_x_grad:
             gx = k_blur(gz) if ctx.blur else gz
@@ -1386,8 +1388,7 @@ class _ConvModTail(Function):
               'mod_conv_fwd')
         style_c = _c(style) if style is not None else None
         s_, t_ = _affine_from_stats(mean, rstd, style_c, n, cout)
-        ctx.saved_tail = (y, mean, rstd, style_c, noise)
-        ctx.save_for_backward(a_in, s_in, t_in, w)
+        ctx.save_for_backward(a_in, s_in, t_in, w, y, mean, rstd, style_c, noise)
         ctx.g, ctx.scale = g, scale
         ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, False
         ctx.bias_shape = bias.shape if bias is not None else None
@@ -1402,8 +1403,8 @@ class _ConvModTail(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_b, *_):
-        a_in, s_in, t_in, w = ctx.saved_tensors
-        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, g_b)
+        a_in, s_in, t_in, w = ctx.saved_tensors[:4]
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors[4:], g_b)
         g = ctx.g
         ga = gw = None
         if ctx.needs_input_grad[0]:
