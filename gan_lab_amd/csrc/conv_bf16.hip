@@ -23,6 +23,9 @@
 // load plus a lane shuffle) so every operand read stays a 16-byte aligned ds_read_b128.
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -357,6 +360,317 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(BfWgArgs p) {
       }
 }
 
+// ---- weight gradient, rolling rows fed by LDS-DMA (the default) ----------------------------------------------------
+// The tile kernel above writes every activation row to LDS three times (one bf16 copy per horizontal tap) and is bound by
+// those ds_write_b64, not by the matrix cores; a first rolling kernel with register staging ran one global-load latency
+// per row.  Here the fp32 rows go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, three rows in flight
+// per pipeline) and become bf16 in REGISTERS, where the tap shift is free - it is the choice of which fp32 pairs
+// v_cvt_pk_bf16_f32 packs:
+//   lane (k-group g, l16 = ci): f[4..11] = x[ci][8g .. 8g+7] (2 ds_read_b128), f[3] / f[12] = the neighbouring k-group's
+//                               last / first pixel (ds_bpermute) or the strip's halo pixel; B_kx[j] = f[3 + j + kx]
+//   lane (g, l16 = co):         A[j] = gy[co][8g + j] (2 ds_read_b128)
+// A pipeline (4 waves) owns 64 co x 64 ci x 9 taps (wave = 32 x 32: 2 x 2 x 9 accumulator tiles) and walks segments of RS
+// image rows x 32 columns.  One step = one activation row R: it meets the gradient rows R+1, R, R-1 (ky = 0, 1, 2),
+// whose fragments roll through three register slots (the loop is unrolled by 3 so the slot <-> ky map is static), so
+// each step brings ONE x row and ONE gy row: 16.5 KB into a ring of four slots, one barrier per step, 36 MFMAs per wave.
+// Every step runs all 36 MFMAs: a gradient row outside the segment, an activation row outside the image and a halo
+// pixel outside the image are read from a slot of zeros (an address offset), which keeps the accumulators out of
+// branches.
+// LDS image of a row slice: [channel][8 units of 4 pixels], unit u of channel c at position u ^ swz(c) - an LDS-DMA
+// writes 64 x 16 bytes in lane order, so the swizzle is applied to the SOURCE address (8 lanes still fetch one whole
+// 128-byte line) and again by the reader; swz() makes the 16 lanes of every ds_read_b128 group hit 16 different slots.
+// A 512-thread workgroup runs TWO pipelines on different segments of the same 64 x 64 tile and adds the second one's
+// accumulators to the first through LDS before the flush, which halves the partial-sum traffic.
+// Measured per row and pipeline pair (128 -> 128 @128^2 x8): 0.27 us of MFMA, 0.17 us of LDS-DMA (the address unit
+// takes 64 B per clock: 16.5 KB + two 64-line halo gathers) and 0.07 us of everything else - and they ADD UP: with the
+// DMAs issued but never waited for the time is the same, so the cost is the address unit's, not the latency's.
+constexpr int RW_T = 64;
+constexpr int RW_D = 4;                                  // ring slots: compute on t, DMAs of t+1 .. t+3 in flight
+constexpr int RW_ROW = 8 * RW_T;                         // 16-byte units of a 32-pixel row slice of 64 channels
+constexpr int RW_SLOT = 2 * RW_ROW + 32;                 // gy slice, x slice, 64 + 64 halo pixels
+constexpr int RW_PIPE = RW_D * RW_SLOT;                  // 66 KB per pipeline
+
+struct BfWrArgs {
+  const float* gy;
+  const float* x;
+  float* ws;          // [flush slot][pair][wave][tile][lane] float4
+  int N, CI, CO, H, W;
+  int tiles_ci, npairs, RS, segs_y, strips, nseg, streams;
+};
+
+__device__ __forceinline__ int rw_swz(int ch) { return (((ch >> 1) & 3) << 1) | ((((ch & 15) + 4) >> 3) & 1); }
+
+typedef __attribute__((address_space(1))) const void* rw_gptr;
+typedef __attribute__((address_space(3))) void* rw_lptr;
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 smem[2 * RW_PIPE + RW_SLOT];   // two rings + one slot of zeros
+
+  // wave-uniform quantities are made SGPRs explicitly: the row / segment arithmetic then costs no vector registers
+  const int kgp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int wv = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+  const int lane = threadIdx.x & 63, l16 = lane & 15, kg = lane >> 4;
+  const int wa = wv >> 1, wc = wv & 1;
+  const int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % p.npairs, slot = bid / p.npairs;
+  const int ci0 = (pair % p.tiles_ci) * RW_T, co0 = (pair / p.tiles_ci) * RW_T;
+  const int plane = p.H * p.W;
+  u32x4* const ring = smem + kgp * RW_PIPE;
+  for (int i = threadIdx.x; i < RW_SLOT; i += 512) smem[2 * RW_PIPE + i] = u32x4{0u, 0u, 0u, 0u};
+  const unsigned zslot = (unsigned)((2 - kgp) * RW_PIPE) * 16u;       // byte offset of the zero slot from `ring`
+  // LDS byte addresses of this lane's fragment reads inside a ring slot (the reads are inline asm: hipcc would put
+  // s_waitcnt vmcnt(0) in front of every ds_read it emits itself while an LDS-DMA is in flight)
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(rw_lptr)ring;
+  const int sw = rw_swz(l16);
+  unsigned aaddr[2][2], baddr[2][2], eaddr[2];
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    const int ca = wa * 32 + nn * 16 + l16, cb = wc * 32 + nn * 16 + l16;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      aaddr[nn][o] = lds0 + (unsigned)(ca * 8 + ((2 * kg + o) ^ sw)) * 16u;
+      baddr[nn][o] = lds0 + (unsigned)(RW_ROW + cb * 8 + ((2 * kg + o) ^ sw)) * 16u;
+    }
+    eaddr[nn] = lds0 + (unsigned)(2 * RW_ROW) * 16u + (unsigned)((kg >> 1) * 64 + cb) * 4u;
+  }
+
+  // DMA work of this wave per step: LDS-DMA instructions 2wv, 2wv + 1 of the gy slice and of the x slice (8 channels x
+  // 8 units each; the same per-lane byte offset serves both tensors) and, for waves 0 / 1, one 4-byte gather of the 64
+  // left / right halo pixels
+  unsigned doff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ch = 8 * (2 * wv + k) + (lane >> 3);
+    doff[k] = (unsigned)(ch * plane + 4 * ((lane & 7) ^ rw_swz(ch))) * 4u;
+  }
+  const unsigned hoff = (unsigned)(lane * plane) * 4u;
+
+  f32x4 acc[2][2][9];
+#pragma unroll
+  for (int na = 0; na < 2; ++na)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[na][nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int RS = p.RS, T = (RS + 4) / 3 * 3;                   // RS + 2 steps, rounded up to the unroll
+  const int nloop = (p.nseg + p.streams - 1) / p.streams;      // the same for both pipelines: barriers are shared
+  for (int it = 0; it < nloop; ++it) {
+    const int seg = (slot * 2 + kgp) + it * p.streams;
+    const bool live = seg < p.nseg && slot * 2 + kgp < p.streams;
+    int sx = 0, sy = 0, n = 0;
+    if (live) {
+      sx = seg % p.strips;
+      const int t2 = seg / p.strips;
+      sy = t2 % p.segs_y;
+      n = t2 / p.segs_y;
+    }
+    const int ox0 = sx * 32, r0 = sy * RS;
+    const char* gyb = reinterpret_cast<const char*>(p.gy + ((long long)n * p.CO + co0) * plane);
+    const char* xb = reinterpret_cast<const char*>(p.x + ((long long)n * p.CI + ci0) * plane);
+    const bool lok = ox0 > 0, rok = ox0 + 32 < p.W;
+    // halo gather: wave 0 fetches x[.., ox0 - 1], wave 1 x[.., ox0 + 32] (clamped into the row; lanes whose halo
+    // pixel lies outside the image read the zero slot instead)
+    const int hcol = (wv & 1) ? (rok ? ox0 + 32 : ox0 + 31) : (lok ? ox0 - 1 : ox0);
+    const bool ezero = (kg == 0 && !lok) || (kg == 3 && !rok);
+
+    auto issue = [&](int t) {
+      u32x4* q = ring + (t & (RW_D - 1)) * RW_SLOT;
+      int gr = r0 + t, xr = r0 - 1 + t;                       // rows; out of range -> any valid row, never read
+      gr = gr < p.H ? gr : p.H - 1;
+      xr = xr < 0 ? 0 : (xr < p.H ? xr : p.H - 1);
+      const unsigned grow = (unsigned)(gr * p.W + ox0) * 4u, xrow = (unsigned)(xr * p.W + ox0) * 4u;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __builtin_amdgcn_global_load_lds((rw_gptr)(gyb + (doff[k] + grow)), (rw_lptr)(q + (2 * wv + k) * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (doff[k] + xrow)), (rw_lptr)(q + RW_ROW + (2 * wv + k) * 64), 16,
+                                         0, 0);
+      }
+      if (wv < 2)
+        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (hoff + (unsigned)(xr * p.W + hcol) * 4u)),
+                                         (rw_lptr)(reinterpret_cast<float*>(q + 2 * RW_ROW) + wv * 64), 4, 0, 0);
+    };
+    // outstanding DMAs of two steps: 2 x 5 for waves 0 and 1 (which also gather the halo), 2 x 4 for waves 2 and 3
+    auto wait_two_steps = [&]() {
+      if (wv < 2)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+
+    bf16x8 a[3][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+      for (int na = 0; na < 2; ++na) a[s_][na] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+
+    auto compute = [&](int t, auto phase) {
+      constexpr int P = decltype(phase)::value;
+      const unsigned so = (unsigned)((t & (RW_D - 1)) * RW_SLOT) * 16u;
+      const int R = r0 - 1 + t;
+      const bool gok = live && t < RS, xok = live && t < RS + 2 && (unsigned)R < (unsigned)p.H;
+      const unsigned sog = gok ? so : zslot, sox = xok ? so : zslot;
+      u32x4 fa[2][2], fm[2][2];
+      float fe[2];
+#pragma unroll
+      for (int na = 0; na < 2; ++na) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[na][0]) : "v"(aaddr[na][0] + sog));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[na][1]) : "v"(aaddr[na][1] + sog));
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fm[nb][0]) : "v"(baddr[nb][0] + sox));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fm[nb][1]) : "v"(baddr[nb][1] + sox));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fe[nb]) : "v"(ezero ? eaddr[nb] + zslot : eaddr[nb] + sox));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fm[0][0]), "+v"(fm[0][1]),
+                     "+v"(fe[0]), "+v"(fm[1][0]), "+v"(fm[1][1]), "+v"(fe[1]));
+      // from here to the barrier the compiler is free to interleave the conversions with the MFMAs
+#pragma unroll
+      for (int na = 0; na < 2; ++na) {
+        const u32x4 f0 = fa[na][0], f1 = fa[na][1];
+        a[P][na] = __builtin_bit_cast(
+            bf16x8, pack8(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                          __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)));
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const u32x4 m0 = fm[nb][0], m1 = fm[nb][1];
+        const float e = fe[nb];
+        const float pl = __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)m1.w));
+        const float pr = __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 16) << 2, (int)m0.x));
+        const float f3 = kg == 0 ? e : pl, f12 = kg == 3 ? e : pr;
+        const float f4 = __uint_as_float(m0.x), f5 = __uint_as_float(m0.y), f6 = __uint_as_float(m0.z),
+                    f7 = __uint_as_float(m0.w), f8 = __uint_as_float(m1.x), f9 = __uint_as_float(m1.y),
+                    f10 = __uint_as_float(m1.z), f11 = __uint_as_float(m1.w);
+        bf16x8 b[3];
+        b[0] = __builtin_bit_cast(bf16x8, pack8(f3, f4, f5, f6, f7, f8, f9, f10));     // x[8g - 1 .. 8g + 6]
+        b[1] = __builtin_bit_cast(bf16x8, pack8(f4, f5, f6, f7, f8, f9, f10, f11));    // x[8g .. 8g + 7]
+        b[2] = __builtin_bit_cast(bf16x8, pack8(f5, f6, f7, f8, f9, f10, f11, f12));   // x[8g + 1 .. 8g + 8]
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int sl = (P + 3 - ky) % 3;      // gradient row r0 + t - ky sits in slot (P - ky) mod 3
+#pragma unroll
+          for (int na = 0; na < 2; ++na)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+              acc[na][nb][ky * 3 + kx] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[sl][na], b[kx], acc[na][nb][ky * 3 + kx], 0, 0, 0);
+        }
+      }
+    };
+    // DMA(t+3) goes into the slot read in step t-1 (all waves are past that step's barrier); before this step's
+    // barrier each wave waits until only its DMAs of t+2 and t+3 are outstanding, i.e. its part of t+1 has landed
+    auto step = [&](int t, auto phase) {
+      compute(t, phase);
+      issue(t + 3);          // after the MFMAs are queued (issued first it costs 5 - 10 % more)
+      wait_two_steps();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+
+    issue(0);
+    issue(1);
+    issue(2);
+    wait_two_steps();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // first pass: the zero slot's ds_writes
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; t += 3) {      // T is a multiple of 3: steps past RS + 1 multiply zeros
+      step(t, std::integral_constant<int, 0>{});
+      step(t + 1, std::integral_constant<int, 1>{});
+      step(t + 2, std::integral_constant<int, 2>{});
+    }
+    // the DMAs issued for steps T .. T+2 still target the ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // the second pipeline hands its accumulators over through LDS, one tap row (12 tiles) per round
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    __syncthreads();
+    if (kgp == 1) {
+#pragma unroll
+      for (int na = 0; na < 2; ++na)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            red[((wv * 12) + (na * 2 + nb) * 3 + kx) * 64 + lane] = acc[na][nb][ky * 3 + kx];
+    }
+    __syncthreads();
+    if (kgp == 0) {
+#pragma unroll
+      for (int na = 0; na < 2; ++na)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            acc[na][nb][ky * 3 + kx] += red[((wv * 12) + (na * 2 + nb) * 3 + kx) * 64 + lane];
+    }
+  }
+  if (kgp == 1) return;
+  // flush in register order (whole 1 KB wave stores): ws[slot][pair][wave][tile = (na, nb, tap)][lane] float4; the
+  // reduce kernel sums the slots and scatters to [co][ci][9]
+  f32x4* wsb = reinterpret_cast<f32x4*>(p.ws) + (((long long)slot * p.npairs + pair) * 4 + wv) * (36 * 64) + lane;
+#pragma unroll
+  for (int na = 0; na < 2; ++na)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) wsb[((na * 2 + nb) * 9 + tap) * 64] = acc[na][nb][tap];
+}
+
+// D[i = co][j = ci] of tile (na, nb, tap) of wave (wa, wc): lane holds co = 32wa + 16na + 4kg + r, ci = 32wc + 16nb + l16
+__global__ void wgrad_bf16_roll_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ gw, int npairs,
+                                              int tiles_ci, int CI, int slots, float scale) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;        // (pair, wave, tile, lane)
+  if (e >= npairs * 4 * 36 * 64) return;
+  const int lane = e & 63, tile = (e >> 6) % 36, wv = (e / (64 * 36)) & 3, pair = e / (64 * 36 * 4);
+  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < slots; ++k) sum += ws[(long long)k * npairs * (4 * 36 * 64) + e];   // fixed order: deterministic
+  const int tap = tile % 9, nb = (tile / 9) & 1, na = tile / 18;
+  const int co = (pair / tiles_ci) * RW_T + (wv >> 1) * 32 + na * 16 + (lane >> 4) * 4;
+  const int ci = (pair % tiles_ci) * RW_T + (wv & 1) * 32 + nb * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gw[((long long)(co + r) * CI + ci) * 9 + tap] = sum[r] * scale;
+}
+
+struct WrPlan {
+  int RS, segs_y, strips, nseg, streams, flush_slots;
+};
+
+bool wr_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("GANLAB_BF16_WGRAD_ROLL");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return v;
+}
+
+WrPlan wr_plan(const ganlab_conv_geom* g) {
+  WrPlan q;
+  q.RS = 4;
+  for (int d = 32; d >= 4; --d)
+    if (g->Hin % d == 0) {
+      q.RS = d;
+      break;
+    }
+  q.segs_y = g->Hin / q.RS;
+  q.strips = g->Win / 32;
+  q.nseg = g->N * q.strips * q.segs_y;
+  const int npairs = (g->Cout / RW_T) * (g->Cin / RW_T);
+  int want = (512 + npairs - 1) / npairs;          // two 4-wave pipelines (one 512-thread workgroup) per CU
+  if (want > q.nseg) want = q.nseg;
+  if (want < 1) want = 1;
+  const int per = (q.nseg + want - 1) / want;      // segments per pipeline
+  q.streams = (q.nseg + per - 1) / per;
+  q.flush_slots = (q.streams + 1) / 2;
+  return q;
+}
+
 __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, long long n, int slots,
                                          float scale) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -428,7 +742,8 @@ int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const gan
 
 size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g) {
   if (!bf16_ok(g)) return 0;
-  return (size_t)wgrad_slots(g) * g->Cout * g->Cin * 9 * sizeof(float);
+  const int slots = wr_enabled() ? wr_plan(g).flush_slots : wgrad_slots(g);
+  return (size_t)slots * g->Cout * g->Cin * 9 * sizeof(float);
 }
 
 int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
@@ -436,6 +751,20 @@ int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const gan
   if (gy == nullptr || x == nullptr || gw == nullptr || g == nullptr) return GANLAB_EINVAL;
   if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
   if (workspace == nullptr || workspace_bytes < ganlab_conv_wgrad_bf16_workspace(g)) return GANLAB_EWORKSPACE;
+  if (wr_enabled()) {
+    const WrPlan q = wr_plan(g);
+    BfWrArgs r;
+    r.gy = gy; r.x = x; r.ws = reinterpret_cast<float*>(workspace);
+    r.N = g->N; r.CI = g->Cin; r.CO = g->Cout; r.H = g->Hin; r.W = g->Win;
+    r.tiles_ci = r.CI / RW_T; r.npairs = r.tiles_ci * (r.CO / RW_T);
+    r.RS = q.RS; r.segs_y = q.segs_y; r.strips = q.strips; r.nseg = q.nseg; r.streams = q.streams;
+    const long long grid = (long long)r.npairs * q.flush_slots;
+    GL_LAUNCH(conv_wgrad_bf16_roll_kernel, dim3((unsigned)grid), dim3(512), 0, gl_stream(stream), r);
+    const int n4 = r.npairs * 4 * 36 * 64;
+    GL_LAUNCH(wgrad_bf16_roll_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, gl_stream(stream),
+              reinterpret_cast<const f32x4*>(r.ws), gw, r.npairs, r.tiles_ci, r.CI, q.flush_slots, scale);
+    return GL_CHECK_LAUNCH();
+  }
   BfWgArgs a;
   a.gy = gy; a.x = x; a.ws = reinterpret_cast<float*>(workspace);
   a.N = g->N; a.CI = g->Cin; a.CO = g->Cout; a.H = g->Hin; a.W = g->Win;

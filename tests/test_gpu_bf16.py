@@ -41,6 +41,7 @@ CASES = [
     (1, 64, 32, 32, 192, False, True, None),      # 3 co blocks
     (2, 64, 16, 16, 128, True, False, None),      # nearest upsample in front (materialised, then bf16 conv)
     (3, 192, 24, 96, 128, False, True, 'lrelu'),  # nothing a power of two except the tile
+    (8, 320, 16, 96, 320, False, False, None),    # 25 channel tiles: every weight-gradient pipeline walks 2 segments
 ]
 
 
