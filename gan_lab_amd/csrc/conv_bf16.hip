@@ -33,8 +33,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TH = 8, TW = 32;          // pixel tile of one workgroup
-constexpr int PR = TH + 2, PC = TW + 8; // staged patch: rows oy0-1 .. oy0+8, columns ox0-4 .. ox0+35
+constexpr int TW = 32;                  // strip width of the weight-gradient kernels
 constexpr int CK = 32;                  // input channels per K chunk (= one MFMA k-step per tap)
 constexpr int COT = 64;                 // output channels per workgroup
 
@@ -84,13 +83,19 @@ struct BfArgs {
 };
 
 // ---- forward / input-gradient kernel ---------------------------------------------------------------------------
-constexpr int X_UNITS = 4 * PR * PC;          // 16-byte units of one activation chunk (kg, row, col)
+// Pixel tile: 256 pixels = 16 MFMA column blocks, 4 per wave.  TH x TW = 8 x 32 for maps at least 32 wide, 16 x 16 for
+// the 16-pixel-wide maps (one whole 16^2 image per workgroup).
 constexpr int W_UNITS = 9 * 4 * COT;          // 16-byte units of one weight chunk (tap, kg, co)
-constexpr int X_ITEMS = 4 * PR * (PC / 4);    // staging items: (kg, row, 4-column group)
-constexpr int X_PT = (X_ITEMS + 255) / 256;   // 2
 constexpr int W_PT = W_UNITS / 256;           // 9
 
+template <int TH, int TW>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
+  constexpr int PR = TH + 2, PC = TW + 8;       // staged patch: rows oy0-1 .. oy0+TH, columns ox0-4 .. ox0+TW+3
+  constexpr int X_UNITS = 4 * PR * PC;          // 16-byte units of one activation chunk (kg, row, col)
+  constexpr int X_ITEMS = 4 * PR * (PC / 4);    // staging items: (kg, row, 4-column group)
+  constexpr int X_PT = (X_ITEMS + 255) / 256;   // 2
+  constexpr int COLB = TW / 16;                 // MFMA column blocks per tile row
+  static_assert(TH * TW == 256 && (PR * PC) % 16 == 0, "k-group planes must stay a multiple of 256 bytes apart");
   __shared__ __attribute__((aligned(16))) u32x4 Xs[X_UNITS];
   __shared__ __attribute__((aligned(16))) u32x4 Ws[W_UNITS];
 
@@ -165,10 +170,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // operand base units: B: pixel (row 2wn + nb/2, col 16(nb&1) + l16) of k-group kgl; column 3 = LP(4) - pad(1)
+  // operand base units: B: column block 4wn + nb = pixel (row (4wn + nb) / COLB, col 16 ((4wn + nb) % COLB) + l16) of
+  // k-group kgl; column 3 = LP(4) - pad(1)
   int bbase[4];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) bbase[nb] = (kgl * PR + 2 * wn + (nb >> 1)) * PC + 16 * (nb & 1) + l16 + 3;
+  for (int nb = 0; nb < 4; ++nb)
+    bbase[nb] = (kgl * PR + (4 * wn + nb) / COLB) * PC + 16 * ((4 * wn + nb) % COLB) + l16 + 3;
   const int abase = kgl * COT + l16;
 
   const int nchunks = p.CI / CK;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
       const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        const int oy = oy0 + 2 * wn + (nb >> 1), ox = ox0 + 16 * (nb & 1) + l16;
+        const int oy = oy0 + (4 * wn + nb) / COLB, ox = ox0 + 16 * ((4 * wn + nb) % COLB) + l16;
         float v = acc[mb][nb][r] + bv;
         if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
         yb[(long long)co * plane + oy * p.W + ox] = v;
@@ -680,11 +687,16 @@ __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __
   gw[i] = s * scale;
 }
 
+// forward / input gradient: 8 x 32 pixel tiles, or 16 x 16 tiles for maps whose width is a multiple of 16 only
 bool bf16_ok(const ganlab_conv_geom* g) {
   return g != nullptr && g->ks == 3 && g->pad == 1 && g->up == 0 && g->pool == 0 && g->N > 0 && g->Cin > 0 &&
-         g->Cout > 0 && g->Cin % 64 == 0 && g->Cout % 64 == 0 && g->Hin % TH == 0 && g->Win % TW == 0 &&
+         g->Cout > 0 && g->Cin % 64 == 0 && g->Cout % 64 == 0 &&
+         ((g->Hin % 8 == 0 && g->Win % 32 == 0) || (g->Hin % 16 == 0 && g->Win % 16 == 0)) &&
          (long long)g->Cin * g->Hin * g->Win * 4 < (1LL << 31) && (long long)g->Cout * g->Hin * g->Win * 4 < (1LL << 31);
 }
+
+// the weight-gradient kernels walk 32-pixel strips
+bool bf16_wgrad_ok(const ganlab_conv_geom* g) { return bf16_ok(g) && g->Hin % 8 == 0 && g->Win % 32 == 0; }
 
 int wgrad_slots(const ganlab_conv_geom* g) {
   const int groups = (g->Cout / COT) * (g->Cin / WG_CI);
@@ -719,11 +731,15 @@ static int launch_fwd(const float* x, const void* wp, const float* bias, float* 
   BfArgs a;
   a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y;
   a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
-  a.tiles_x = W / TW; a.tiles_y = H / TH; a.tiles_co = CO / COT;
+  const bool wide = W % 32 == 0 && H % 8 == 0;
+  a.tiles_x = wide ? W / 32 : W / 16; a.tiles_y = wide ? H / 8 : H / 16; a.tiles_co = CO / COT;
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
   const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  GL_LAUNCH(conv_fwd_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
+  if (wide)
+    GL_LAUNCH((conv_fwd_bf16_kernel<8, 32>), dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
+  else
+    GL_LAUNCH((conv_fwd_bf16_kernel<16, 16>), dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -741,7 +757,7 @@ int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const gan
 }
 
 size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g) {
-  if (!bf16_ok(g)) return 0;
+  if (!bf16_wgrad_ok(g)) return 0;
   const int slots = wr_enabled() ? wr_plan(g).flush_slots : wgrad_slots(g);
   return (size_t)slots * g->Cout * g->Cin * 9 * sizeof(float);
 }
@@ -749,7 +765,7 @@ size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g) {
 int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
                            void* workspace, size_t workspace_bytes, void* stream) {
   if (gy == nullptr || x == nullptr || gw == nullptr || g == nullptr) return GANLAB_EINVAL;
-  if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
+  if (!bf16_wgrad_ok(g)) return GANLAB_EUNSUPPORTED;
   if (workspace == nullptr || workspace_bytes < ganlab_conv_wgrad_bf16_workspace(g)) return GANLAB_EWORKSPACE;
   if (wr_enabled()) {
     const WrPlan q = wr_plan(g);

@@ -30,8 +30,18 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# torch.cuda.current_stream() builds a Python Stream object through several layers of device-index resolution (~10 us;
+# a quarter of the host time of a launch-bound step): ask the C binding for the raw handle of this process's device.
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_DEV_INDEX = [None]
+
+
 def _st():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _RAW_STREAM is None:
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _DEV_INDEX[0] is None:
+        _DEV_INDEX[0] = torch.cuda.current_device()     # one GPU per process: fixed after the first launch
+    return ctypes.c_void_p(_RAW_STREAM(_DEV_INDEX[0]))
 
 
 def _c(t, what='tensor'):
@@ -84,7 +94,25 @@ class Geom:
     fused kernels, csrc/conv_s2.hip).  ``s2`` tells whether the stride-2 fast path applies."""
     __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c', 'bf')
 
+    _CACHE = {}
+
+    def __new__(cls, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
+        # a training step builds the same few dozen geometries again and again; each costs two ctypes structures and
+        # two library queries, so they are interned (instances are immutable after construction)
+        key = (int(N), int(Cin), int(Hin), int(Win), int(Cout), int(ks), int(pad), int(bool(up)), int(bool(pool)),
+               _COMPUTE[0])
+        g = cls._CACHE.get(key)
+        if g is None:
+            g = object.__new__(cls)
+            g._c = None
+            if len(cls._CACHE) > 4096:
+                cls._CACHE.clear()
+            cls._CACHE[key] = g
+        return g
+
     def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
+        if self._c is not None:
+            return
         if ks not in (1, 3):
             raise ValueError('conv kernels support ks in {1, 3}; a 4x4 valid conv runs as a linear')
         self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool = \
@@ -412,6 +440,14 @@ def k_conv_wgrad(gy, x, g, scale):
     if g.bf is not None:
         xin = k_up2(x, 1.0) if g.up else x
         nbytes = L.ganlab_conv_wgrad_bf16_workspace(ctypes.byref(g.bf))
+        if nbytes == 0:
+            # 16-pixel-wide maps: bf16 forward / input gradient, but the bf16 weight-gradient kernels walk 32-pixel
+            # strips - the (exact) fp32 kernel takes the materialised input
+            nbytes = L.ganlab_conv_wgrad_workspace(ctypes.byref(g.bf))
+            ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+            check(L.ganlab_conv_wgrad_f32(_p(gy), _p(xin), _p(gw), ctypes.byref(g.bf), scale, _p(ws), ws.numel() * 4,
+                                          _st()), 'conv_wgrad')
+            return gw
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
         check(L.ganlab_conv_wgrad_bf16(_p(gy), _p(xin), _p(gw), ctypes.byref(g.bf), scale, _p(ws), ws.numel() * 4,
                                        _st()), 'conv_wgrad_bf16')

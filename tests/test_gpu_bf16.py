@@ -42,6 +42,8 @@ CASES = [
     (2, 64, 16, 16, 128, True, False, None),      # nearest upsample in front (materialised, then bf16 conv)
     (3, 192, 24, 96, 128, False, True, 'lrelu'),  # nothing a power of two except the tile
     (8, 320, 16, 96, 320, False, False, None),    # 25 channel tiles: every weight-gradient pipeline walks 2 segments
+    (3, 128, 16, 16, 64, False, True, 'lrelu'),   # 16-wide maps: 16 x 16 pixel tiles; the weight gradient stays fp32
+    (2, 64, 32, 48, 128, False, False, None),     # width a multiple of 16 only
 ]
 
 
@@ -85,8 +87,12 @@ def test_bf16_conv_fwd_dgrad_wgrad(ops, case):
     gxi = F.conv_transpose2d(bf(gz32), bf(wt * scale), None, padding=1)
     gx_ref = F.avg_pool2d(gxi, 2) * 4 if up else gxi
     assert_close(xg.grad.cpu(), gx_ref, 5e-5, 'bf16 dgrad vs bf16-operand float64')
-    gw_ref = torch.nn.grad.conv2d_weight(bf(xi), wt.shape, bf(gz32), padding=1) * scale
-    assert_close(wg.grad.cpu(), gw_ref, 5e-5, 'bf16 wgrad vs bf16-operand float64')
+    if xi.shape[-1] % 32 == 0:
+        gw_ref = torch.nn.grad.conv2d_weight(bf(xi), wt.shape, bf(gz32), padding=1) * scale
+        assert_close(wg.grad.cpu(), gw_ref, 5e-5, 'bf16 wgrad vs bf16-operand float64')
+    else:       # the bf16 weight-gradient kernels walk 32-pixel strips: narrower maps take the exact fp32 kernel
+        gw_ref = torch.nn.grad.conv2d_weight(xi.double(), wt.shape, gz, padding=1) * scale
+        assert_close(wg.grad.cpu(), gw_ref, 2e-5, 'fp32 wgrad of a 16-wide bf16 layer vs float64')
     if has_b:
         assert_close(bg.grad.cpu(), gz.sum(dim=(0, 2, 3)), 2e-4, 'bias grad')
     # precision vs the fp32 arithmetic on unrounded operands (same LeakyReLU mask: a bf16-sized forward error flips the

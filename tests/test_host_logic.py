@@ -249,7 +249,10 @@ def test_bf16_compute_mode_host_side():
     def ok(n, cin, h, w, cout, ks=3, pad=1, up=0, pool=0):
         return L.ganlab_conv_bf16_supported(ctypes.byref(_lib.ConvGeom(n, cin, h, w, cout, ks, pad, up, pool)))
     assert ok(8, 128, 128, 128, 128) == 1 and ok(8, 512, 32, 32, 512) == 1 and ok(8, 256, 64, 64, 128) == 1
-    assert ok(8, 128, 16, 16, 128) == 0          # W < 32: stays on the exact fp32 kernels
+    assert ok(8, 128, 16, 16, 128) == 1          # 16-wide maps: 16 x 16 pixel tiles (forward / input gradient) ...
+    wsz = L.ganlab_conv_wgrad_bf16_workspace
+    assert wsz(ctypes.byref(_lib.ConvGeom(8, 128, 16, 16, 128, 3, 1, 0, 0))) == 0   # ... but an fp32 weight gradient
+    assert ok(8, 128, 8, 8, 128) == 0 and ok(8, 128, 24, 16, 128) == 0              # H % 16 for the 16-wide tiles
     assert ok(8, 16, 1024, 1024, 16) == 0        # thin layers
     assert ok(8, 96, 32, 32, 128) == 0           # Cin not a multiple of 64
     assert ok(8, 128, 32, 32, 128, ks=1, pad=0) == 0 and ok(8, 128, 32, 32, 128, up=1) == 0
