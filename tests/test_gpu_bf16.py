@@ -113,6 +113,36 @@ def test_bf16_mode_leaves_unsupported_shapes_exact(ops):
     assert_close(y.cpu(), F.conv2d(x.double() * 0.1, wt.double(), padding=1), 2e-5, 'fp32 kernel in bf16 mode')
 
 
+FULL = [(8, 128, 128, 128, 128), (8, 256, 64, 64, 512), (8, 512, 32, 32, 512), (8, 512, 16, 16, 512)]
+
+
+@pytest.mark.parametrize('shape', FULL, ids=[str(c) for c in FULL])
+def test_bf16_full_size_triple_product(ops, shape):
+    """BASELINE config #2's own layer sizes (batch 8), where a float64 reference is out of reach: with operands that ARE
+    bf16 numbers every product inside the three kernels is exact, so <conv(x, w), gy> = <x, dgrad(gy, w)> =
+    <w, wgrad(gy, x)> - one triple sum, accumulated in fp32 in three different orders by three different kernels
+    (forward tile kernel, its input-gradient twin, the rolling-row weight gradient or - at 16 pixels - the fp32 one)."""
+    n, cin, h, w, cout = shape
+    gen = torch.Generator().manual_seed(n * cin + h)
+    bfr = lambda t: t.to(torch.bfloat16).float().cuda()
+    x, wt = bfr(torch.randn(n, cin, h, w, generator=gen)), bfr(torch.randn(cout, cin, 3, 3, generator=gen))
+    gy = bfr(torch.randn(n, cout, h, w, generator=gen))
+    with ops.compute_dtype('bf16'):
+        g = ops.Geom(n, cin, h, w, cout, 3, 1)
+    assert g.bf is not None
+    y = ops.k_conv_fwd(x, wt, None, g, 1.0)
+    gx = ops.k_conv_dgrad(gy, wt, g, 1.0)
+    gw = ops.k_conv_wgrad(gy, x, g, 1.0)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    t_y, t_x, t_w = dot(y, gy), dot(x, gx), dot(wt, gw)
+    scale = (float(y.double().pow(2).sum()) * float(gy.double().pow(2).sum())) ** 0.5     # |y| |gy|: the sum's natural size
+    assert abs(t_y - t_x) <= 1e-5 * scale and abs(t_y - t_w) <= 1e-5 * scale, (t_y, t_x, t_w, scale)
+    # and the weight gradient is not merely consistent in the mean: a random projection onto a second bf16 weight
+    w2 = bfr(torch.randn(cout, cin, 3, 3, generator=gen))
+    y2 = ops.k_conv_fwd(x, w2, None, g, 1.0)
+    assert abs(dot(y2, gy) - dot(w2, gw)) <= 1e-5 * scale
+
+
 def test_bf16_double_backward_closed(ops):
     """R1-style double backward through bf16 layers: d/dw of |d y/d x|^2 exists and is close to fp32 autograd."""
     gen = torch.Generator().manual_seed(11)
