@@ -2114,6 +2114,18 @@ def pixelnorm(x, eps=1e-8):
     return _PixelNorm.apply(x, float(eps))
 
 
+def style_mod(x, style):
+    """AdaIN's affine WITHOUT the normalisation (``use_instancenorm=False``, stylegan/architectures.py:497-526 with the
+    norm list empty): ``x * (ys + 1) + yb`` with ``style`` = (N, 2C) = [ys | yb].  A per-(sample, channel) affine is the
+    per-channel affine kernel on the (1, N*C, H, W) view; its backward is made of differentiable ops, so R1-style
+    double backward is closed."""
+    n, c = int(x.shape[0]), int(x.shape[1])
+    st = style.reshape(n, 2, c)
+    ys1 = (st[:, 0] + 1.0).reshape(-1).contiguous()
+    yb = st[:, 1].reshape(-1).contiguous()
+    return chan_affine(x.reshape(1, n * c, *x.shape[2:]), ys1, yb).reshape(x.shape)
+
+
 def mbstd_stat(x, group_size, eps=1e-8):
     return _MbstdStat.apply(x, int(group_size), float(eps))
 

@@ -239,8 +239,6 @@ class StyleGenerator(StyleGAN):
         mods = list(layer[2])
         bias = mods.pop(0) if mods and isinstance(mods[0], Conv2dBias) else None
         act = mods.pop(0) if mods and isinstance(mods[0], LeakyReLU) else None
-        if not self.use_instancenorm:
-            raise NotImplementedError('use_instancenorm=False (AdaIN without normalisation) has no fused kernel')
         bias_t = bias.bias if bias is not None else None
         bias_scale = (bias.lrmul if bias.use_lrmul else 1.0) if bias is not None else 1.0
         name = 'lrelu' if act is not None else None
@@ -252,7 +250,8 @@ class StyleGenerator(StyleGAN):
             blur = bool(head) and isinstance(head[-1], Blur2d)
             conv = head[0] if (len(head) == 1 and isinstance(head[0], Conv2dEx)) else None
             if isinstance(out, ops.Deferred) and conv is not None and conv.conv2d.bias is None and bias is not None \
-                    and not self.use_pixelnorm and ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):
+                    and self.use_instancenorm and not self.use_pixelnorm \
+                    and ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):
                 # plain 3x3 layer, deferred in -> deferred out in ONE pass over the activations (conv with per-sample
                 # weights, noise + bias + LeakyReLU + InstanceNorm statistics in its epilogue)
                 nz = layer[1].draw(out.a[:, :1], noise[n] if noise is not None else None) if self.use_noise else None
@@ -266,7 +265,7 @@ class StyleGenerator(StyleGAN):
             out = ops.materialize(out)
         nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
         nw = layer[1].noise_weight if nz is not None else None
-        if not self.use_pixelnorm:
+        if self.use_instancenorm and not self.use_pixelnorm:
             if defer_out and ops.deferrable(out):
                 # blur + noise + bias + LeakyReLU + statistics in one pass; the normalisation is left to the consumer
                 return ops.layer_tail_deferred(out, bias_t, nz, nw, y, bias_scale=bias_scale, act=name, slope=slope,
@@ -274,8 +273,11 @@ class StyleGenerator(StyleGAN):
             # blur + noise + bias + LeakyReLU (+ the InstanceNorm statistics) in one pass, IN + (ys+1, yb) in a second
             return ops.layer_tail(out, bias_t, nz, nw, y, bias_scale=bias_scale, act=name, slope=slope, blur=blur,
                                   eps=IN_EPS)
-        out = ops.pixelnorm(ops.bias_act(out, bias_t, nz, nw, bias_scale=bias_scale, act=name, slope=slope, blur=blur))
-        return ops.instnorm_style(out, y, IN_EPS)
+        out = ops.bias_act(out, bias_t, nz, nw, bias_scale=bias_scale, act=name, slope=slope, blur=blur)
+        if self.use_pixelnorm:
+            out = ops.pixelnorm(out)
+        # use_instancenorm=False: the style is applied to the un-normalised activations
+        return ops.instnorm_style(out, y, IN_EPS) if self.use_instancenorm else ops.style_mod(out, y)
 
     def _consumer_is_modulated(self, n, L):
         """Can the consumer of layer n's output take a deferred tensor?  The next layer when it is a plain 3x3 conv (no

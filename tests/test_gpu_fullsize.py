@@ -41,15 +41,15 @@ def _full_widths():
     ops.set_compute_dtype('f32')
 
 
-def _build(kind, res, seed=11):
+def _build(kind, res, seed=11, **gen_kwargs):
     from gan_lab_amd import progressive as P
     from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator, StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
     torch.manual_seed(seed)
     if kind == 'stylegan':
         P.StyleGAN.reset_state()
-        g, d = StyleGenerator(final_res=res, blur_type='binomial'), StyleDiscriminator(final_res=res,
-                                                                                       blur_type='binomial')
+        g, d = StyleGenerator(final_res=res, blur_type='binomial', **gen_kwargs), StyleDiscriminator(final_res=res,
+                                                                                                     blur_type='binomial')
     else:
         P.ProGAN.reset_state()
         g, d = ProGenerator(final_res=res, blur_type='binomial'), ProDiscriminator(final_res=res,
@@ -103,9 +103,9 @@ def _hip_step(kind, g, d, z, real, noise, loss, gp, eps_interp, dtype):
                 gg={k: p.grad.detach().cpu() for k, p in g.named_parameters() if p.grad is not None})
 
 
-def _oracle_step(kind, sd_g, sd_d, z, real, noise, loss, gp, eps_interp, dt=torch.float32, want=('d', 'g')):
+def _oracle_step(kind, sd_g, sd_d, z, real, noise, loss, gp, eps_interp, dt=torch.float32, want=('d', 'g'), **cfg_kwargs):
     from oracle import nets, ops as O, step
-    cfg = nets.make_cfg(use_pixelnorm=(kind == 'progan'))
+    cfg = nets.make_cfg(use_pixelnorm=(kind == 'progan'), **cfg_kwargs)
     og = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd_g.items()}
     od = {k: v.to(dt).clone().requires_grad_(True) for k, v in sd_d.items()}
     z, real = z.to(dt), real.to(dt)

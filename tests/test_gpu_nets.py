@@ -185,6 +185,51 @@ def test_stylegan_step_gradients_vs_oracle(res, fmap_base, fmap_max, b, min_entr
     assert len(ed) + len(eg) > min_entries
 
 
+def test_stylegan_without_instancenorm_vs_oracle(capsys):
+    """``use_instancenorm=False`` (stylegan/architectures.py:138, :230-232, :324-325: AdaIN's affine on the un-normalised
+    activations): image, D outputs, R1, losses and every parameter gradient of a D step and a G step against the oracle,
+    64^2 at the real channel widths (512 ... 256), batch 4.  Without the normalisation the activations grow layer by layer, so this
+    is also the composition in which the style affine's own gradients (sum g*x, sum g per sample and channel) carry
+    weight."""
+    import test_gpu_fullsize as FS
+    from gan_lab_amd import progressive as P
+    from util import rel_err
+    P.FMAP_BASE, P.FMAP_MAX = 8192, 512
+    g, d, sd_g, sd_d = FS._build('stylegan', 64, use_instancenorm=False)
+    assert not g.use_instancenorm
+    gen = torch.Generator().manual_seed(5)
+    b = 4
+    z, real = torch.randn(b, 512, generator=gen), torch.rand(b, 3, 64, 64, generator=gen) * 2 - 1
+    noise = [torch.randn(b, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2), generator=gen) for n in range(len(g.gen_layers))]
+    hip = FS._hip_step('stylegan', g, d, z, real, noise, 'nonsaturating', 'r1', None, 'f32')
+    cpu = FS._oracle_step('stylegan', sd_g, sd_d, z, real, noise, 'nonsaturating', 'r1', None, use_instancenorm=False)
+    rep = {k: rel_err(hip[k], cpu[k]) for k in ('img', 'd_real', 'd_fake', 'gp', 'loss_d', 'loss_g')}
+    ed, _ = FS._grad_errors(hip['gd'], cpu['gd'])
+    eg, _ = FS._grad_errors(hip['gg'], cpu['gg'])
+    rep['worst_d'], rep['worst_g'] = max(ed.items(), key=lambda kv: kv[1]), max(eg.items(), key=lambda kv: kv[1])
+    # entries beyond 1e-3 are judged like in test_stylegan_step_gradients_vs_oracle: against float64, where the HIP value
+    # must be as close to the exact one as the CPU fp32 path (LeakyReLU tie channels recognised and reported)
+    bad_d, bad_g = [k for k, v in ed.items() if v > TOL], [k for k, v in eg.items() if v > TOL]
+    still = {}
+    if bad_d or bad_g:
+        want = (('d',) if bad_d else ()) + (('g',) if bad_g else ())
+        ex = FS._oracle_step('stylegan', sd_g, sd_d, z, real, noise, 'nonsaturating', 'r1', None, dt=torch.float64,
+                             want=want, use_instancenorm=False)
+        for tag, bad, key in (('d.', bad_d, 'gd'), ('g.', bad_g, 'gg')):
+            if bad:
+                s_, j, ties = FS._judge_outliers(tag, bad, hip[key], cpu[key], ex[key],
+                                                 max(v.abs().max().item() for v in ex[key].values()))
+                still.update(s_)
+                rep['judged_' + tag] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
+                rep.setdefault('lrelu_tie_channels', {}).update(ties)
+    with capsys.disabled():
+        print('\nstylegan-64 without InstanceNorm, HIP vs oracle:', rep)
+    for k in ('img', 'd_real', 'd_fake', 'gp', 'loss_d', 'loss_g'):
+        assert rep[k] <= TOL, (k, rep)
+    assert not still, still
+    assert len(eg) > 40
+
+
 def test_thin16_network_is_as_accurate_as_the_cpu_path(capsys, monkeypatch):
     """The 1024^2 layers' width (16 channels) on 256^2 planes, batch 2: fromRGB -> rolling-window convs -> thin stride-2
     kernels in D, and in G the deferred-InstanceNorm chain of csrc/mod.hip (blurred layer -> modulated 3x3 layer with the
