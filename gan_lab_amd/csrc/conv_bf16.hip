@@ -77,8 +77,8 @@ struct BfArgs {
   const float* bias;
   float* y;
   int N, CI, CO, H, W;
-  int tiles_x, tiles_y, tiles_co;
-  float bias_scale, slope;
+  int tiles_x, tiles_y, tiles_co;   // H, W: the resolution the 3x3 taps run at (2x the input's with UP, 2x the output's with POOL)
+  float bias_scale, slope, oscale;  // y = act(oscale * (pooled) conv + bias * bias_scale)
   int act;
 };
 
@@ -88,7 +88,12 @@ struct BfArgs {
 constexpr int W_UNITS = 9 * 4 * COT;          // 16-byte units of one weight chunk (tap, kg, co)
 constexpr int W_PT = W_UNITS / 256;           // 9
 
-template <int TH, int TW>
+// UP: the input is the nearest 2x upsample of x (H/2 x W/2 in memory) - the staging reads each source pixel pair once and
+// writes it to two columns, so the upsampled tensor is never materialised.  POOL: the epilogue adds the 2 x 2 output
+// pixels (rows: two accumulator tiles of the same wave; columns: the neighbouring lane) and stores H/2 x W/2.  The four
+// stride-2 passes are these two: conv(up2 x) and the input gradient of pool2(conv x) take UP (oscale 1 / 0.25),
+// pool2(conv x) and the input gradient of conv(up2 x) take POOL (oscale 0.25 / 1).
+template <int TH, int TW, bool UP = false, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
   constexpr int PR = TH + 2, PC = TW + 8;       // staged patch: rows oy0-1 .. oy0+TH, columns ox0-4 .. ox0+TW+3
   constexpr int X_UNITS = 4 * PR * PC;          // 16-byte units of one activation chunk (kg, row, col)
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
   const int tyi = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
   const int co0 = co_t * COT, oy0 = tyi * TH, ox0 = txi * TW;
-  const int plane = p.H * p.W;
+  const int iW = UP ? p.W >> 1 : p.W;
+  const int plane = UP ? (p.H >> 1) * iW : p.H * p.W;        // input plane (elements)
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x + (long long)n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
@@ -124,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
     const int r = t % PR, kg = t / PR;
     const int vy = oy0 - 1 + r, vx = ox0 - 4 + 4 * q;
     const bool ok = e < X_ITEMS && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
-    goff[i] = ok ? ((kg * 8) * plane + vy * p.W + vx) * 4 : (int)0x80000000;
+    goff[i] = !ok ? (int)0x80000000
+                  : UP ? ((kg * 8) * plane + (vy >> 1) * iW + (vx >> 1)) * 4 : ((kg * 8) * plane + vy * p.W + vx) * 4;
     lunit[i] = e < X_ITEMS ? (kg * PR + r) * PC + 4 * q : -1;
   }
   const int cstride = plane * 4;   // bytes between channels
@@ -140,8 +147,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
         // an out-of-range base stays out of range after adding j*cstride < 2^31 only if it cannot wrap: keep the
         // marker by selecting per load
         const int off = goff[i] == (int)0x80000000 ? (int)0x80000000 : goff[i] + j * cstride;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, soff, 0);
-        xr[i][j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        if constexpr (UP) {   // columns vx .. vx+3 of the upsampled row = source pixels vx/2, vx/2 + 1, each twice
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, off, soff, 0);
+          xr[i][j] = float4{__uint_as_float(v.x), __uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.y)};
+        } else {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, soff, 0);
+          xr[i][j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
       }
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wp) + (long long)c * 9 * 4 * p.CO;
 #pragma unroll
@@ -202,21 +214,47 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
   }
 
   // epilogue: lane holds channels co0 + 16mb + 4kgl + r of pixel (row, col); 16 lanes -> 64 contiguous bytes
-  float* yb = p.y + (long long)n * p.CO * plane;
+  if constexpr (!POOL) {
+    const int oplane = p.H * p.W;
+    float* yb = p.y + (long long)n * p.CO * oplane;
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + mb * 16 + kgl * 4 + r;
-      const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mb * 16 + kgl * 4 + r;
+        const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const int oy = oy0 + (4 * wn + nb) / COLB, ox = ox0 + 16 * ((4 * wn + nb) % COLB) + l16;
-        float v = acc[mb][nb][r] + bv;
-        if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
-        yb[(long long)co * plane + oy * p.W + ox] = v;
+        for (int nb = 0; nb < 4; ++nb) {
+          const int oy = oy0 + (4 * wn + nb) / COLB, ox = ox0 + 16 * ((4 * wn + nb) % COLB) + l16;
+          float v = acc[mb][nb][r] * p.oscale + bv;
+          if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+          yb[(long long)co * oplane + oy * p.W + ox] = v;
+        }
       }
-    }
+  } else {
+    // the wave's four column blocks are two tile rows x COLB... : blocks (b, b + COLB) of the same column range are
+    // vertical neighbours when COLB == 2 (rows 2wn, 2wn+1), blocks (2k, 2k+1) when COLB == 1 (rows 4wn+2k, 4wn+2k+1)
+    const int oW = p.W >> 1, oplane = (p.H >> 1) * oW;
+    float* yb = p.y + (long long)n * p.CO * oplane;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mb * 16 + kgl * 4 + r;
+        const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int b0 = COLB == 2 ? k : 2 * k, b1 = COLB == 2 ? k + 2 : 2 * k + 1;
+          float sum = acc[mb][b0][r] + acc[mb][b1][r];
+          sum += __shfl_xor(sum, 1, 64);                       // the horizontal neighbour (l16 ^ 1)
+          const int oy = (oy0 + (4 * wn + b0) / COLB) >> 1;
+          const int ox = (ox0 + 16 * ((4 * wn + b0) % COLB) + l16) >> 1;
+          float v = sum * p.oscale + bv;
+          if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
+          if ((l16 & 1) == 0) yb[(long long)co * oplane + oy * oW + ox] = v;
+        }
+      }
+  }
 }
 
 // ---- weight-gradient kernel --------------------------------------------------------------------------------------
@@ -687,16 +725,21 @@ __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __
   gw[i] = s * scale;
 }
 
-// forward / input gradient: 8 x 32 pixel tiles, or 16 x 16 tiles for maps whose width is a multiple of 16 only
+// forward / input gradient: 8 x 32 pixel tiles, or 16 x 16 tiles for maps whose width is a multiple of 16 only; the
+// nearest upsample in front (up) or the 2 x 2 average pool behind (pool) fold into the kernel (not both)
 bool bf16_ok(const ganlab_conv_geom* g) {
-  return g != nullptr && g->ks == 3 && g->pad == 1 && g->up == 0 && g->pool == 0 && g->N > 0 && g->Cin > 0 &&
-         g->Cout > 0 && g->Cin % 64 == 0 && g->Cout % 64 == 0 &&
-         ((g->Hin % 8 == 0 && g->Win % 32 == 0) || (g->Hin % 16 == 0 && g->Win % 16 == 0)) &&
-         (long long)g->Cin * g->Hin * g->Win * 4 < (1LL << 31) && (long long)g->Cout * g->Hin * g->Win * 4 < (1LL << 31);
+  if (g == nullptr || g->ks != 3 || g->pad != 1 || (g->up && g->pool) || g->N <= 0 || g->Cin <= 0 || g->Cout <= 0 ||
+      g->Cin % 64 != 0 || g->Cout % 64 != 0 || g->Hin <= 0 || g->Win <= 0)
+    return false;
+  const long long H = (long long)g->Hin * (g->up ? 2 : 1), W = (long long)g->Win * (g->up ? 2 : 1);   // where the taps run
+  if (!((H % 8 == 0 && W % 32 == 0) || (H % 16 == 0 && W % 16 == 0))) return false;
+  return (long long)g->Cin * H * W * 4 < (1LL << 31) && (long long)g->Cout * H * W * 4 < (1LL << 31);
 }
 
 // the weight-gradient kernels walk 32-pixel strips
-bool bf16_wgrad_ok(const ganlab_conv_geom* g) { return bf16_ok(g) && g->Hin % 8 == 0 && g->Win % 32 == 0; }
+bool bf16_wgrad_ok(const ganlab_conv_geom* g) {
+  return bf16_ok(g) && !g->up && !g->pool && g->Hin % 8 == 0 && g->Win % 32 == 0;
+}
 
 int wgrad_slots(const ganlab_conv_geom* g) {
   const int groups = (g->Cout / COT) * (g->Cin / WG_CI);
@@ -726,20 +769,28 @@ long long ganlab_conv_pack_bf16(const float* w, void* out, int Cout, int Cin, in
   return st != GANLAB_OK ? st : n;
 }
 
+// mode 0: plain; 1: UP (x is H/2 x W/2); 2: POOL (y is H/2 x W/2).  H, W: the resolution of the 3x3 taps.
 static int launch_fwd(const float* x, const void* wp, const float* bias, float* y, int N, int CI, int CO, int H, int W,
-                      float bias_scale, int act, float slope, void* stream) {
+                      float bias_scale, int act, float slope, int mode, float oscale, void* stream) {
   BfArgs a;
   a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y;
   a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
   const bool wide = W % 32 == 0 && H % 8 == 0;
   a.tiles_x = wide ? W / 32 : W / 16; a.tiles_y = wide ? H / 8 : H / 16; a.tiles_co = CO / COT;
-  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act; a.oscale = oscale;
   const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  if (wide)
-    GL_LAUNCH((conv_fwd_bf16_kernel<8, 32>), dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
-  else
-    GL_LAUNCH((conv_fwd_bf16_kernel<16, 16>), dim3((unsigned)grid), dim3(256), 0, gl_stream(stream), a);
+  const dim3 gd((unsigned)grid), bd(256);
+  hipStream_t st = gl_stream(stream);
+  if (wide) {
+    if (mode == 1) GL_LAUNCH((conv_fwd_bf16_kernel<8, 32, true, false>), gd, bd, 0, st, a);
+    else if (mode == 2) GL_LAUNCH((conv_fwd_bf16_kernel<8, 32, false, true>), gd, bd, 0, st, a);
+    else GL_LAUNCH((conv_fwd_bf16_kernel<8, 32>), gd, bd, 0, st, a);
+  } else {
+    if (mode == 1) GL_LAUNCH((conv_fwd_bf16_kernel<16, 16, true, false>), gd, bd, 0, st, a);
+    else if (mode == 2) GL_LAUNCH((conv_fwd_bf16_kernel<16, 16, false, true>), gd, bd, 0, st, a);
+    else GL_LAUNCH((conv_fwd_bf16_kernel<16, 16>), gd, bd, 0, st, a);
+  }
   return GL_CHECK_LAUNCH();
 }
 
@@ -747,13 +798,18 @@ int ganlab_conv_fwd_bf16(const float* x, const void* wp, const float* bias, floa
                          float bias_scale, int act, float slope, void* stream) {
   if (x == nullptr || wp == nullptr || y == nullptr || g == nullptr) return GANLAB_EINVAL;
   if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
-  return launch_fwd(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope, stream);
+  const int m = g->up ? 2 : 1;        // conv(up2 x): UP; pool2(conv x): POOL with the 1/4 of the average
+  return launch_fwd(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin * m, g->Win * m, bias_scale, act, slope,
+                    g->up ? 1 : (g->pool ? 2 : 0), g->pool ? 0.25f : 1.f, stream);
 }
 
 int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream) {
   if (gy == nullptr || wp == nullptr || gx == nullptr || g == nullptr) return GANLAB_EINVAL;
   if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
-  return launch_fwd(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin, g->Win, 0.f, GANLAB_ACT_NONE, 0.f, stream);
+  // adjoints: of the nearest upsample the 2 x 2 sum (POOL, factor 1), of the average pool the upsample / 4 (UP)
+  const int m = g->up ? 2 : 1;
+  return launch_fwd(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin * m, g->Win * m, 0.f, GANLAB_ACT_NONE, 0.f,
+                    g->up ? 2 : (g->pool ? 1 : 0), g->pool ? 0.25f : 1.f, stream);
 }
 
 size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g) {

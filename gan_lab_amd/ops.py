@@ -92,7 +92,7 @@ class Geom:
     """Static description of one convolution (mirrors ganlab_conv_geom) + derived output size.
     ``up``: nearest 2x upsample folded in front; ``pool``: 2x2 average pool folded behind (stride-2
     fused kernels, csrc/conv_s2.hip).  ``s2`` tells whether the stride-2 fast path applies."""
-    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c', 'bf')
+    __slots__ = ('N', 'Cin', 'Hin', 'Win', 'Cout', 'ks', 'pad', 'up', 'pool', 'Ho', 'Wo', 's2', '_c', 'bf', 'bf_fused')
 
     _CACHE = {}
 
@@ -123,15 +123,21 @@ class Geom:
             self.Ho, self.Wo = self.Ho // 2, self.Wo // 2
         self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool)
         # bf16 compute mode (decided HERE, so a backward that runs outside the `compute_dtype` block still uses the
-        # kernels its forward used): the bf16 kernels take the materialised (upsampled) input, no pool fusion
-        self.bf = None
-        if _COMPUTE[0] == 'bf16' and not self.pool:
+        # kernels its forward used).  ``bf``: the plain geometry at the resolution of the taps (what the weight-gradient
+        # kernels take, on a materialised upsample of x or of the pooled layer's gy); ``bf_fused``: this geometry with
+        # its up / pool flag - the forward and input-gradient kernels fold the resampling in
+        self.bf = self.bf_fused = None
+        if _COMPUTE[0] == 'bf16':
             v = ConvGeom(self.N, self.Cin, hv, wv, self.Cout, self.ks, self.pad, 0, 0)
             if _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(v)):
                 self.bf = v
+                if (self.up or self.pool) and _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(self._c)):
+                    self.bf_fused = self._c
+                elif self.pool:
+                    self.bf = None
         self.s2 = bool(self.bf is None and (self.up or self.pool) and
                        _lib.lib().ganlab_conv_s2_supported(ctypes.byref(self._c)))
-        if self.pool and not self.s2:
+        if self.pool and not self.s2 and self.bf_fused is None:
             raise ValueError('pool=1 geometry is not supported by the stride-2 kernels; compose conv + pool')
 
     def ref(self):
@@ -151,9 +157,9 @@ def pool_fusable(N, Cin, Hin, Win, Cout, ks, pad):
     if ks != 3 or pad != 1:
         return False
     if _COMPUTE[0] == 'bf16':
-        v = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 0)
+        v = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 1)
         if _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(v)):
-            return False        # bf16 conv, then the pool as its own (HBM-bound) pass
+            return True         # the bf16 kernel sums the 2 x 2 outputs in its epilogue
     c = ConvGeom(int(N), int(Cin), int(Hin), int(Win), int(Cout), 3, 1, 0, 1)
     return bool(_lib.lib().ganlab_conv_s2_supported(ctypes.byref(c)))
 
@@ -291,6 +297,8 @@ def conv_flops(g):
     if g.s2:
         lo_h, lo_w = (g.Hin, g.Win) if g.up else (g.Ho, g.Wo)
         return 2.0 * 16 * g.Cin * g.Cout * lo_h * lo_w * g.N
+    if g.bf is not None:       # bf16 layers run all 9 taps at the taps' resolution, also with a folded upsample / pool
+        return 2.0 * g.ks * g.ks * g.Cin * g.Cout * g.bf.Hin * g.bf.Win * g.N
     return 2.0 * g.ks * g.ks * g.Cin * g.Cout * g.Ho * g.Wo * g.N
 
 
@@ -311,10 +319,11 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         bias = _c(bias, 'bias')
         assert bias.numel() == g.Cout
     y = _new(g.out_shape, x)
-    if g.bf is not None:   # bf16-compute layer (the nearest upsample, if any, is materialised first)
-        xin = k_up2(x, 1.0) if g.up else x
+    if g.bf is not None:   # bf16-compute layer; a nearest upsample in front / average pool behind folds into the kernel
+        geom = g.bf_fused if g.bf_fused is not None else g.bf
+        xin = k_up2(x, 1.0) if (g.up and g.bf_fused is None) else x
         wp = _packed_bf16(w, PACK_FWD, scale)
-        check(_lib.lib().ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(g.bf), bias_scale,
+        check(_lib.lib().ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(geom), bias_scale,
                                               act, slope, _st()), 'conv_fwd_bf16')
         return y
     if g.s2:   # stride-2 fused layer: conv+avgpool (S kernel) or upsample+conv (T kernel)
@@ -354,6 +363,11 @@ def k_conv_dgrad(gy, w, g, scale):
     _note('dgrad', g)
     if g.bf is not None:
         wp = _packed_bf16(w, PACK_DGRAD, scale)
+        if g.bf_fused is not None:     # the adjoint of the upsample (2 x 2 sum) / of the pool (upsample / 4) is in the kernel
+            gx = _new(g.in_shape, gy)
+            check(_lib.lib().ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(gx), ctypes.byref(g.bf_fused), _st()),
+                  'conv_dgrad_bf16')
+            return gx
         gxv = _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy)
         check(_lib.lib().ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(gxv), ctypes.byref(g.bf), _st()),
               'conv_dgrad_bf16')
@@ -438,7 +452,11 @@ def k_conv_wgrad(gy, x, g, scale):
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     if g.bf is not None:
+        # the weight gradient contracts over the pixels the taps run on: it takes the materialised upsample of x (up) or of
+        # the pooled layer's output gradient (pool: up2(gy) / 4, the adjoint of the average)
         xin = k_up2(x, 1.0) if g.up else x
+        if g.pool:
+            gy = k_up2(gy, 0.25)
         nbytes = L.ganlab_conv_wgrad_bf16_workspace(ctypes.byref(g.bf))
         if nbytes == 0:
             # 16-pixel-wide maps: bf16 forward / input gradient, but the bf16 weight-gradient kernels walk 32-pixel

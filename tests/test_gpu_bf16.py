@@ -113,6 +113,49 @@ def test_bf16_mode_leaves_unsupported_shapes_exact(ops):
     assert_close(y.cpu(), F.conv2d(x.double() * 0.1, wt.double(), padding=1), 2e-5, 'fp32 kernel in bf16 mode')
 
 
+POOL_CASES = [(2, 64, 16, 64, 128, True, 'lrelu'), (3, 128, 32, 32, 64, False, None), (2, 64, 32, 16, 64, True, 'lrelu')]
+
+
+@pytest.mark.parametrize('case', POOL_CASES, ids=[str(c) for c in POOL_CASES])
+def test_bf16_pooled_conv_fwd_dgrad_wgrad(ops, case):
+    """conv -> AvgPool2d(2) -> +bias -> LeakyReLU as ONE bf16 kernel (the 2 x 2 sum in the epilogue), its input gradient
+    (the upsample / 4 folded into the staging) and its weight gradient (on the materialised up2(gy) / 4): exact against
+    float64 on bf16-rounded operands - the pooled gradient up2(gz)/4 is itself rounded to bf16 by the kernels, as the
+    reference composition would round it."""
+    n, cin, h, w, cout, has_b, act = case
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen)
+    b = torch.randn(cout, generator=gen) if has_b else None
+    scale = 1.0 / (cin * 9) ** 0.5
+    xg, wg = x.clone().cuda().requires_grad_(True), wt.clone().cuda().requires_grad_(True)
+    bg = b.clone().cuda().requires_grad_(True) if has_b else None
+    with ops.compute_dtype('bf16'):
+        assert ops.pool_fusable(n, cin, h, w, cout, 3, 1)
+        y = ops.conv2d(xg, wg, bg, scale=scale, padding=1, act=act, slope=0.2, pool=True)
+    assert tuple(y.shape) == (n, cout, h // 2, w // 2)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy.cuda())
+    pre = F.avg_pool2d(F.conv2d(bf(x), bf(wt * scale), None, padding=1), 2)
+    if has_b:
+        pre = pre + b.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(pre, 0.2) if act == 'lrelu' else pre
+    assert_close(y.detach().cpu(), ref, TOL_EXACT, 'bf16 pooled conv vs bf16-operand float64')
+    mask = torch.where(y.detach().cpu() > 0, 1.0, 0.2).float() if act == 'lrelu' else torch.ones_like(gy)
+    gz = gy * mask                                                    # fp32, as the pointwise kernel computes it
+    gzu = F.interpolate(gz, scale_factor=2, mode='nearest') * 0.25    # adjoint of the average pool (exact in fp32)
+    gx_ref = F.conv_transpose2d(bf(gzu), bf(wt * scale), None, padding=1)
+    assert_close(xg.grad.cpu(), gx_ref, 5e-5, 'bf16 pooled-conv dgrad vs bf16-operand float64')
+    gw_ref = torch.nn.grad.conv2d_weight(bf(x), wt.shape, bf(gzu), padding=1) * scale
+    if w % 32 == 0:
+        assert_close(wg.grad.cpu(), gw_ref, 5e-5, 'bf16 pooled-conv wgrad vs bf16-operand float64')
+    else:
+        gw64 = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gzu.double(), padding=1) * scale
+        assert_close(wg.grad.cpu(), gw64, 2e-5, 'fp32 wgrad of a 16-wide pooled bf16 layer')
+    if has_b:
+        assert_close(bg.grad.cpu(), gz.double().sum(dim=(0, 2, 3)), 2e-4, 'bias grad')
+
+
 FULL = [(8, 128, 128, 128, 128), (8, 256, 64, 64, 512), (8, 512, 32, 32, 512), (8, 512, 16, 16, 512)]
 
 

@@ -255,7 +255,11 @@ def test_bf16_compute_mode_host_side():
     assert ok(8, 128, 8, 8, 128) == 0 and ok(8, 128, 24, 16, 128) == 0              # H % 16 for the 16-wide tiles
     assert ok(8, 16, 1024, 1024, 16) == 0        # thin layers
     assert ok(8, 96, 32, 32, 128) == 0           # Cin not a multiple of 64
-    assert ok(8, 128, 32, 32, 128, ks=1, pad=0) == 0 and ok(8, 128, 32, 32, 128, up=1) == 0
+    assert ok(8, 128, 32, 32, 128, ks=1, pad=0) == 0
+    # the nearest upsample in front / the average pool behind fold into the forward and input-gradient kernels (not both)
+    assert ok(8, 128, 32, 32, 128, up=1) == 1 and ok(8, 128, 32, 32, 128, pool=1) == 1
+    assert ok(8, 128, 32, 32, 128, up=1, pool=1) == 0 and ok(8, 128, 4, 8, 128, up=1) == 0
+    assert wsz(ctypes.byref(_lib.ConvGeom(8, 128, 32, 32, 128, 3, 1, 1, 0))) == 0      # weight gradient: plain geometry only
     assert ok(8, 128, 36, 32, 128) == 0          # H % 8
     assert L.ganlab_conv_pack_bf16(None, None, 128, 256, 0, 1.0, None) == 9 * 128 * 256
     assert L.ganlab_conv_pack_bf16(None, None, 100, 256, 0, 1.0, None) == -1
@@ -270,8 +274,11 @@ def test_bf16_compute_mode_host_side():
         g_bf = ops.Geom(8, 128, 32, 32, 128, 3, 1)
         g_up = ops.Geom(8, 256, 32, 32, 128, 3, 1, up=1)       # upsample materialised, then the bf16 conv at 64^2
         g_thin = ops.Geom(8, 16, 64, 64, 16, 3, 1)
-        assert not ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)  # conv (bf16) then pool, no stride-2 fusion
+        assert ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)      # conv + pool as one bf16 kernel
+        g_pool = ops.Geom(8, 128, 64, 64, 128, 3, 1, pool=1)
     assert g_bf.bf is not None and g_up.bf is not None and (g_up.bf.Hin, g_up.up, g_up.s2) == (64, 1, False)
+    assert g_bf.bf_fused is None and g_up.bf_fused is not None and (g_up.bf_fused.Hin, g_up.bf_fused.up) == (32, 1)
+    assert g_pool.bf_fused is not None and (g_pool.bf.Hin, g_pool.Ho, g_pool.s2) == (64, 32, False)
     assert g_thin.bf is None
     assert ops.get_compute_dtype() == 'f32' and ops.Geom(8, 128, 32, 32, 128, 3, 1).bf is None
     assert ops.pool_fusable(8, 128, 64, 64, 128, 3, 1)
