@@ -445,9 +445,19 @@ struct BfWrArgs {
 
 __device__ __forceinline__ int rw_swz(int ch) { return (((ch >> 1) & 3) << 1) | ((((ch & 15) + 4) >> 3) & 1); }
 
+// half-resolution slices ([channel][4 units]): the 16 lanes of a ds_read_b128 group are 8 channels of one k-group and
+// the 8 complementary channels of its neighbour; P = (0, 3, 2, 1) over channel / 4 keeps their 16 slots distinct
+__device__ __forceinline__ int rw_swz_up(int ch) { return (0x6C >> (((ch >> 2) & 3) * 2)) & 3; }
+
 typedef __attribute__((address_space(1))) const void* rw_gptr;
 typedef __attribute__((address_space(3))) void* rw_lptr;
 
+// XUP / GUP: the activation / the output gradient is stored at HALF the resolution of the taps and the kernel sees its
+// nearest 2x upsample (the weight gradient of conv(up2 x), resp. of pool2(conv x) whose gy is up2(gy_pooled) / 4 - the 1/4
+// goes into the reduce pass's scale).  Row R of the taps is source row R >> 1, a strip's 32 columns are 16 source pixels:
+// four 16-byte units per channel instead of eight (position u ^ swz_up(c)), half the DMAs, and the fragment builder
+// writes every source pixel twice before the tap shift picks its pairs.
+template <bool XUP, bool GUP>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 smem[2 * RW_PIPE + RW_SLOT];   // two rings + one slot of zeros
 
@@ -459,22 +469,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
   const int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
   const int pair = bid % p.npairs, slot = bid / p.npairs;
   const int ci0 = (pair % p.tiles_ci) * RW_T, co0 = (pair / p.tiles_ci) * RW_T;
-  const int plane = p.H * p.W;
+  const int xW = XUP ? p.W >> 1 : p.W, gW = GUP ? p.W >> 1 : p.W;                 // row lengths in memory
+  const int xplane = XUP ? (p.H >> 1) * xW : p.H * p.W, gplane = GUP ? (p.H >> 1) * gW : p.H * p.W;
   u32x4* const ring = smem + kgp * RW_PIPE;
   for (int i = threadIdx.x; i < RW_SLOT; i += 512) smem[2 * RW_PIPE + i] = u32x4{0u, 0u, 0u, 0u};
   const unsigned zslot = (unsigned)((2 - kgp) * RW_PIPE) * 16u;       // byte offset of the zero slot from `ring`
   // LDS byte addresses of this lane's fragment reads inside a ring slot (the reads are inline asm: hipcc would put
   // s_waitcnt vmcnt(0) in front of every ds_read it emits itself while an LDS-DMA is in flight)
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(rw_lptr)ring;
-  const int sw = rw_swz(l16);
+  const int sw = rw_swz(l16), swu = rw_swz_up(l16);
   unsigned aaddr[2][2], baddr[2][2], eaddr[2];
 #pragma unroll
   for (int nn = 0; nn < 2; ++nn) {
     const int ca = wa * 32 + nn * 16 + l16, cb = wc * 32 + nn * 16 + l16;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      aaddr[nn][o] = lds0 + (unsigned)(ca * 8 + ((2 * kg + o) ^ sw)) * 16u;
-      baddr[nn][o] = lds0 + (unsigned)(RW_ROW + cb * 8 + ((2 * kg + o) ^ sw)) * 16u;
+    for (int o = 0; o < 2; ++o) {     // half-resolution slices: ONE unit (4 source pixels) per lane, index o unused
+      aaddr[nn][o] = lds0 + (unsigned)(GUP ? ca * 4 + (kg ^ swu) : ca * 8 + ((2 * kg + o) ^ sw)) * 16u;
+      baddr[nn][o] = lds0 + (unsigned)(RW_ROW + (XUP ? cb * 4 + (kg ^ swu) : cb * 8 + ((2 * kg + o) ^ sw))) * 16u;
     }
     eaddr[nn] = lds0 + (unsigned)(2 * RW_ROW) * 16u + (unsigned)((kg >> 1) * 64 + cb) * 4u;
   }
@@ -482,13 +493,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
   // DMA work of this wave per step: LDS-DMA instructions 2wv, 2wv + 1 of the gy slice and of the x slice (8 channels x
   // 8 units each; the same per-lane byte offset serves both tensors) and, for waves 0 / 1, one 4-byte gather of the 64
   // left / right halo pixels
-  unsigned doff[2];
+  // (a half-resolution slice is 4 instructions of 16 channels x 4 units: one per wave)
+  unsigned dgoff[2], dxoff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int ch = 8 * (2 * wv + k) + (lane >> 3);
-    doff[k] = (unsigned)(ch * plane + 4 * ((lane & 7) ^ rw_swz(ch))) * 4u;
+    const int ch = 8 * (2 * wv + k) + (lane >> 3), chu = 16 * wv + (lane >> 2);
+    dgoff[k] = GUP ? (unsigned)(chu * gplane + 4 * ((lane & 3) ^ rw_swz_up(chu))) * 4u
+                   : (unsigned)(ch * gplane + 4 * ((lane & 7) ^ rw_swz(ch))) * 4u;
+    dxoff[k] = XUP ? (unsigned)(chu * xplane + 4 * ((lane & 3) ^ rw_swz_up(chu))) * 4u
+                   : (unsigned)(ch * xplane + 4 * ((lane & 7) ^ rw_swz(ch))) * 4u;
   }
-  const unsigned hoff = (unsigned)(lane * plane) * 4u;
+  const unsigned hoff = (unsigned)(lane * xplane) * 4u;
 
   f32x4 acc[2][2][9];
 #pragma unroll
@@ -511,12 +526,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
       n = t2 / p.segs_y;
     }
     const int ox0 = sx * 32, r0 = sy * RS;
-    const char* gyb = reinterpret_cast<const char*>(p.gy + ((long long)n * p.CO + co0) * plane);
-    const char* xb = reinterpret_cast<const char*>(p.x + ((long long)n * p.CI + ci0) * plane);
+    const char* gyb = reinterpret_cast<const char*>(p.gy + ((long long)n * p.CO + co0) * gplane);
+    const char* xb = reinterpret_cast<const char*>(p.x + ((long long)n * p.CI + ci0) * xplane);
     const bool lok = ox0 > 0, rok = ox0 + 32 < p.W;
     // halo gather: wave 0 fetches x[.., ox0 - 1], wave 1 x[.., ox0 + 32] (clamped into the row; lanes whose halo
-    // pixel lies outside the image read the zero slot instead)
-    const int hcol = (wv & 1) ? (rok ? ox0 + 32 : ox0 + 31) : (lok ? ox0 - 1 : ox0);
+    // pixel lies outside the image read the zero slot instead); in source columns when x is stored at half resolution
+    const int xc0 = XUP ? ox0 >> 1 : ox0, xcn = XUP ? 16 : 32, gc0 = GUP ? ox0 >> 1 : ox0;
+    const int hcol = (wv & 1) ? (rok ? xc0 + xcn : xc0 + xcn - 1) : (lok ? xc0 - 1 : xc0);
     const bool ezero = (kg == 0 && !lok) || (kg == 3 && !rok);
 
     auto issue = [&](int t) {
@@ -524,23 +540,34 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
       int gr = r0 + t, xr = r0 - 1 + t;                       // rows; out of range -> any valid row, never read
       gr = gr < p.H ? gr : p.H - 1;
       xr = xr < 0 ? 0 : (xr < p.H ? xr : p.H - 1);
-      const unsigned grow = (unsigned)(gr * p.W + ox0) * 4u, xrow = (unsigned)(xr * p.W + ox0) * 4u;
+      if (GUP) gr >>= 1;
+      if (XUP) xr >>= 1;
+      const unsigned grow = (unsigned)(gr * gW + gc0) * 4u, xrow = (unsigned)(xr * xW + xc0) * 4u;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        __builtin_amdgcn_global_load_lds((rw_gptr)(gyb + (doff[k] + grow)), (rw_lptr)(q + (2 * wv + k) * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (doff[k] + xrow)), (rw_lptr)(q + RW_ROW + (2 * wv + k) * 64), 16,
-                                         0, 0);
-      }
+      for (int k = 0; k < (GUP ? 1 : 2); ++k)
+        __builtin_amdgcn_global_load_lds((rw_gptr)(gyb + (dgoff[k] + grow)),
+                                         (rw_lptr)(q + (GUP ? wv : 2 * wv + k) * 64), 16, 0, 0);
+#pragma unroll
+      for (int k = 0; k < (XUP ? 1 : 2); ++k)
+        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (dxoff[k] + xrow)),
+                                         (rw_lptr)(q + RW_ROW + (XUP ? wv : 2 * wv + k) * 64), 16, 0, 0);
       if (wv < 2)
-        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (hoff + (unsigned)(xr * p.W + hcol) * 4u)),
+        __builtin_amdgcn_global_load_lds((rw_gptr)(xb + (hoff + (unsigned)(xr * xW + hcol) * 4u)),
                                          (rw_lptr)(reinterpret_cast<float*>(q + 2 * RW_ROW) + wv * 64), 4, 0, 0);
     };
-    // outstanding DMAs of two steps: 2 x 5 for waves 0 and 1 (which also gather the halo), 2 x 4 for waves 2 and 3
+    // outstanding DMAs of two steps: per step 4 (3 with a half-resolution operand), +1 for waves 0 and 1 (the halo)
     auto wait_two_steps = [&]() {
-      if (wv < 2)
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (XUP || GUP) {
+        if (wv < 2)
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        if (wv < 2)
+          asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
     };
 
     bf16x8 a[3][2];
@@ -560,12 +587,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
 #pragma unroll
       for (int na = 0; na < 2; ++na) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fa[na][0]) : "v"(aaddr[na][0] + sog));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[na][1]) : "v"(aaddr[na][1] + sog));
+        if (!GUP) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[na][1]) : "v"(aaddr[na][1] + sog));
+        else fa[na][1] = u32x4{0u, 0u, 0u, 0u};      // unused (never a copy of fa[na][0]: that register is still in flight)
       }
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fm[nb][0]) : "v"(baddr[nb][0] + sox));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fm[nb][1]) : "v"(baddr[nb][1] + sox));
+        if (!XUP) asm volatile("ds_read_b128 %0, %1" : "=v"(fm[nb][1]) : "v"(baddr[nb][1] + sox));
+        else fm[nb][1] = u32x4{0u, 0u, 0u, 0u};
         asm volatile("ds_read_b32 %0, %1" : "=v"(fe[nb]) : "v"(ezero ? eaddr[nb] + zslot : eaddr[nb] + sox));
       }
       asm volatile("s_waitcnt lgkmcnt(0)"
@@ -575,20 +604,27 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16_roll_kernel(BfWrArgs p
 #pragma unroll
       for (int na = 0; na < 2; ++na) {
         const u32x4 f0 = fa[na][0], f1 = fa[na][1];
-        a[P][na] = __builtin_bit_cast(
-            bf16x8, pack8(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
-                          __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)));
+        if (GUP)    // 4 source pixels, each twice
+          a[P][na] = __builtin_bit_cast(
+              bf16x8, pack8(__uint_as_float(f0.x), __uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.y),
+                            __uint_as_float(f0.z), __uint_as_float(f0.z), __uint_as_float(f0.w), __uint_as_float(f0.w)));
+        else
+          a[P][na] = __builtin_bit_cast(
+              bf16x8, pack8(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                            __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)));
       }
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const u32x4 m0 = fm[nb][0], m1 = fm[nb][1];
+        const u32x4 m0 = fm[nb][0], m1 = XUP ? fm[nb][0] : fm[nb][1];
         const float e = fe[nb];
         const float pl = __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)m1.w));
         const float pr = __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 16) << 2, (int)m0.x));
         const float f3 = kg == 0 ? e : pl, f12 = kg == 3 ? e : pr;
-        const float f4 = __uint_as_float(m0.x), f5 = __uint_as_float(m0.y), f6 = __uint_as_float(m0.z),
-                    f7 = __uint_as_float(m0.w), f8 = __uint_as_float(m1.x), f9 = __uint_as_float(m1.y),
-                    f10 = __uint_as_float(m1.z), f11 = __uint_as_float(m1.w);
+        // (XUP: m1 == m0 holds source pixels 4g .. 4g+3, so the neighbours' m1.w / m0.x are source pixels 4g-1 / 4g+4)
+        const float f4 = __uint_as_float(m0.x), f5 = __uint_as_float(XUP ? m0.x : m0.y),
+                    f6 = __uint_as_float(XUP ? m0.y : m0.z), f7 = __uint_as_float(XUP ? m0.y : m0.w),
+                    f8 = __uint_as_float(XUP ? m0.z : m1.x), f9 = __uint_as_float(XUP ? m0.z : m1.y),
+                    f10 = __uint_as_float(XUP ? m0.w : m1.z), f11 = __uint_as_float(XUP ? m0.w : m1.w);
         bf16x8 b[3];
         b[0] = __builtin_bit_cast(bf16x8, pack8(f3, f4, f5, f6, f7, f8, f9, f10));     // x[8g - 1 .. 8g + 6]
         b[1] = __builtin_bit_cast(bf16x8, pack8(f4, f5, f6, f7, f8, f9, f10, f11));    // x[8g .. 8g + 7]
@@ -697,14 +733,15 @@ bool wr_enabled() {
 
 WrPlan wr_plan(const ganlab_conv_geom* g) {
   WrPlan q;
+  const int H = g->Hin * (g->up ? 2 : 1), W = g->Win * (g->up ? 2 : 1);   // the resolution of the taps
   q.RS = 4;
   for (int d = 32; d >= 4; --d)
-    if (g->Hin % d == 0) {
+    if (H % d == 0) {
       q.RS = d;
       break;
     }
-  q.segs_y = g->Hin / q.RS;
-  q.strips = g->Win / 32;
+  q.segs_y = H / q.RS;
+  q.strips = W / 32;
   q.nseg = g->N * q.strips * q.segs_y;
   const int npairs = (g->Cout / RW_T) * (g->Cin / RW_T);
   int want = (512 + npairs - 1) / npairs;          // two 4-wave pipelines (one 512-thread workgroup) per CU
@@ -737,8 +774,11 @@ bool bf16_ok(const ganlab_conv_geom* g) {
 }
 
 // the weight-gradient kernels walk 32-pixel strips
+// (with up / pool only the rolling kernel: it reads the half-resolution operand in place)
 bool bf16_wgrad_ok(const ganlab_conv_geom* g) {
-  return bf16_ok(g) && !g->up && !g->pool && g->Hin % 8 == 0 && g->Win % 32 == 0;
+  if (!bf16_ok(g)) return false;
+  const int m = g->up ? 2 : 1;
+  return (g->Hin * m) % 8 == 0 && (g->Win * m) % 32 == 0 && (!(g->up || g->pool) || wr_enabled());
 }
 
 int wgrad_slots(const ganlab_conv_geom* g) {
@@ -827,14 +867,19 @@ int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const gan
     const WrPlan q = wr_plan(g);
     BfWrArgs r;
     r.gy = gy; r.x = x; r.ws = reinterpret_cast<float*>(workspace);
-    r.N = g->N; r.CI = g->Cin; r.CO = g->Cout; r.H = g->Hin; r.W = g->Win;
+    const int m = g->up ? 2 : 1;
+    r.N = g->N; r.CI = g->Cin; r.CO = g->Cout; r.H = g->Hin * m; r.W = g->Win * m;
     r.tiles_ci = r.CI / RW_T; r.npairs = r.tiles_ci * (r.CO / RW_T);
     r.RS = q.RS; r.segs_y = q.segs_y; r.strips = q.strips; r.nseg = q.nseg; r.streams = q.streams;
-    const long long grid = (long long)r.npairs * q.flush_slots;
-    GL_LAUNCH(conv_wgrad_bf16_roll_kernel, dim3((unsigned)grid), dim3(512), 0, gl_stream(stream), r);
+    const dim3 gd((unsigned)((long long)r.npairs * q.flush_slots)), bd(512);
+    // conv(up2 x): x is stored at half the taps' resolution; pool2(conv x): gy is, and its adjoint carries 1/4
+    if (g->up) GL_LAUNCH((conv_wgrad_bf16_roll_kernel<true, false>), gd, bd, 0, gl_stream(stream), r);
+    else if (g->pool) GL_LAUNCH((conv_wgrad_bf16_roll_kernel<false, true>), gd, bd, 0, gl_stream(stream), r);
+    else GL_LAUNCH((conv_wgrad_bf16_roll_kernel<false, false>), gd, bd, 0, gl_stream(stream), r);
     const int n4 = r.npairs * 4 * 36 * 64;
     GL_LAUNCH(wgrad_bf16_roll_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, gl_stream(stream),
-              reinterpret_cast<const f32x4*>(r.ws), gw, r.npairs, r.tiles_ci, r.CI, q.flush_slots, scale);
+              reinterpret_cast<const f32x4*>(r.ws), gw, r.npairs, r.tiles_ci, r.CI, q.flush_slots,
+              g->pool ? scale * 0.25f : scale);
     return GL_CHECK_LAUNCH();
   }
   BfWgArgs a;

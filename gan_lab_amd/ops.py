@@ -452,8 +452,16 @@ def k_conv_wgrad(gy, x, g, scale):
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     if g.bf is not None:
-        # the weight gradient contracts over the pixels the taps run on: it takes the materialised upsample of x (up) or of
-        # the pooled layer's output gradient (pool: up2(gy) / 4, the adjoint of the average)
+        if g.bf_fused is not None:
+            # the rolling-row kernel reads the half-resolution operand (x of conv(up2 x), gy of pool2(conv x)) in place
+            nbytes = L.ganlab_conv_wgrad_bf16_workspace(ctypes.byref(g.bf_fused))
+            if nbytes > 0:
+                ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+                check(L.ganlab_conv_wgrad_bf16(_p(gy), _p(x), _p(gw), ctypes.byref(g.bf_fused), scale, _p(ws),
+                                               ws.numel() * 4, _st()), 'conv_wgrad_bf16')
+                return gw
+        # otherwise (16-wide taps) the weight gradient takes the materialised upsample of x (up) or of the pooled layer's
+        # output gradient (pool: up2(gy) / 4, the adjoint of the average)
         xin = k_up2(x, 1.0) if g.up else x
         if g.pool:
             gy = k_up2(gy, 0.25)

@@ -146,11 +146,14 @@ int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const g
  * the operands are rounded to bf16 (RNE) on their way into LDS and multiplied on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation; every tensor in HBM stays fp32 (the reference's storage type, fp32 master weights).  The reference
  * itself is fp32 only, so this path is an extension selected by the caller (gan_lab_amd.ops.compute_dtype).
- * Supported (ganlab_conv_bf16_supported; forward and input gradient): 3x3, pad 1, no up / pool, Cin % 64 == 0,
- * Cout % 64 == 0 and either H % 8 == 0, W % 32 == 0 or H % 16 == 0, W % 16 == 0; everything else stays on the exact
- * fp32 kernels.  The weight gradient needs W % 32 == 0 (H % 8 == 0): ganlab_conv_wgrad_bf16_workspace returns 0 for a
- * geometry it does not take (ganlab_conv_wgrad_bf16 then returns GANLAB_EUNSUPPORTED) and the caller uses
- * ganlab_conv_wgrad_f32 on the same tensors.
+ * Supported (ganlab_conv_bf16_supported; forward and input gradient): 3x3, pad 1, Cin % 64 == 0, Cout % 64 == 0 and, at
+ * the resolution the taps run on (2 Hin x 2 Win with up), either H % 8 == 0, W % 32 == 0 or H % 16 == 0, W % 16 == 0;
+ * up (nearest 2x upsample in front, progan/architectures.py:160-186) or pool (2x2 average pool behind, :261-284) - not
+ * both - fold into the kernels: x / gx are Hin x Win, y / gy are Ho x Wo as for ganlab_conv_s2_*; everything else stays
+ * on the exact fp32 kernels.  The weight gradient needs W % 32 == 0, H % 8 == 0 at the taps' resolution (with up it reads
+ * the Hin x Win input in place, with pool the pooled gy): ganlab_conv_wgrad_bf16_workspace returns 0 for a geometry it
+ * does not take (ganlab_conv_wgrad_bf16 then returns GANLAB_EUNSUPPORTED) and the caller uses ganlab_conv_wgrad_f32 on
+ * the plain geometry with the materialised upsample of x, resp. of gy / 4.
  * pack: returns the number of bf16 elements (9*Cout*Cin) when `out` is NULL; mode is GANLAB_PACK_*. */
 int ganlab_conv_bf16_supported(const ganlab_conv_geom* g);
 long long ganlab_conv_pack_bf16(const float* w, void* out, int Cout, int Cin, int mode, float scale, void* stream);

@@ -44,6 +44,7 @@ CASES = [
     (8, 320, 16, 96, 320, False, False, None),    # 25 channel tiles: every weight-gradient pipeline walks 2 segments
     (3, 128, 16, 16, 64, False, True, 'lrelu'),   # 16-wide maps: 16 x 16 pixel tiles; the weight gradient stays fp32
     (2, 64, 32, 48, 128, False, False, None),     # width a multiple of 16 only
+    (3, 128, 12, 48, 64, True, True, 'lrelu'),    # upsample folded in: taps at 24 x 96 (3 strips, one 24-row segment)
 ]
 
 
@@ -113,7 +114,8 @@ def test_bf16_mode_leaves_unsupported_shapes_exact(ops):
     assert_close(y.cpu(), F.conv2d(x.double() * 0.1, wt.double(), padding=1), 2e-5, 'fp32 kernel in bf16 mode')
 
 
-POOL_CASES = [(2, 64, 16, 64, 128, True, 'lrelu'), (3, 128, 32, 32, 64, False, None), (2, 64, 32, 16, 64, True, 'lrelu')]
+POOL_CASES = [(2, 64, 16, 64, 128, True, 'lrelu'), (3, 128, 32, 32, 64, False, None), (2, 64, 32, 16, 64, True, 'lrelu'),
+              (3, 64, 24, 96, 128, True, None)]
 
 
 @pytest.mark.parametrize('case', POOL_CASES, ids=[str(c) for c in POOL_CASES])

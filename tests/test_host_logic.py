@@ -259,7 +259,8 @@ def test_bf16_compute_mode_host_side():
     # the nearest upsample in front / the average pool behind fold into the forward and input-gradient kernels (not both)
     assert ok(8, 128, 32, 32, 128, up=1) == 1 and ok(8, 128, 32, 32, 128, pool=1) == 1
     assert ok(8, 128, 32, 32, 128, up=1, pool=1) == 0 and ok(8, 128, 4, 8, 128, up=1) == 0
-    assert wsz(ctypes.byref(_lib.ConvGeom(8, 128, 32, 32, 128, 3, 1, 1, 0))) == 0      # weight gradient: plain geometry only
+    assert wsz(ctypes.byref(_lib.ConvGeom(8, 128, 32, 32, 128, 3, 1, 1, 0))) > 0       # weight gradient: half-resolution x in place
+    assert wsz(ctypes.byref(_lib.ConvGeom(8, 128, 8, 8, 128, 3, 1, 1, 0))) == 0        # ... but not on 16-wide taps
     assert ok(8, 128, 36, 32, 128) == 0          # H % 8
     assert L.ganlab_conv_pack_bf16(None, None, 128, 256, 0, 1.0, None) == 9 * 128 * 256
     assert L.ganlab_conv_pack_bf16(None, None, 100, 256, 0, 1.0, None) == -1
