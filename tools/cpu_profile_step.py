@@ -19,10 +19,11 @@ def main():
     ap.add_argument('--res', type=int, default=128)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--model', default='stylegan')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--top', type=int, default=45)
     a = ap.parse_args()
-    learner = bench.build_learner(a.res, a.batch, 'cuda', a.dtype, 'stylegan')
+    learner = bench.build_learner(a.res, a.batch, 'cuda', a.dtype, a.model)
     sched = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
     for _ in range(3):
         bench.one_step(learner, sched)
