@@ -82,6 +82,8 @@ SIGNATURES = {
     'ganlab_channel_sum_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_channel_sum_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
     'ganlab_instnorm_stats_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_f, _c_p]),
+    'ganlab_row_stats_workspace': (_c_sz, [_c_ll, _c_ll]),
+    'ganlab_row_stats_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_ll, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_instnorm_style_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_instnorm_style_bwd_reduce_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_ll, _c_p]),
     'ganlab_instnorm_style_bwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int,

@@ -383,6 +383,37 @@ __global__ void act_stats_finish_kernel(const double* __restrict__ spart, float*
   rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// partial sums of one chunk of one row: block (row, chunk), fp64 sums of exact float squares, [row][chunk][2]
+__global__ __launch_bounds__(256) void row_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ spart,
+                                                                int chunks, long long m4) {
+  __shared__ double red[2][4];
+  const long long row = blockIdx.x / chunks;
+  const int k = blockIdx.x % chunks;
+  const long long per = (m4 + chunks - 1) / chunks, lo = k * per, hi = lo + per < m4 ? lo + per : m4;
+  const float4* p4 = reinterpret_cast<const float4*>(x) + row * m4;
+  double s = 0.0, ss = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 v = p4[i];
+    const double a = (double)v.x, b = (double)v.y, c = (double)v.z, d = (double)v.w;
+    s += (a + b) + (c + d);
+    ss += (a * a + b * b) + (c * c + d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    spart[((long long)blockIdx.x) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    spart[((long long)blockIdx.x) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 inline int act_stats_chunks(long long hw4) {
   long long c = (hw4 + 256 * 8 - 1) / (256 * 8);      // ~8 float4 per thread
   if (c < 1) c = 1;
@@ -1455,6 +1486,27 @@ int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long lon
   else
     GL_LAUNCH(instnorm_stats_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, ST, x, mean,
                        rstd, planes, HW, eps);
+  return GL_CHECK_LAUNCH();
+}
+
+/* the same statistics for FEW, LONG rows (LayerNorm over C*H*W: batch-many rows of 10^5..10^6 elements - one block per
+ * row leaves 3/4 of the CUs idle): each row is cut into chunks, fp64 partial sums per chunk, fixed-order finish */
+size_t ganlab_row_stats_workspace(long long rows, long long M) {
+  if (rows <= 0 || M <= 0) return 0;
+  return (size_t)rows * act_stats_chunks(M / 4) * 2 * sizeof(double);
+}
+
+int ganlab_row_stats_f32(const float* x, float* mean, float* rstd, long long rows, long long M, float eps,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !mean || !rstd || rows <= 0 || M <= 0) return GANLAB_EINVAL;
+  const int chunks = act_stats_chunks(M / 4);
+  if ((M & 3) != 0 || chunks < 2 || rows * chunks > 0x7fffffffLL)      // short or ragged rows: one block per row
+    return ganlab_instnorm_stats_f32(x, mean, rstd, rows, M, eps, stream);
+  if (!workspace || workspace_bytes < ganlab_row_stats_workspace(rows, M)) return GANLAB_EWORKSPACE;
+  double* sp = reinterpret_cast<double*>(workspace);
+  GL_LAUNCH(row_stats_partial_kernel, dim3((unsigned)(rows * chunks)), dim3(256), 0, ST, x, sp, chunks, M >> 2);
+  GL_LAUNCH(act_stats_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ST, (const double*)sp, mean,
+            rstd, rows, chunks, 1.0 / (double)M, eps);
   return GL_CHECK_LAUNCH();
 }
 

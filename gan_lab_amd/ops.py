@@ -1775,7 +1775,9 @@ class _LayerNorm(Function):
         b = _c(bias).reshape(m) if bias is not None else None
         L = _lib.lib()
         mean, rstd = _new((n,), x), _new((n,), x)
-        check(L.ganlab_instnorm_stats_f32(_p(x), _p(mean), _p(rstd), n, m, eps, _st()), 'ln_stats')
+        nbytes = L.ganlab_row_stats_workspace(n, m)
+        ws = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
+        check(L.ganlab_row_stats_f32(_p(x), _p(mean), _p(rstd), n, m, eps, _p(ws), ws.numel() * 8, _st()), 'ln_stats')
         y = torch.empty_like(x)
         check(L.ganlab_ln_affine_fwd_f32(_p(x), _p(mean), _p(rstd), _p(w), _p(b), _p(y), n, m, _st()), 'ln_affine_fwd')
         ctx.save_for_backward(x, weight, mean, rstd)   # the weight INPUT: the double backward reaches the parameter

@@ -232,6 +232,11 @@ size_t ganlab_channel_sum_workspace(int N, int C, long long HW);
 /* InstanceNorm2d(eps, biased var) statistics per (n,c) plane: mean, rstd (custom_layers.py:98-99) */
 int ganlab_instnorm_stats_f32(const float* x, float* mean, float* rstd, long long planes, long long HW,
                               float eps, void* stream);
+/* the same statistics for few, long rows (LayerNorm([C,R,R]) of the ResNet critics, custom_layers.py:100-107: `rows` =
+ * batch, M = C*R*R): several blocks per row, fp64 partial sums, fixed-order finish (deterministic). */
+size_t ganlab_row_stats_workspace(long long rows, long long M);
+int ganlab_row_stats_f32(const float* x, float* mean, float* rstd, long long rows, long long M, float eps,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* y = (x-mean)*rstd*(ys+1)+yb with style (N,2,C) (stylegan/architectures.py:524-526); style may be
  * NULL (plain InstanceNorm). */
 int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float* rstd,

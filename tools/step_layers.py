@@ -2,7 +2,7 @@
 """Per-layer conv timing of one G+D step at the bench configuration: wraps the conv launchers of
 gan_lab_amd.ops with device events and prints, per (kind, geometry): calls, total ms, executed TFLOP/s
 (stride-2 fused layers priced with their 16 low-res taps) and the share of the step.
-    python tools/step_layers.py [--res 1024] [--batch 32]"""
+    python tools/step_layers.py [--res 1024] [--batch 32] [--model stylegan|progan|resnetgan]"""
 import argparse
 import collections
 import os
@@ -19,11 +19,20 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument('--res', type=int, default=1024)
     p.add_argument('--batch', type=int, default=32)
+    p.add_argument('--model', default='stylegan', choices=('stylegan', 'progan', 'resnetgan'))
     a = p.parse_args()
     torch.cuda.set_device(0)
-    L = bench.build_learner(a.res, a.batch, 'cuda')
-    real = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
-    bench.one_step(L, real)
+    if a.model == 'resnetgan':      # BASELINE config #5: one main iteration = 1 G + 5 critic iterations
+        import types
+        wl = bench.Workload(types.SimpleNamespace(model='resnetgan', res=a.res, batch=a.batch, dtype='f32', world=1,
+                                                  nimg_transition=0), torch)
+        one = wl.step
+    else:
+        L = bench.build_learner(a.res, a.batch, 'cuda', 'f32', a.model)
+        real = torch.rand(a.batch, 3, a.res, a.res, device='cuda') * 2 - 1
+        one = lambda: bench.one_step(L, real)
+    one()
+    one()
     rec = []
 
     def wrap(name, fn, gi):
@@ -48,7 +57,7 @@ def main():
     torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s0.record()
-    bench.one_step(L, real)
+    one()
     s1.record()
     torch.cuda.synchronize()
     step_ms = s0.elapsed_time(s1)
