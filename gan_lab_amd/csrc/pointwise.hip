@@ -960,8 +960,15 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_split_kernel(const float* _
 }
 
 // slices per pixel for the split kernels: enough threads for ~8 waves per SIMD, at least 16 pixels (64 bytes) per row
+static bool pixelnorm_generic() {       // GANLAB_PIXELNORM_GENERIC=1: the one-thread-per-pixel kernels for every shape (A/B)
+  static const bool v = [] { const char* e = getenv("GANLAB_PIXELNORM_GENERIC"); return e != nullptr && atoi(e) != 0; }();
+  return v;
+}
+
 static int pixelnorm_splits(int N, int C, long long HW) {
-  if (C < 256) return 0;
+  // maps only: a block's 16+ pixels are contiguous within a row of HW; the latent vectors of the mapping network
+  // (HW == 1, N x 512 values) stay on the one-thread-per-pixel kernel
+  if (C < 256 || HW < 16 || pixelnorm_generic()) return 0;
   const long long px = (long long)N * HW;
   return px >= 262144 ? 0 : (px >= 65536 ? 4 : 16);
 }
@@ -1559,7 +1566,8 @@ int ganlab_instnorm_style_bwd_apply_f32(const float* gy, const float* x, const f
 int ganlab_pixelnorm_fwd_f32(const float* x, float* y, int N, int C, long long HW, float eps, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const dim3 gd(ew_blocks((long long)N * HW)), bd(256);
-  if (C == 16) GL_LAUNCH(pixelnorm_fwd_reg_kernel<16>, gd, bd, 0, ST, x, y, N, HW, eps);
+  if (pixelnorm_generic()) GL_LAUNCH(pixelnorm_fwd_kernel, gd, bd, 0, ST, x, y, N, C, HW, eps);
+  else if (C == 16) GL_LAUNCH(pixelnorm_fwd_reg_kernel<16>, gd, bd, 0, ST, x, y, N, HW, eps);
   else if (C == 32) GL_LAUNCH(pixelnorm_fwd_reg_kernel<32>, gd, bd, 0, ST, x, y, N, HW, eps);
   else if (C == 64) GL_LAUNCH(pixelnorm_fwd_reg_kernel<64>, gd, bd, 0, ST, x, y, N, HW, eps);
   else if (C == 128) GL_LAUNCH(pixelnorm_fwd_reg_kernel<128>, gd, bd, 0, ST, x, y, N, HW, eps);
@@ -1575,7 +1583,8 @@ int ganlab_pixelnorm_bwd_f32(const float* gy, const float* x, float* gx, int N, 
                              void* stream) {
   if (!gy || !x || !gx || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const dim3 gd(ew_blocks((long long)N * HW)), bd(256);
-  if (C == 16) GL_LAUNCH(pixelnorm_bwd_reg_kernel<16>, gd, bd, 0, ST, gy, x, gx, N, HW, eps);
+  if (pixelnorm_generic()) GL_LAUNCH(pixelnorm_bwd_kernel, gd, bd, 0, ST, gy, x, gx, N, C, HW, eps);
+  else if (C == 16) GL_LAUNCH(pixelnorm_bwd_reg_kernel<16>, gd, bd, 0, ST, gy, x, gx, N, HW, eps);
   else if (C == 32) GL_LAUNCH(pixelnorm_bwd_reg_kernel<32>, gd, bd, 0, ST, gy, x, gx, N, HW, eps);
   else if (C == 64) GL_LAUNCH(pixelnorm_bwd_reg_kernel<64>, gd, bd, 0, ST, gy, x, gx, N, HW, eps);
   else if (C == 128) GL_LAUNCH(pixelnorm_bwd_reg_kernel<128>, gd, bd, 0, ST, gy, x, gx, N, HW, eps);
