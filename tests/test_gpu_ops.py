@@ -235,6 +235,28 @@ def test_bias_act_noise(ops):
         assert_close(nwg.grad, nw.grad, TOL)
 
 
+PN_SHAPES = [(2, 16, 32, 32), (2, 32, 16, 24), (3, 64, 16, 16), (2, 128, 8, 8),      # channels in registers
+             (4, 512, 8, 8), (3, 256, 64, 64), (2, 512, 4, 4), (2, 320, 8, 8),       # channel-split blocks (S = 16 / 4)
+             (5, 512, 1, 1), (2, 96, 8, 8), (1, 256, 512, 512)]                      # one thread per pixel
+
+
+@pytest.mark.parametrize('shape', PN_SHAPES, ids=[str(c) for c in PN_SHAPES])
+def test_pixelnorm_every_kernel_vs_float64(ops, shape):
+    """PixelNorm2d (custom_layers.py:81-86) forward and backward on each of its three kernel families (chosen by the
+    shape inside ganlab_pixelnorm_*_f32): against float64, 2e-6 relative - the sums have at most 512 terms."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=gen) * 1.5 + 0.2
+    cot = torch.randn(*shape, generator=gen)
+    xd = x.double().requires_grad_(True)
+    ref = xd * ((xd ** 2).mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    (ref * cot.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = ops.pixelnorm(xg)
+    assert_close(y, ref.detach(), 2e-6, 'pixelnorm forward')
+    (y * cot.cuda()).sum().backward()
+    assert_close(xg.grad, xd.grad, 2e-6, 'pixelnorm backward')
+
+
 def test_instnorm_style_and_pixelnorm(ops):
     from oracle import ops as O
     G = load_golden('ops.npz')

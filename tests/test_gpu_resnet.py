@@ -89,7 +89,8 @@ def test_batch_norm_train_and_eval():
     assert_close(mine(x.cuda()).cpu(), ref(x), 1e-5, 'bn eval')
 
 
-@pytest.mark.parametrize('shape', [(4, 3, 8, 8), (2, 8, 16, 16), (3, 5, 4, 4)])
+@pytest.mark.parametrize('shape', [(4, 3, 8, 8), (2, 8, 16, 16), (3, 5, 4, 4),
+                                   (3, 16, 32, 32), (2, 32, 64, 64)])      # the last two: several statistics blocks per row
 def test_layer_norm_first_and_second_order(shape):
     """LayerNorm([C,R,R]) inside a WGAN-GP style double backward: d/dtheta of |d out / d x|^2."""
     from gan_lab_amd.utils.custom_layers import LayerNorm
