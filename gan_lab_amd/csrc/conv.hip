@@ -1101,7 +1101,7 @@ struct WgradArgs {
   const float* gy;
   float* part;  // [slots][Cout][Cin][KK]
   int Cout, Ho, Wo;
-  int tiles_x, tiles_y, tiles_n, tiles_co, tiles_ci, S;
+  int tiles_x, tiles_y, tiles_n, tiles_co, tiles_ci, S, xcd;
 };
 
 template <int KS_, int NBC_, int WM_, int WK_, int TWL_, int THL_, int NIL_, int XMODE_>
@@ -1133,11 +1133,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WK, wk = wave % WK;
-  int bid = blockIdx.x;
-  const int split = bid % p.S;
-  bid /= p.S;
-  const int ci_t = bid % p.tiles_ci;
-  const int co_t = bid / p.tiles_ci;
+  // Workgroups of one split walk the same pixel tiles, each with its own (co, ci) tile pair: gy is shared by the pairs of
+  // a co tile, x by those of a ci tile.  Consecutive logical ids = the pairs of one split, and gl_xcd_remap keeps them on
+  // one XCD, so those re-reads hit its L2 (with the split index fastest they were 5.9x the operands from HBM).
+  int bid = p.xcd ? gl_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  int split, ci_t, co_t;
+  if (p.xcd) {
+    const int pairs = p.tiles_ci * p.tiles_co;
+    split = bid / pairs;
+    bid %= pairs;
+    ci_t = bid % p.tiles_ci;
+    co_t = bid / p.tiles_ci;
+  } else {
+    split = bid % p.S;
+    bid /= p.S;
+    ci_t = bid % p.tiles_ci;
+    co_t = bid / p.tiles_ci;
+  }
   const int co0 = co_t * CO_T, ci0 = ci_t * CI_T;
   const int plane = p.in.Hi * p.in.Wi, oplane = p.Ho * p.Wo;
 
@@ -1753,6 +1765,9 @@ struct LaunchFn {
   template <class Cfg> int run() {
     a.tiles_x = pl->tiles_x; a.tiles_y = pl->tiles_y; a.tiles_n = pl->tiles_n;
     a.tiles_co = pl->tiles_co; a.tiles_ci = pl->tiles_ci; a.S = pl->S;
+    // XCD-aware block order (default; GANLAB_WGRAD_XCD=0 restores split-fastest): 64->64 @256^2 +4.5 %, 128->128 @128^2 +2 %,
+    // the others +-0.5 % (tools/wgrad_thick_probe.py), HBM reads 5.9x -> see profiles/r02g_thick_wgrad_pmc.txt
+    { static const int v = [] { const char* e = getenv("GANLAB_WGRAD_XCD"); return (e && e[0] == '0') ? 0 : 1; }(); a.xcd = v; }
     const long long grid = (long long)pl->tiles_co * pl->tiles_ci * pl->S;
     GL_LAUNCH(conv_wgrad_kernel<Cfg>, dim3((unsigned)grid), dim3(256), 0, st, a);
     return GL_CHECK_LAUNCH();
