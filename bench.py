@@ -2,8 +2,13 @@
 """Benchmark of the G+D training step (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W                      # headline: BASELINE config #3
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-             --master-port P bench.py --gpus N --steps K --warmup W)
+    N > 1, either way:
+      * under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+        --master-port P bench.py --gpus N ...): RANK / LOCAL_RANK / WORLD_SIZE come from the environment and
+        WORLD_SIZE must equal --gpus (anything else exits non-zero: no silent single-rank run);
+      * bare (python bench.py --gpus N ...): this process touches no GPU, starts exactly that launcher as a child with
+        N fresh ranks, relays rank 0's JSON line and exits with the child's code.
+    python bench.py --gpus 2 --dry-run-dist   # CPU rehearsal of the N-rank path: gloo ranks, host logic only
     python bench.py --config {2,4,5} ...                               # the other BASELINE configurations
 
 Default (= --config 3): images/sec of the full G+D step (1 D-iteration + 1 G-iteration), StyleGAN 1024^2, batch 32
@@ -57,6 +62,9 @@ def parse():
     p.add_argument('--cpu-baseline-batch', type=int, default=1)
     p.add_argument('--cpu-baseline-steps', type=int, default=3)
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--dry-run-dist', action='store_true',
+                   help='rehearse the multi-rank path on CPU: gloo ranks build a small learner (host logic only), '
+                        'broadcast its arenas and run the bucketed gradient exchange; no GPU is touched')
     a = p.parse_args()
     dflt = {2: ('stylegan', 128, 8, 'bf16', 20), 3: ('stylegan', 1024, 32, 'f32', 3), 4: ('progan', 256, 32, 'f32', 10),
             5: ('resnetgan', 64, 64, 'f32', 5)}[a.config]
@@ -355,30 +363,205 @@ def cpu_baseline(torch, res, batch, steps=3):
                       f'{med:.1f} s'}
 
 
+def _baseline_record(torch, batch, images_per_step, times, what, model, n_phys, usable):
+    med = statistics.median(times[1:])
+    return {'value': round(images_per_step / med, 5), 'unit': 'images/sec', 'cores': n_phys, 'kind': 'port',
+            'cpu_model': model, 'logical_cpus': usable, 'torch_threads': torch.get_num_threads(),
+            'step_seconds': [round(t, 2) for t in times],
+            'sample': f'{what} at batch {batch} (torch CPU fp32, {n_phys} threads = physical cores of {model}): '
+                      f'1 warm-up + {len(times) - 1} timed steps, median {med:.1f} s'}
+
+
+def cpu_baseline_progan(torch, res, batch, steps=2):
+    """Config #4's CPU yardstick: the oracle's G+D step of the full-width ProGAN at the final resolution (WGAN +
+    WGAN-GP + drift, PixelNorm; oracle/nets.py + oracle/step.py FunctionalGAN) at a reduced batch, stated."""
+    from gan_lab_amd import progressive as P
+    from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator
+    from oracle import nets, step
+    import numpy as np
+    model, n_phys, usable = host_cpu()
+    torch.set_num_threads(n_phys)
+    torch.manual_seed(0)
+    P.ProGAN.reset_state()
+    g, d = ProGenerator(final_res=res, blur_type='binomial'), ProDiscriminator(final_res=res, blur_type='binomial')
+    for _ in range(int(np.log2(res)) - 2):
+        g.increase_scale()
+        d.increase_scale()
+    gan = step.FunctionalGAN(g.state_dict(), d.state_dict(), nets.make_cfg(use_pixelnorm=True), model='progan',
+                             loss='wgan', gp='wgan-gp', lda=10., eps_drift=.001)
+    del g, d
+    real = torch.rand(batch, 3, res, res) * 2 - 1
+    times = []
+    for _ in range(1 + steps):
+        t0 = time.perf_counter()
+        gan.d_step(torch.randn(batch, 512), real, eps_interp=torch.rand(batch, 1, 1, 1))
+        gan.g_step(torch.randn(batch, 512), beta=0.999)
+        times.append(time.perf_counter() - t0)
+    return _baseline_record(torch, batch, batch, times, f'G+D step of ProGAN {res}^2, stabilised phase (oracle/step.py '
+                            f'FunctionalGAN: WGAN + WGAN-GP + drift)', model, n_phys, usable)
+
+
+def cpu_baseline_resnet(torch, res, batch, steps=2, nd=5):
+    """Config #5's CPU yardstick: one main iteration (1 G-iter + ``nd`` critic iters, WGAN + WGAN-GP) of the ResNet GAN
+    through oracle/resnet.py ResnetFunctionalGAN at a reduced batch, stated; images = real images consumed."""
+    from gan_lab_amd.resnetgan import architectures as A
+    from oracle import resnet
+    model, n_phys, usable = host_cpu()
+    torch.set_num_threads(n_phys)
+    torch.manual_seed(0)
+    g = (A.Generator64PixResnet if res == 64 else A.Generator32PixResnet)()
+    d = (A.Discriminator64PixResnet if res == 64 else A.Discriminator32PixResnet)()
+    gan = resnet.ResnetFunctionalGAN(g.state_dict(), d.state_dict(), res)
+    zlen = g.len_latent if hasattr(g, 'len_latent') else 128
+    del g, d
+    times = []
+    for _ in range(1 + steps):
+        t0 = time.perf_counter()
+        gan.g_step(torch.randn(batch, zlen))
+        for _ in range(nd):
+            gan.d_step(torch.randn(batch, zlen), torch.rand(batch, 3, res, res) * 2 - 1, torch.rand(batch, 1, 1, 1))
+        times.append(time.perf_counter() - t0)
+    return _baseline_record(torch, batch, batch * nd, times, f'main iteration (1 G-iter + {nd} critic iters) of ResNet '
+                            f'GAN {res}^2 (oracle/resnet.py ResnetFunctionalGAN: WGAN + WGAN-GP)', model, n_phys, usable)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-rank launch
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` (N > 1) outside a launcher: start N FRESH ranks through torch.distributed.run as a
+    child process (this parent has made no GPU call and makes none: a process that has initialised the GPU must not be
+    replaced or forked), relay rank 0's one JSON line to stdout and return the child's exit code."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    print(f'bench.py: starting {a.gpus} ranks: {" ".join(cmd)}', file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)       # stderr is inherited
+    record = None
+    for raw in proc.stdout:
+        line = raw.decode(errors='replace').rstrip('\n')
+        if line.startswith('{') and line.endswith('}'):
+            record = line
+        elif line:
+            print(line, file=sys.stderr)
+    rc = proc.wait()
+    if record is not None:
+        print(record, flush=True)
+    if rc == 0 and record is None:
+        print('bench.py: the ranks exited 0 without a JSON record', file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dry_run_dist(a, json_fd):
+    """CPU rehearsal of what an N-rank run does around the kernels (gloo, GANLAB_HOST_LOGIC_ONLY): process group from
+    the launcher's environment, the learner's construction (arenas, rank-0 parameter / EWMA broadcast, shared Philox
+    seed), then K 'steps' whose backward is a plain torch expression on the arena parameters - enough to fire the
+    bucket hooks of parallel.GradReducer, agree on the launch order and mean-reduce the flat gradient arenas exactly as
+    d_step / g_step do.  Checks that every rank ends with identical, correctly averaged gradients."""
+    import contextlib
+    import io
+    import torch
+    import torch.distributed as dist
+    os.environ['GANLAB_HOST_LOGIC_ONLY'] = '1'
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(1234 + rank)
+    from gan_lab_amd import parallel, progressive as P
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.stylegan.learner import StyleGANLearner
+    P.FMAP_BASE, P.FMAP_MAX = 256, 16
+    with contextlib.redirect_stdout(io.StringIO()):
+        L = StyleGANLearner(make_config('stylegan', dev='cpu', pin_memory=False, res_samples=32, res_dataset=32,
+                                        init_res=32, batch_size=4, len_latent=16, len_dlatent=16, mapping_num_fcs=2,
+                                        cutoff_trunc_trick=None, log_every=0, random_seed=7))
+    L.reducer = parallel.GradReducer(bucket_mb=0.02)           # several buckets even for this toy network
+    ok, launched = True, []
+    dist.barrier()
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        for arena in (L.arena_d, L.arena_g):
+            arena.zero_grad()
+            coef = float(rank + 1 + it)
+            loss = sum((p * coef).sum() for p in arena.params)         # d loss / d p == coef on this rank
+            L.reducer.arm(arena)
+            loss.backward()
+            L.reducer.start(arena.gflat)
+            L.reducer.finish()
+            want = sum(float(r + 1 + it) for r in range(world)) / world
+            used = torch.cat([arena.gflat[o:o + n] for o, n in zip(arena.offsets, arena.sizes)])
+            ok = ok and bool(torch.allclose(used, torch.full_like(used, want), rtol=1e-6, atol=0))
+            launched.append(L.reducer.bucket_report(arena)['launched_in_backward'])
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    flags = torch.tensor([int(ok)])
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    rep = L.reducer.bucket_report(L.arena_d)
+    if rank == 0:
+        out = {'metric': 'dry run of the multi-rank path (gloo, host logic only; no GPU)', 'value': None, 'unit': None,
+               'n_gpus': world, 'world_size_observed': dist.get_world_size(), 'backend': dist.get_backend(),
+               'steps': a.steps, 'warmup': 0, 'ms_per_step': round(dt / max(a.steps, 1) * 1e3, 3), 'dry_run': True,
+               'gradients_averaged_correctly_on_every_rank': bool(flags.item()),
+               'd_arena_buckets': len(rep['bounds']), 'bucket_order_agreed': rep['agreed'],
+               'buckets_launched_inside_backward_per_reduction': launched}
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if bool(flags.item()) else 1
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and a.gpus > 1:
+        sys.exit(launch_ranks(a))                   # parent: no torch.cuda call before or after
+    world = int(env_world or '1')
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.gpus != world:
+        # never a silent single-rank (or wrong-size) run: the record's n_gpus must be what was asked for
+        print(f'bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}; start it as "python bench.py --gpus '
+              f'{a.gpus}" (it launches the ranks itself) or with --nproc-per-node {a.gpus}', file=sys.stderr)
+        sys.exit(2)
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 on the way
     # (RCCL prints a version banner there when its communicator is created, libraries print notices) goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if a.dry_run_dist:
+        sys.exit(dry_run_dist(a, json_fd))
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     a.world = world
     use_dist = world > 1 or os.environ.get('GANLAB_DIST_WORLD1') == '1'   # the knob: RCCL path on one rank
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        if torch.cuda.device_count() < world:
+            print(f'bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs are visible', file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world)
+        assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f'warning: --gpus {a.gpus} but WORLD_SIZE={world}', file=sys.stderr)
     from gan_lab_amd import _lib, ops as _ops
     _lib.lib()
     torch.manual_seed(1234 + rank)      # parameter init differs per rank on purpose: rank 0's values are broadcast
@@ -408,10 +591,19 @@ def main():
     with flops:
         wl.step()
     torch.cuda.synchronize()
+    exchange = None
     if use_dist:
         tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        red = getattr(wl.learner, 'reducer', None)
+        if red is not None and hasattr(wl.learner, 'arena_d'):
+            rd, rg = red.bucket_report(wl.learner.arena_d), red.bucket_report(wl.learner.arena_g)
+            exchange = {'backend': dist.get_backend(), 'bucket_mb': 32,
+                        'd_buckets': len(rd['bounds']) if rd else None, 'g_buckets': len(rg['bounds']) if rg else None,
+                        'd_launched_inside_backward': rd['launched_in_backward'] if rd else None,
+                        'g_launched_inside_backward': rg['launched_in_backward'] if rg else None,
+                        'order_agreed': bool(rd and rd['agreed'] and rg and rg['agreed'])}
     ld, lg = (float(ld) if ld is not None else None), (float(lg) if lg is not None else None)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
@@ -421,9 +613,15 @@ def main():
         exec_tflops = flops.total * a.steps / dt / 1e12      # this rank's executed conv FLOPs per second
         algo = ALGO_TFLOP_PER_IMAGE.get((a.model, a.res))
         name = {'stylegan': 'StyleGAN', 'progan': 'ProGAN', 'resnetgan': 'ResNetGAN'}[a.model]
+        metric = f'images/sec (G+D step), {name} {a.res}^2 bs{a.batch}/GPU'
+        if a.model == 'resnetgan':
+            # NOT the G+D-step definition of the other configurations: every critic iteration's real batch is counted
+            metric = (f'real images consumed/sec incl. {wl.nd} critic iters (main iteration = 1 G-iter + {wl.nd} '
+                      f'critic iters), {name} {a.res}^2 bs{a.batch}/GPU')
         out = {
-            'metric': f'images/sec (G+D step), {name} {a.res}^2 bs{a.batch}/GPU',
-            'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'metric': metric,
+            'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world,
+            'world_size_observed': dist.get_world_size() if use_dist else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': wl.what, 'baseline_config': a.config, 'global_batch': world * a.batch,
@@ -439,6 +637,8 @@ def main():
             'algorithmic_tflops_step': round(ips / world * algo, 2) if algo else None,
             'loss_d': ld, 'loss_g': lg, 'peak_mem_gib': round(peak_mem, 1),
         }
+        if exchange is not None:
+            out['gradient_exchange'] = exchange
         out.update(wl.extra)
     del wl
     torch.cuda.empty_cache()
@@ -463,15 +663,16 @@ def main():
             # <KS=3,MB=4,32x8>, the 64..512-channel stride-1 layers): its 256->256 @64^2 instance
             out['roofline_top_kernel_by_time'] = with_insitu(measure_dominant_kernel(torch, a.batch, 256, 64), insitu_top)
             torch.cuda.empty_cache()
-        if world == 1 and not a.no_cpu_baseline and a.model == 'stylegan':
-            out['cpu_baseline'] = cpu_baseline(torch, a.cpu_baseline_res or a.res, a.cpu_baseline_batch,
-                                               a.cpu_baseline_steps)
-        elif world == 1 and not a.no_cpu_baseline:
-            # configs 4 / 5: the oracle step of the headline network is the one CPU yardstick this file carries
-            out['cpu_baseline'] = None
-            out['cpu_baseline_note'] = 'timed for the StyleGAN configurations only (oracle/step.py FunctionalGAN)'
-        else:
-            out['cpu_baseline'] = None
+        out['cpu_baseline'] = None
+        if world == 1 and not a.no_cpu_baseline:
+            if a.model == 'stylegan':
+                out['cpu_baseline'] = cpu_baseline(torch, a.cpu_baseline_res or a.res, a.cpu_baseline_batch,
+                                                   a.cpu_baseline_steps)
+            elif a.model == 'progan':
+                out['cpu_baseline'] = cpu_baseline_progan(torch, a.cpu_baseline_res or a.res, max(a.cpu_baseline_batch, 4),
+                                                          a.cpu_baseline_steps)
+            else:
+                out['cpu_baseline'] = cpu_baseline_resnet(torch, a.res, min(a.batch, 16), a.cpu_baseline_steps)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_dist:

@@ -1539,7 +1539,12 @@ int ganlab_instnorm_style_fwd_f32(const float* x, const float* mean, const float
   if (!x || !mean || !rstd || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   // U = 2 float4 per thread measured best (tools/pw_probe.py: 5.8 vs 5.1 TB/s for the grid-stride form at 32x16x1024^2;
   // U = 4 equal, U = 8 5.4); GANLAB_PW_CHUNK=0 selects the grid-stride kernel (A/B)
-  static const int chunk_u = [] { const char* e = getenv("GANLAB_PW_CHUNK"); return e ? atoi(e) : 2; }();
+  // (the grid and the kernel's per-block span must agree: only U in {2, 4, 8} exists, anything else means 2)
+  static const int chunk_u = [] {
+    const char* e = getenv("GANLAB_PW_CHUNK");
+    const int v = e ? atoi(e) : 2;
+    return (v == 0 || v == 2 || v == 4 || v == 8) ? v : 2;
+  }();
   if (chunk_u > 0 && HW % (1024 * 8) == 0 && (long long)N * C * (HW / (1024 * chunk_u)) < 0x7fffffffLL) {
     const int chunks = (int)(HW / (1024 * chunk_u));
     const unsigned grid = (unsigned)((long long)N * C * chunks);

@@ -96,21 +96,24 @@ class Geom:
 
     def __new__(cls, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
         # a training step builds the same few dozen geometries again and again; each costs two ctypes structures and
-        # two library queries, so they are interned (instances are immutable after construction)
+        # two library queries, so they are interned (instances are immutable after construction).  An instance enters
+        # the cache only once its construction has SUCCEEDED: a rejected geometry raises on every attempt.
         key = (int(N), int(Cin), int(Hin), int(Win), int(Cout), int(ks), int(pad), int(bool(up)), int(bool(pool)),
                _COMPUTE[0])
         g = cls._CACHE.get(key)
         if g is None:
             g = object.__new__(cls)
             g._c = None
+            g._build(*key[:9])
             if len(cls._CACHE) > 4096:
                 cls._CACHE.clear()
             cls._CACHE[key] = g
         return g
 
     def __init__(self, N, Cin, Hin, Win, Cout, ks, pad, up=0, pool=0):
-        if self._c is not None:
-            return
+        pass            # built (and validated) in __new__
+
+    def _build(self, N, Cin, Hin, Win, Cout, ks, pad, up, pool):
         if ks not in (1, 3):
             raise ValueError('conv kernels support ks in {1, 3}; a 4x4 valid conv runs as a linear')
         self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool = \
@@ -119,7 +122,7 @@ class Geom:
         self.Ho, self.Wo = hv + 2 * pad - ks + 1, wv + 2 * pad - ks + 1
         if self.pool:
             self.Ho, self.Wo = self.Ho // 2, self.Wo // 2
-        self._c = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool)
+        cg = ConvGeom(self.N, self.Cin, self.Hin, self.Win, self.Cout, self.ks, self.pad, self.up, self.pool)
         # bf16 compute mode (decided HERE, so a backward that runs outside the `compute_dtype` block still uses the
         # kernels its forward used).  ``bf``: the plain geometry at the resolution of the taps (what the weight-gradient
         # kernels take, on a materialised upsample of x or of the pooled layer's gy); ``bf_fused``: this geometry with
@@ -129,14 +132,15 @@ class Geom:
             v = ConvGeom(self.N, self.Cin, hv, wv, self.Cout, self.ks, self.pad, 0, 0)
             if _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(v)):
                 self.bf = v
-                if (self.up or self.pool) and _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(self._c)):
-                    self.bf_fused = self._c
+                if (self.up or self.pool) and _lib.lib().ganlab_conv_bf16_supported(ctypes.byref(cg)):
+                    self.bf_fused = cg
                 elif self.pool:
                     self.bf = None
         self.s2 = bool(self.bf is None and (self.up or self.pool) and
-                       _lib.lib().ganlab_conv_s2_supported(ctypes.byref(self._c)))
+                       _lib.lib().ganlab_conv_s2_supported(ctypes.byref(cg)))
         if self.pool and not self.s2 and self.bf_fused is None:
             raise ValueError('pool=1 geometry is not supported by the stride-2 kernels; compose conv + pool')
+        self._c = cg
 
     def ref(self):
         return ctypes.byref(self._c)

@@ -122,6 +122,7 @@ class ProGANLearner(GANLearner):
     def _make_arenas(self, first=False, old_lagged=None):
         """Flat parameter / gradient arenas for G and D (+ the EWMA shadow of G)."""
         dev = self.config.dev
+        self.reducer.abandon()                   # hooks of the arenas this call replaces (growth / checkpoint load)
         self.arena_g = ParamArena(self.gen_model.named_parameters(), dev)
         self.arena_d = ParamArena(self.disc_model.named_parameters(), dev)
         # Replicas start from rank 0's values at construction AND after every growth event: the new blocks and the
@@ -234,9 +235,13 @@ class ProGANLearner(GANLearner):
                 loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
         if self.eps:
             loss = loss + bp.drift_loss(d_real, c.eps_drift)
+        # RCCL mean all-reduce of the flat gradient arena: each ~32 MiB bucket is launched from inside the backward sweep
+        # when its last gradient has landed (parallel.GradReducer), the rest by start(); the generator forward of the
+        # G step runs while they are in flight and _finish_d_update() waits
+        self.reducer.arm(self.arena_d)
         with ops.no_grad_towards(xr):          # d loss / d (real batch) is nobody's input: skip that kernel
             loss.backward()
-        self.reducer.start(self.arena_d.gflat)   # RCCL mean all-reduce, overlaps what follows
+        self.reducer.start(self.arena_d.gflat)
         if not defer_update:
             self._finish_d_update()
         return loss.detach()
@@ -256,8 +261,10 @@ class ProGANLearner(GANLearner):
         if d_update_pending:
             self._finish_d_update()
         loss = self.loss_func_gen(self.disc_model(fake))
+        self.reducer.arm(self.arena_g)           # buckets go out while the backward is still producing the others
         loss.backward()
-        self.reducer.allreduce(self.arena_g.gflat)
+        self.reducer.start(self.arena_g.gflat)
+        self.reducer.finish()                    # Adam needs the averaged gradients; the EWMA follows the update
         self.opt_gen.step()
         if c.use_ewma_gen:
             self.ewma.update(self.beta)
@@ -444,10 +451,13 @@ class ProGANLearner(GANLearner):
                 if (itr + 1) % c.num_iters_save_model == 0:
                     self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
         except KeyboardInterrupt:
-            # progan/learner.py:986-1013: Ctrl-C saves the latest checkpoint before the run ends
+            # progan/learner.py:986-1013: Ctrl-C saves the latest checkpoint before the run ends.  The signal reaches the
+            # ranks at different points of the step (one may already have its gradient all-reduce in flight), so NO
+            # collective runs here: pending reductions are dropped, rank 0 writes atomically, nobody waits at a barrier
             self.set_requires_grad_disc(True)
+            self.reducer.abandon()
             if not self.not_trained_yet:
-                self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+                self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'), sync=False)
                 if parallel.rank() == 0:
                     print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
             raise
@@ -653,13 +663,14 @@ class ProGANLearner(GANLearner):
         """Main iterations the live LambdaLR has stepped through (a fresh scheduler's ``_step_count`` is 1)."""
         return max(self.scheduler_gen._step_count - 1, 0) if (self.sched_bool and self.scheduler_gen is not None) else 0
 
-    def save_model(self, save_path, reference_format=False):
+    def save_model(self, save_path, reference_format=False, sync=True):
         """Checkpoint.  Default: this package's plain-data format (tensors + builtin types only; key names follow
         progan/learner.py:1257-1298).  ``reference_format=True``: the dict the reference's own ``save_model`` writes -
         same key set, ``config`` / ``lagged_params`` pickled under the reference's class names, torch-Adam optimiser
         state dicts, the ``nl`` / resampler modules - so the reference's ``load_model`` (:1305-1448) reads it
         (``checkpoint.reference_checkpoint_dict``).  Under data parallelism only rank 0 writes (replicas are identical),
-        through a temporary file + ``os.replace``; every rank waits for the file to be complete."""
+        through a temporary file + ``os.replace``; every rank waits for the file to be complete (``sync=False``: no
+        barrier - the interrupt path, where the ranks are not at the same point of the step)."""
         from .. import checkpoint as ckpt
         if self.not_trained_yet and reference_format:
             raise Exception('Please train your model for atleast 1 iteration before saving.')
@@ -670,7 +681,8 @@ class ProGANLearner(GANLearner):
                 ckpt.save_atomic(ck, save_path, foreign=True)
             else:
                 ckpt.save_atomic(self._plain_checkpoint_dict(), save_path)
-        parallel.barrier()
+        if sync:
+            parallel.barrier()
 
     def _plain_checkpoint_dict(self):
         cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}  # noqa: E731
@@ -705,6 +717,9 @@ class ProGANLearner(GANLearner):
             'valid_z': tcpu(self.valid_z), 'valid_label': tcpu(self.valid_label), 'rand_idxs': tcpu(self.rand_idxs),
             'grid_inputs_constructed': self.grid_inputs_constructed,
             'gen_metrics_num': self.gen_metrics_num, 'disc_metrics_num': self.disc_metrics_num,
+            # device Philox stream (latents, per-layer noise): a resumed run continues the sequence instead of replaying
+            # the start of the original one
+            'rng_state': dict(rng._STATE),
         }
         ck.update({k: (tcpu(v) if torch.is_tensor(v) else v) for k, v in self._extra_checkpoint_fields().items()})
         return ck
@@ -785,3 +800,10 @@ class ProGANLearner(GANLearner):
         self.scheduler_gen = self.scheduler_disc = None
         self.train_dataiter = None
         self.pretrained_model = True
+        st = ck.get('rng_state')
+        if st is not None:
+            # the learner owns the device stream: the saved offset always resumes; the seed is rank 0's, so it is only
+            # taken over by a single process (data-parallel ranks keep their own rank-mixed seed of this construction)
+            rng._STATE['offset'] = int(st['offset'])
+            if parallel.world_size() == 1:
+                rng._STATE['seed'] = int(st['seed'])

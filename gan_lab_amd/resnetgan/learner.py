@@ -195,6 +195,7 @@ class GANLearner(object):
         out = self.disc_model(self.gen_model(zb))
         # :573-578 - the minimax generator loss here is -BCE(D(G(z)), 0), like backprop_utils
         loss = self.loss_func_gen(out)
+        self.reducer.arm(self.arena_g)
         loss.backward()
         self.reducer.allreduce(self.arena_g.gflat)
         self.opt_gen.step()
@@ -213,6 +214,7 @@ class GANLearner(object):
         loss = self.loss_func_disc(self.disc_model(xgenb), self.disc_model(xb))
         if self.gradient_penalty is not None:
             loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
+        self.reducer.arm(self.arena_d)
         loss.backward()
         self.reducer.allreduce(self.arena_d.gflat)
         self.opt_disc.step()
@@ -280,14 +282,16 @@ class GANLearner(object):
         except KeyboardInterrupt:
             # resnetgan/learner.py: Ctrl-C saves the latest checkpoint before the run ends
             self.set_requires_grad_disc(True)
+            self.reducer.abandon()          # no collective in the interrupt path (ranks are at different points)
             if not self.not_trained_yet:
-                self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'))
+                self.save_model(c.save_model_dir / (self.model.casefold().replace(' ', '') + '_model.tar'), sync=False)
                 if parallel.rank() == 0:
                     print(f'\nTraining interrupted. Saved latest checkpoint into "{c.save_model_dir}/".\n')
             raise
 
-    def save_model(self, save_path):
-        """Checkpoint as plain data (key names follow resnetgan/learner.py:1076-1140)."""
+    def save_model(self, save_path, sync=True):
+        """Checkpoint as plain data (key names follow resnetgan/learner.py:1076-1140).  ``sync=False``: no barrier
+        behind rank 0's write (the interrupt path)."""
         if self.not_trained_yet:
             raise Exception('Please train your model for atleast 1 iteration before saving.')
         from .. import checkpoint as ckpt
@@ -310,7 +314,8 @@ class GANLearner(object):
         }
         if parallel.rank() == 0:            # replicas are identical: one writer, atomically; everyone waits for the file
             ckpt.save_atomic(ck, save_path)
-        parallel.barrier()
+        if sync:
+            parallel.barrier()
 
     def load_model(self, load_path, dev_of_saved_model='cpu'):
         from .. import checkpoint as ckpt

