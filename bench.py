@@ -178,6 +178,30 @@ class Workload(object):
 # ------------------------------------------------------------------------------------------------------------------
 # roofline of the dominant kernel
 # ------------------------------------------------------------------------------------------------------------------
+# the per-kernel HBM traffic table under profiles/ comes from the default command (config 3) resp. --config 2: only the
+# instance that kernel symbol ran THERE is priced with it
+NORTHSTAR_OF_TRAFFIC_TABLE = {False: (16, 1024, 32)}
+
+
+def kernel_traffic(symbol):
+    """HBM bytes per launch of ``symbol`` from the newest tracked per-kernel traffic table (tools/step_traffic.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the bench command, gfx950 corrections applied) -
+    (bytes, source file), or None.  Measured by the profiler, not inside this run: the source is named."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_step_traffic.json')))
+    if not files or not symbol:
+        return None
+    short = re.sub(r'\(.*$', '', re.sub(r'^void ', '', symbol).replace('(anonymous namespace)::', ''))[:70]
+    try:
+        rec = json.load(open(files[-1]))['kernels'].get(short)
+    except (OSError, ValueError, KeyError):
+        return None
+    if not rec:
+        return None
+    return round(rec['read_bytes_per_launch'] + rec['written_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
+
+
 def measure_dominant_kernel(torch, batch, c, res, reps=5):
     """Average launch duration of one 3x3 conv instance in an isolated loop (device events on the launch stream) and
     the symbol / grid the library dispatched for it."""
@@ -203,12 +227,9 @@ def measure_dominant_kernel(torch, batch, c, res, reps=5):
     out = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
            'traffic': None, 'kernel': kernel, 'grid': grid, 'instance': f'3x3 {c}->{c} @{res}^2 x{batch}',
            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
-    if (c, res, batch, bf) == (16, 1024, 32, False):
-        # HBM bytes per launch of THIS kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # separate passes): 2.55e9 read (1.19x the algorithmic 2 GiB: column halo + strip-boundary rows) + 2.17e9
-        # written.  Not re-measured inside this run - the source file is named.
-        out['traffic'] = 4.722e9
-        out['traffic_source'] = 'profiles/r01g_northstar_conv_pmc.csv'
+    t = kernel_traffic(kernel)
+    if t is not None and (c, res, batch) == NORTHSTAR_OF_TRAFFIC_TABLE.get(bf):
+        out['traffic'], out['traffic_source'] = t
     return out
 
 

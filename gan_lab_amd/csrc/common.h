@@ -58,6 +58,17 @@ __device__ __forceinline__ float gl_block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// fp64 variant (`red` = 4 doubles): long per-channel sums - bias / noise-weight gradients are sums over N*H*W terms that
+// largely cancel - keep their partials in double from the thread accumulator to the fixed-order finish
+__device__ __forceinline__ double gl_block_sum_256d(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // ---- wgrad_roll.hip: rolling-window weight gradient of the thin 3x3 layers (used by ganlab_conv_wgrad_f32) ----------
@@ -70,3 +81,8 @@ bool gl_wgrad_s2_roll_supported(int N, int Cl, int Ch, int Hl, int Wl, const voi
 int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl);
 int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, int N, int Cl, int Ch, int Hl, int Wl,
                             hipStream_t st);
+
+// ---- conv_s2_roll.hip: rolling-window S / T kernels of the thin (16 <-> 32 channel) stride-2 fused layers ----------------
+bool gl_s2_roll_supported(int is_T, int N, int Cin, int Cout, int Hl, int Wl, const void* x, const void* y);
+int gl_s2_roll_launch(int is_T, const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Cout,
+                      int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st);

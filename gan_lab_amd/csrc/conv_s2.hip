@@ -681,6 +681,11 @@ int launch_s2(K kernel, S2Args a, hipStream_t st) {
 }
 
 int run_S(S2Args a, hipStream_t st) {
+  // the thin top-resolution pair (16 high-resolution channels -> 32 low-resolution ones) on 32-aligned planes: the
+  // rolling-window kernel (conv_s2_roll.hip); GANLAB_S2_ROLL=0 keeps the tile kernel (same-box A/B measurements)
+  if (gl_s2_roll_supported(0, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.x, a.y))
+    return gl_s2_roll_launch(0, a.x, a.wp, a.bias, a.y, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.Cin_p, a.Cout_p, a.bias_scale,
+                             a.act, a.slope, st);
   if (a.Wl <= 16 && a.Cout > 32) return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
   if (a.Cout <= 16) return launch_s2<SCfg<1>>(conv_s2_down_kernel<SCfg<1>>, a, st);
   if (a.Cout <= 32) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
@@ -688,6 +693,9 @@ int run_S(S2Args a, hipStream_t st) {
 }
 
 int run_T(S2Args a, hipStream_t st) {
+  if (gl_s2_roll_supported(1, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.x, a.y))
+    return gl_s2_roll_launch(1, a.x, a.wp, a.bias, a.y, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.Cin_p, a.Cout_p, a.bias_scale,
+                             a.act, a.slope, st);
   if (a.Cout <= 16) return launch_s2<TCfg<1, 4>>(conv_s2_up_kernel<TCfg<1, 4>>, a, st);
   if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
   // 32 output channels per workgroup for the thick layers as well: the 64-channel tile keeps 128 accumulator registers

@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
                                                          const float* __restrict__ noise,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ noise_w, float* __restrict__ out,
-                                                         float* __restrict__ part, int N, int C, int H, int W,
+                                                         double* __restrict__ part, int N, int C, int H, int W,
                                                          int chunks, float bias_scale, int act, float slope,
                                                          int want_sums, double* __restrict__ spart = nullptr) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   __shared__ double dred[2][4];
   const int c = blockIdx.y, chunk = blockIdx.x;
   const int w4 = W >> 2, hr = H / R;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
   double ds = 0.0, dss = 0.0;
   const float b = (MODE == BF_FWD && bias) ? bias[c] * bias_scale : 0.f;
   const float nw = (MODE == BF_FWD && noise) ? noise_w[c] : 0.f;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;        // bias / noise-weight gradient partials in fp64
   for (long long base = chunk * 256LL; base < total; base += (long long)chunks * 256) {
     const long long i = base + threadIdx.x;
     const bool live = i < total;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           o[j] = m[j] > 0.f ? o[j] : o[j] * slope;
-          s0 += o[j];
+          s0 += (double)o[j];
         }
       } else {
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
           *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(noise + n * HW + co + k * W);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          s0 += cen[k + 1][j];
-          s1 += cen[k + 1][j] * nz[j];
+          s0 += (double)cen[k + 1][j];
+          s1 += (double)cen[k + 1][j] * nz[j];
         }
       }
       *reinterpret_cast<float4*>(out + plane + co + (long long)k * W) = *reinterpret_cast<float4*>(o);
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
     }
   }
   if (MODE != BF_FWD && want_sums) {
-    s0 = gl_block_sum_256(s0, red);
+    s0 = gl_block_sum_256d(s0, red);
     if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s0;
     if (MODE == BF_AT) {
       __syncthreads();
-      s1 = gl_block_sum_256(s1, red);
+      s1 = gl_block_sum_256d(s1, red);
       if (threadIdx.x == 0) part[((long long)C + c) * chunks + chunk] = s1;
     }
   }
@@ -483,12 +483,12 @@ __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __rest
 // stage 1: grid (chunks, C); stage 2: one wave per channel
 // ---------------------------------------------------------------------------------------------- //
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ a, const float* __restrict__ b,
-                                                          float* __restrict__ part, int N, int C, long long HW,
+                                                          double* __restrict__ part, int N, int C, long long HW,
                                                           int chunks) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   const int c = blockIdx.y, chunk = blockIdx.x;
   const long long total = (long long)N * HW;
-  float s = 0.f;
+  double s = 0.0;       // fp64 from the first addition on: these sums run over 1e5..1e7 terms that mostly cancel
   if ((HW & 3) == 0 && (total >> 2) < 0x7fffffffLL) {
     // 16-byte loads and 32-bit index arithmetic (the scalar form with a 64-bit division per element ran at 2.8 TB/s)
     const unsigned hw4 = (unsigned)(HW >> 2), total4 = (unsigned)(total >> 2);
@@ -499,39 +499,40 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
       const float4 v = a4[((long long)n * C + c) * hw4 + q];
       if (b) {
         const float4 w = b4[i];
-        s += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+        s += ((double)v.x * w.x + (double)v.y * w.y) + ((double)v.z * w.z + (double)v.w * w.w);
       } else {
-        s += (v.x + v.y) + (v.z + v.w);
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
       }
     }
   } else {
     for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
       const long long n = i / HW, hw = i - n * HW;
       const float v = a[(n * C + c) * HW + hw];
-      s += b ? v * b[i] : v;
+      s += b ? (double)v * b[i] : (double)v;
     }
   }
-  s = gl_block_sum_256(s, red);
+  s = gl_block_sum_256d(s, red);
   if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s;
 }
 
-__global__ void channel_sum_stage2(const float* __restrict__ part, float* __restrict__ out, int C, int chunks,
+__global__ void channel_sum_stage2(const double* __restrict__ part, float* __restrict__ out, int C, int chunks,
                                    float scale) {
   const int c = blockIdx.x;
-  float s = 0.f;
+  double s = 0.0;
   for (int i = threadIdx.x; i < chunks; i += 64) s += part[(long long)c * chunks + i];
-  s = gl_wave_sum(s);
-  if (threadIdx.x == 0) out[c] = s * scale;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[c] = (float)(s * (double)scale);
 }
 
 // gz = gy * lrelu'(y) AND the per-channel sums of gz (bias gradient) in one pass:
 // grid (chunks, C); partial sums go to part[c][chunk], channel_sum_stage2 finishes them.
 __global__ __launch_bounds__(256) void act_bwd_bias_stage1(const float* __restrict__ gy, const float* __restrict__ y,
-                                                           float* __restrict__ gz, float* __restrict__ part, int N,
+                                                           float* __restrict__ gz, double* __restrict__ part, int N,
                                                            int C, long long HW, int chunks, float slope) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   const int c = blockIdx.y, chunk = blockIdx.x;
-  float s = 0.f;
+  double s = 0.0;
   if ((HW & 3) == 0) {
     const long long hw4 = HW >> 2, total = (long long)N * hw4;
     for (long long i = chunk * 256LL + threadIdx.x; i < total; i += (long long)chunks * 256) {
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_stage1(const float* __restri
       r.z = o.z > 0.f ? g.z : g.z * slope;
       r.w = o.w > 0.f ? g.w : g.w * slope;
       reinterpret_cast<float4*>(gz)[off] = r;
-      s += (r.x + r.y) + (r.z + r.w);
+      s += ((double)r.x + (double)r.y) + ((double)r.z + (double)r.w);
     }
   } else {
     const long long total = (long long)N * HW;
@@ -554,10 +555,10 @@ __global__ __launch_bounds__(256) void act_bwd_bias_stage1(const float* __restri
       const long long off = (n * C + c) * HW + hw;
       const float r = y[off] > 0.f ? gy[off] : gy[off] * slope;
       gz[off] = r;
-      s += r;
+      s += (double)r;
     }
   }
-  s = gl_block_sum_256(s, red);
+  s = gl_block_sum_256d(s, red);
   if (threadIdx.x == 0) part[(long long)c * chunks + chunk] = s;
 }
 
@@ -699,13 +700,14 @@ __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* _
       for (long long i = t; i < (HW >> 2); i += T) {
         const float4 g = reinterpret_cast<const float4*>(pg)[i];
         const float4 v = reinterpret_cast<const float4*>(px)[i];
-        a += (g.x + g.y) + (g.z + g.w);
-        b += (g.x * ((v.x - m) * r) + g.y * ((v.y - m) * r)) + (g.z * ((v.z - m) * r) + g.w * ((v.w - m) * r));
+        a += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+        b += ((double)g.x * ((v.x - m) * r) + (double)g.y * ((v.y - m) * r)) +
+             ((double)g.z * ((v.z - m) * r) + (double)g.w * ((v.w - m) * r));
       }
     } else {
       for (long long i = t; i < HW; i += T) {
-        a += pg[i];
-        b += pg[i] * ((px[i] - m) * r);
+        a += (double)pg[i];
+        b += (double)pg[i] * ((px[i] - m) * r);
       }
     }
   }
@@ -766,9 +768,9 @@ __global__ void instnorm_bwd_apply_kernel(const float* __restrict__ gy, const fl
 __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ style, const float* __restrict__ s1,
-    const float* __restrict__ s2, const float* __restrict__ noise, float* __restrict__ gz, float* __restrict__ part,
+    const float* __restrict__ s2, const float* __restrict__ noise, float* __restrict__ gz, double* __restrict__ part,
     int N, int C, long long hw4, int chunks, int act, float slope, int want_b, int want_nw, int contig) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   const long long pl = blockIdx.y;
   const int c = (int)(pl % C);
   const long long n = pl / C;
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
   const float4* px = reinterpret_cast<const float4*>(x) + pl * hw4;
   const float4* pn = (want_nw && noise) ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
   float4* po = reinterpret_cast<float4*>(gz) + pl * hw4;
-  float sb = 0.f, snw = 0.f;
+  double sb = 0.0, snw = 0.0;      // bias / noise-weight gradients: fp64 partials (see gl_block_sum_256d)
   const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
   for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
     float g[4], v[4], o[4];
@@ -793,20 +795,20 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
       o[j] = t;
     }
     po[i] = *reinterpret_cast<float4*>(o);
-    sb += (o[0] + o[1]) + (o[2] + o[3]);
+    sb += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
     if (pn) {
       const float4 z = pn[i];
-      snw += (o[0] * z.x + o[1] * z.y) + (o[2] * z.z + o[3] * z.w);
+      snw += ((double)o[0] * z.x + (double)o[1] * z.y) + ((double)o[2] * z.z + (double)o[3] * z.w);
     }
   }
   const long long slot = ((long long)c * N + n) * chunks + blockIdx.x;
   if (want_b) {
-    sb = gl_block_sum_256(sb, red);
+    sb = gl_block_sum_256d(sb, red);
     if (threadIdx.x == 0) part[slot] = sb;
   }
   if (want_nw) {
     if (want_b) __syncthreads();
-    snw = gl_block_sum_256(snw, red);
+    snw = gl_block_sum_256d(snw, red);
     if (threadIdx.x == 0) part[(long long)C * N * chunks + slot] = snw;
   }
 }
@@ -1348,17 +1350,17 @@ int ganlab_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, 
 }
 
 size_t ganlab_channel_sum_workspace(int N, int C, long long HW) {
-  return (size_t)C * channel_chunks(N, HW) * sizeof(float);
+  return (size_t)C * channel_chunks(N, HW) * sizeof(double);
 }
 
 int ganlab_channel_sum_f32(const float* a, const float* b, float* out, int N, int C, long long HW, float scale,
                            void* workspace, size_t workspace_bytes, void* stream) {
   if (!a || !out || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const int chunks = channel_chunks(N, HW);
-  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return GANLAB_EWORKSPACE;
-  GL_LAUNCH(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (float*)workspace, N, C, HW,
+  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(double)) return GANLAB_EWORKSPACE;
+  GL_LAUNCH(channel_sum_stage1, dim3(chunks, C), dim3(256), 0, ST, a, b, (double*)workspace, N, C, HW,
                      chunks);
-  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, out, C, chunks, scale);
+  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, out, C, chunks, scale);
   return GL_CHECK_LAUNCH();
 }
 
@@ -1366,10 +1368,10 @@ int ganlab_act_bwd_bias_f32(const float* gy, const float* y, float* gz, float* g
                             float slope, float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (!gy || !y || !gz || !gb || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const int chunks = channel_chunks(N, HW);
-  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return GANLAB_EWORKSPACE;
-  GL_LAUNCH(act_bwd_bias_stage1, dim3(chunks, C), dim3(256), 0, ST, gy, y, gz, (float*)workspace, N, C, HW, chunks,
+  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(double)) return GANLAB_EWORKSPACE;
+  GL_LAUNCH(act_bwd_bias_stage1, dim3(chunks, C), dim3(256), 0, ST, gy, y, gz, (double*)workspace, N, C, HW, chunks,
             slope);
-  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, scale);
+  GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, scale);
   return GL_CHECK_LAUNCH();
 }
 
@@ -1377,7 +1379,7 @@ int ganlab_blur_fused_supported(int H, int W) { return (H >= 2 && W >= 4 && (H &
 
 size_t ganlab_blur_fused_workspace(int N, int C, int H, int W) {
   if (!ganlab_blur_fused_supported(H, W)) return 0;
-  return (size_t)2 * C * blur_fused_chunks(N, H, W) * sizeof(float);
+  return (size_t)2 * C * blur_fused_chunks(N, H, W) * sizeof(double);
 }
 
 int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
@@ -1385,7 +1387,7 @@ int ganlab_blur_bias_act_f32(const float* x, const float* bias, const float* noi
   if (!x || !y || N <= 0 || C <= 0 || (noise && !noise_w)) return GANLAB_EINVAL;
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
-  BLUR_FUSED_LAUNCH(BF_FWD, x, (const float*)nullptr, noise, bias, noise_w, y, (float*)nullptr, N, C, H, W, chunks,
+  BLUR_FUSED_LAUNCH(BF_FWD, x, (const float*)nullptr, noise, bias, noise_w, y, (double*)nullptr, N, C, H, W, chunks,
                     bias_scale, act, slope, 0);
   return GL_CHECK_LAUNCH();
 }
@@ -1397,7 +1399,7 @@ size_t ganlab_act_stats_workspace(int N, int C, long long HW) {
 
 size_t ganlab_instnorm_bwd_act_workspace(int N, int C, long long HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
-  return (size_t)2 * N * C * 64 * sizeof(float);
+  return (size_t)2 * N * C * 64 * sizeof(double);
 }
 
 /* backward of  out = InstanceNorm(x)*(ys+1)+yb  with  x = lrelu(z + noise_w*noise + bias*bias_scale):
@@ -1415,12 +1417,12 @@ int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const flo
     return GANLAB_EWORKSPACE;
   const long long hw4 = HW / 4, planes = (long long)N * C;
   const int chunks = act_stats_chunks(hw4);
-  float* part = reinterpret_cast<float*>(workspace);
+  double* part = reinterpret_cast<double*>(workspace);
   GL_LAUNCH(instnorm_bwd_apply_act_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, gy, x, mean,
             rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
-  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part, gb, C, N * chunks, bias_scale);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part, gb, C, N * chunks, bias_scale);
   if (gnw)
-    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)part + (size_t)C * N * chunks, gnw, C,
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part + (size_t)C * N * chunks, gnw, C,
               N * chunks, 1.f);
   return GL_CHECK_LAUNCH();
 }
@@ -1459,13 +1461,13 @@ int ganlab_blur_bias_act_stats_f32(const float* x, const float* bias, const floa
   const dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)N);
   if (rows == 8)
     GL_LAUNCH((blur_fused_kernel<BF_FWD, 8, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
-              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+              noise_w, y, (double*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
   else if (rows == 4)
     GL_LAUNCH((blur_fused_kernel<BF_FWD, 4, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
-              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+              noise_w, y, (double*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
   else
     GL_LAUNCH((blur_fused_kernel<BF_FWD, 2, true>), grid, dim3(256), 0, ST, x, (const float*)nullptr, noise, bias,
-              noise_w, y, (float*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
+              noise_w, y, (double*)nullptr, N, C, H, W, chunks, bias_scale, act, slope, 0, sp);
   const long long planes = (long long)N * C;
   GL_LAUNCH(act_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, ST, (const double*)sp, mean,
             rstd, planes, chunks, 1.0 / ((double)H * W), eps);
@@ -1477,10 +1479,10 @@ int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* g
   if (!g || !y || !out || N <= 0 || C <= 0) return GANLAB_EINVAL;
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
-  if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
+  if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(double))) return GANLAB_EWORKSPACE;
   BLUR_FUSED_LAUNCH(BF_A, g, y, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
-                    (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, gb ? 1 : 0);
-  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
+                    (double*)workspace, N, C, H, W, chunks, 1.f, 0, slope, gb ? 1 : 0);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, bias_scale);
   return GL_CHECK_LAUNCH();
 }
 
@@ -1491,12 +1493,12 @@ int ganlab_act_bwd_blur_f32(const float* g, const float* y, const float* noise, 
   if (!ganlab_blur_fused_supported(H, W)) return GANLAB_EUNSUPPORTED;
   const int chunks = blur_fused_chunks(N, H, W);
   const int sums = (gb || gnw) ? 1 : 0;
-  if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(float))) return GANLAB_EWORKSPACE;
+  if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(double))) return GANLAB_EWORKSPACE;
   BLUR_FUSED_LAUNCH(BF_AT, g, y, gnw ? noise : (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
-                    (float*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
-  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace, gb, C, chunks, bias_scale);
+                    (double*)workspace, N, C, H, W, chunks, 1.f, 0, slope, sums);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, bias_scale);
   if (gnw)
-    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const float*)workspace + (size_t)C * chunks, gnw, C,
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace + (size_t)C * chunks, gnw, C,
               chunks, 1.f);
   return GL_CHECK_LAUNCH();
 }

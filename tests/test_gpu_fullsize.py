@@ -13,8 +13,9 @@ Rule for the gradients (fp32 networks): an entry passes at 1e-3 relative (max-ab
 tensor's own max or 1e-3 of the network's largest gradient, whichever is larger).  Entries the fp32 CPU oracle and
 the HIP path disagree on by more than that sit behind ~40 layers with normalisation gains in between, where two
 correct fp32 implementations differ by rounding alone; those are judged against the SAME oracle evaluated in
-float64: the HIP result must be as close to the exact answer as the CPU fp32 path is (no extra noise factor:
-``e_hip <= max(1e-3, 1.5 * e_cpu, worst CPU entry)``).  One documented fp32 effect is recognised by its signature
+float64: the HIP result must be as close to the exact answer as the CPU fp32 path is, ENTRY BY ENTRY (no extra noise
+factor, nothing borrowed from another layer: ``e_hip <= max(1e-3, 1.5 * e_cpu)``; round 2 also admitted the worst CPU
+entry of the whole network - the bias / noise-weight / InstanceNorm-backward sums now keep fp64 partials instead).  One documented fp32 effect is recognised by its signature
 and reported rather than failed: a LeakyReLU mask bit that flips on an activation within one rounding of zero
 (``_without_tie_channels``) - the excess error must then sit in at most two output channels of that one layer's
 weight / bias gradient, with every other channel inside the bar.
@@ -183,9 +184,8 @@ def _judge_outliers(tag, bad, hip, cpu, exact, gmax64):
         e_hip = (hip[k].double() - ex).abs().max().item() / scale
         e_cpu = (cpu[k].double() - ex).abs().max().item() / scale
         judged[k] = (e_hip, e_cpu)
-    cpu_worst = max(e for _, e in judged.values())
     for k, (e_hip, e_cpu) in judged.items():
-        bar = max(TOL, 1.5 * e_cpu, cpu_worst)
+        bar = max(TOL, 1.5 * e_cpu)        # per entry: no allowance borrowed from another layer's CPU error
         if e_hip > bar:
             scale = max(exact[k].abs().max().item(), 1e-3 * gmax64)
             e_rest, dropped = _without_tie_channels(k, hip[k], exact[k], scale)
@@ -194,6 +194,18 @@ def _judge_outliers(tag, bad, hip, cpu, exact, gmax64):
             else:
                 still[tag + k] = (e_hip, e_cpu)
     return still, judged, ties
+
+
+def _layer_of(key):
+    """'g.gen_layers.10.1.noise_weight' -> 'g.gen_layers.10'; 'd.disc_blocks.3.0.0.conv2d.weight' -> 'd.disc_blocks.3'."""
+    parts = key.split('.')
+    return '.'.join(parts[:3]) if len(parts) > 3 and parts[2].isdigit() else '.'.join(parts[:2])
+
+
+def _assert_ties_in_one_layer(rep):
+    """The LeakyReLU tie exemption is a REPORT of one flipped mask bit; two layers showing it at once is not that."""
+    layers = {_layer_of(k) for k in rep.get('lrelu_tie_channels', {})}
+    assert len(layers) <= 1, rep['lrelu_tie_channels']
 
 
 CASES = [('stylegan', 1024, 4, 'nonsaturating', 'r1'), ('progan', 256, 4, 'wgan', 'wgan-gp')]
@@ -245,6 +257,7 @@ def test_full_width_step_vs_oracle(kind, res, b, loss, gp, capsys):
         assert rep[k] <= TOL, (k, rep)
     assert not still, still
     assert len(ed) >= 20 and len(eg) >= 20
+    _assert_ties_in_one_layer(rep)
 
 
 def test_stylegan128_bf16_b8_step_vs_oracle(capsys):
@@ -279,3 +292,132 @@ def test_stylegan128_bf16_b8_step_vs_oracle(capsys):
         print('\nbf16 StyleGAN-128 b8 step vs fp32 oracle:', rep)
     assert rep['img'] < 2e-2 and rep['loss_d'] < 1e-2 and rep['loss_g'] < 1e-2 and rep['gp'] < 2e-2, rep
     assert worst[0] > 0.98, rep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the code path bench.py times: the LEARNER's d_step / g_step at full width, two minibatch-stddev groups
+# ---------------------------------------------------------------------------------------------------------------
+def test_learner_step_full_width_b8_vs_oracle(capsys):
+    """``ProGANLearner.d_step(defer_update=True)`` + ``g_step(d_update_pending=True)`` - flat arenas, FusedAdam,
+    ``no_grad_towards``, the shared D(real) forward, the deferred D update, train-mode generator with mixing
+    regularisation, EWMA - on the full-width StyleGAN-128 at batch 8 (TWO minibatch-stddev groups), fp32, against
+    ``oracle/step.py FunctionalGAN`` (gan_lab/progan/learner.py:734-943) driven with the same latents, noise (injected
+    through ``honour_noise_in_training``), mixing cut and real batch: losses, every gradient in both arenas (per-entry
+    float64 rule of this file), the Adam update of every parameter and the EWMA shadow."""
+    from gan_lab_amd import ops
+    from gan_lab_amd.config import make_config
+    from gan_lab_amd.stylegan.architectures import StyleAddNoise
+    from gan_lab_amd.stylegan.learner import StyleGANLearner
+    from oracle import nets, step
+    res, b, lr = 128, 8, 1e-3
+    torch.manual_seed(31)
+    cfg = make_config('stylegan', dev='cuda', pin_memory=False, res_samples=res, res_dataset=res, init_res=res,
+                      batch_size=b, bs_dict={r: b for r in (4, 8, 16, 32, 64, 128)}, loss='nonsaturating',
+                      gradient_penalty='r1', lda=10., num_iters_save_model=10 ** 9, log_every=0, random_seed=5,
+                      cutoff_trunc_trick=4, lr_base=lr)
+    L = StyleGANLearner(cfg)
+    with torch.no_grad():
+        for k, p in list(L.gen_model.named_parameters()) + list(L.disc_model.named_parameters()):
+            if k.endswith('bias') or k.endswith('noise_weight'):
+                p.normal_(0, 0.3)
+            elif k == 'const_input':
+                p.normal_(1.0, 0.5)
+    L.ewma.flat.copy_(L.arena_g.flat)
+    L.beta = L.get_smoothing_ewma_beta(half_life=10.)
+    L.gen_model.train()
+    L.disc_model.train()
+    assert L.arena_g.is_attached() and L.arena_d.is_attached()
+    sd_g = {k: v.detach().cpu().clone() for k, v in L.gen_model.state_dict().items()}
+    sd_d = {k: v.detach().cpu().clone() for k, v in L.disc_model.state_dict().items()}
+    gen = torch.Generator().manual_seed(99)
+    nl = len(L.gen_model.gen_layers)
+    shapes = [(b, 1, 4 * 2 ** (n // 2), 4 * 2 ** (n // 2)) for n in range(nl)]
+    zd, zg = torch.randn(b, 512, generator=gen), torch.randn(b, 512, generator=gen)
+    zmix_d, zmix_g = torch.randn(b, 512, generator=gen), torch.randn(b, 512, generator=gen)
+    nd = [torch.randn(*s, generator=gen) for s in shapes]
+    ng = [torch.randn(*s, generator=gen) for s in shapes]
+    real = torch.rand(b, 3, res, res, generator=gen) * 2 - 1
+    cut_d, cut_g = 5, 9
+
+    lr_factor = cfg.lr_fctr_dict[res]            # LambdaLR 'resolution dependent' (StyleGAN: 1.5 at 128)
+    for grp in L.opt_gen.param_groups + L.opt_disc.param_groups:
+        grp['lr'] = lr * lr_factor
+    StyleAddNoise.honour_noise_in_training = True
+    try:
+        L.set_requires_grad_disc(True)
+        ld = L.d_step(real.cuda(), zb=zd.cuda(), defer_update=True,
+                      gen_kwargs=dict(noise=[n.cuda() for n in nd], _mix=(cut_d, zmix_d.cuda())))
+        gd = {k: v.detach().cpu().clone() for k, v in L.arena_d.views_of(L.arena_d.gflat).items()}
+        L.set_requires_grad_disc(False)
+        lg = L.g_step(zb=zg.cuda(), d_update_pending=True,
+                      gen_kwargs=dict(noise=[n.cuda() for n in ng], _mix=(cut_g, zmix_g.cuda())))
+        gg = {k: v.detach().cpu().clone() for k, v in L.arena_g.views_of(L.arena_g.gflat).items()}
+    finally:
+        StyleAddNoise.honour_noise_in_training = False
+    torch.cuda.synchronize()
+    new_g = {k: v.detach().cpu() for k, v in L.gen_model.state_dict().items()}
+    new_d = {k: v.detach().cpu() for k, v in L.disc_model.state_dict().items()}
+    lag = {k: v.detach().cpu() for k, v in L.lagged_params.items()}
+
+    def oracle(dt):
+        gan = step.FunctionalGAN({k: v.to(dt) for k, v in sd_g.items()}, {k: v.to(dt) for k, v in sd_d.items()},
+                                 nets.make_cfg(), model='stylegan', loss='nonsaturating', gp='r1', lda=10.,
+                                 eps_drift=.001, lr=lr)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            o_ld, _ = gan.d_step(zd.to(dt), real.to(dt), [n.to(dt) for n in nd], lr_factor=lr_factor, cutoff_idx=cut_d,
+                                 z_mix=zmix_d.to(dt))
+            o_gd = {k: v.grad.detach().clone() for k, v in gan.d.items() if v.grad is not None}
+            o_lg = gan.g_step(zg.to(dt), [n.to(dt) for n in ng], lr_factor=lr_factor, beta=L.beta, cutoff_idx=cut_g,
+                              z_mix=zmix_g.to(dt))
+        finally:
+            torch.set_default_dtype(old)
+        o_gg = {k: v.grad.detach().clone() for k, v in gan.g.items() if v.grad is not None}
+        return dict(ld=o_ld, lg=o_lg, gd=o_gd, gg=o_gg, g={k: v.detach() for k, v in gan.g.items()},
+                    d={k: v.detach() for k, v in gan.d.items()}, lag=gan.lagged)
+
+    cpu = oracle(torch.float32)
+    rep = dict(loss_d=rel_err(ld, cpu['ld']), loss_g=rel_err(lg, cpu['lg']))
+    ed, _ = _grad_errors(gd, cpu['gd'])
+    eg, _ = _grad_errors(gg, cpu['gg'])
+    rep['worst_d_grad'] = max(ed.items(), key=lambda kv: kv[1])
+    rep['worst_g_grad'] = max(eg.items(), key=lambda kv: kv[1])
+    bad_d, bad_g = [k for k, v in ed.items() if v > TOL], [k for k, v in eg.items() if v > TOL]
+    still = {}
+    ex = None
+    if bad_d or bad_g:
+        ex = oracle(torch.float64)
+        for tag, bad, hg, cg, xg in (('d.', bad_d, gd, cpu['gd'], ex['gd']), ('g.', bad_g, gg, cpu['gg'], ex['gg'])):
+            if bad:
+                s, j, ties = _judge_outliers(tag, bad, hg, cg, xg, max(v.abs().max().item() for v in xg.values()))
+                still.update(s)
+                rep.setdefault('lrelu_tie_channels', {}).update(ties)
+                rep['judged_' + tag[0]] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
+    # Adam (beta1 = 0) normalises the step to ~lr * sign(g): where |g| is significant the update must agree to 2 % of
+    # the step size; prev_torgb / prev_fromrgb are outside the optimiser in the stabilised phase and must not move
+    n_upd, worst_upd = 0, (0.0, None)
+    for tag, new, old, ref, grads in (('g.', new_g, sd_g, cpu['g'], cpu['gg']), ('d.', new_d, sd_d, cpu['d'], cpu['gd'])):
+        for k, v0 in old.items():
+            du, du_ref = new[k] - v0, ref[k] - v0
+            if du_ref.abs().max() == 0:
+                assert du.abs().max() == 0, tag + k
+                continue
+            g = grads[k]
+            m = g.abs() > 1e-3 * g.abs().max()
+            e = ((du - du_ref)[m].abs().max() / du_ref[m].abs().max()).item()
+            n_upd += int(m.sum())
+            if e > worst_upd[0]:
+                worst_upd = (e, tag + k)
+    rep['worst_update'] = worst_upd
+    worst_lag = max(((lag[k] - cpu['lag'][k]).abs().max().item() / max(cpu['lag'][k].abs().max().item(), 1e-30), k)
+                    for k in lag)
+    rep['worst_ewma'] = worst_lag
+    with capsys.disabled():
+        print(f'\nlearner d_step + g_step, StyleGAN-{res} b{b} full width, vs FunctionalGAN:', rep)
+    assert rep['loss_d'] <= TOL and rep['loss_g'] <= TOL, rep
+    assert not still, still
+    _assert_ties_in_one_layer(rep)
+    assert len(ed) >= 20 and len(eg) >= 20 and n_upd > 10 ** 6
+    assert worst_upd[0] <= 2e-2, rep
+    assert worst_lag[0] <= 1e-4, rep

@@ -403,6 +403,11 @@ S2_CASES = [
     (1, 40, 6, 64, 12, 'up'),         # three steps, NBA = 2 with a ragged low-channel tile
     (2, 16, 68, 32, 16, 'up'),        # NBA = 1, 34 steps = two strips (32 + 2)
     (2, 64, 36, 64, 64, 'pool'),      # 2 x 4 channel-tile pairs
+    # rolling-window S / T kernels (conv_s2_roll.hip: 16 <-> 32 channels, low-resolution width a multiple of 32)
+    (3, 12, 24, 128, 20, 'pool'),     # channel padding on both sides, two column strips, 6 steps; T as its input gradient
+    (1, 16, 136, 64, 32, 'pool'),     # 34 steps: several strips per column, a ragged last one
+    (2, 24, 10, 64, 10, 'up'),        # T forward with channel padding (24 of 32 in, 10 of 16 out), 5 steps; S as dgrad
+    (1, 32, 68, 32, 16, 'up'),        # one column, 34 steps = strips with a top and a bottom edge each
 ]
 
 

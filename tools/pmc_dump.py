@@ -20,7 +20,7 @@ def main():
                       f'group by dispatch_id, counter_name order by dispatch_id')
     for d, k, c, v, s, e in rows:
         if want in k:
-            print(f'{d},{k[:60]},{c},{v:.0f},{(e - s) if (s and e) else 0}')
+            print(f"{d},{k[:240]},{c},{v:.0f},{(e - s) if (s and e) else 0}")
 
 
 if __name__ == '__main__':
