@@ -63,13 +63,19 @@ SIGNATURES = {
     'ganlab_conv_dgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
     'ganlab_conv_wgrad_bf16_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_in_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    'ganlab_conv_aff_supported': (_c_int, [_GP]),
+    'ganlab_conv_fwd_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_wgrad_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_s2_aff_supported': (_c_int, [_GP]),
+    'ganlab_conv_s2_fwd_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_s2_wgrad_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_mod_conv_supported': (_c_int, [_GP]),
     'ganlab_mod_conv_stat_chunks': (_c_int, [_GP]),
-    'ganlab_mod_conv_pack_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
-    'ganlab_mod_conv_fwd_f32': (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int,
+    'ganlab_mod_conv_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int,
                                          _c_f, _c_f, _c_p, _c_sz, _c_p]),
-    'ganlab_mod_conv_wgrad_workspace': (_c_sz, [_GP]),
-    'ganlab_mod_conv_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_mod_torgb_prep_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_f, _c_p]),
+    'ganlab_mod_torgb_wgrad_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_f, _c_p]),
     'ganlab_mod_torgb_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_mod_torgb_cross_workspace': (_c_sz, [_c_int]),
     'ganlab_mod_torgb_cross_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_p, _c_sz, _c_p]),

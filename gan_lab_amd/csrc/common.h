@@ -76,13 +76,14 @@ bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int
                              const void* gy);
 int gl_wgrad_roll_slots(int N, int Cin, int Cout, int H, int W);
 int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, int Cin, int Cout, int H, int W,
-                         hipStream_t st);
+                         hipStream_t st, const float* aff_s = nullptr, const float* aff_t = nullptr);
 bool gl_wgrad_s2_roll_supported(int N, int Cl, int Ch, int Hl, int Wl, const void* low, const void* high);
 int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl);
 int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, int N, int Cl, int Ch, int Hl, int Wl,
-                            hipStream_t st);
+                            hipStream_t st, const float* aff_s = nullptr, const float* aff_t = nullptr);
 
 // ---- conv_s2_roll.hip: rolling-window S / T kernels of the thin (16 <-> 32 channel) stride-2 fused layers ----------------
 bool gl_s2_roll_supported(int is_T, int N, int Cin, int Cout, int Hl, int Wl, const void* x, const void* y);
 int gl_s2_roll_launch(int is_T, const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Cout,
-                      int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st);
+                      int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st,
+                      const float* aff_s = nullptr, const float* aff_t = nullptr);

@@ -65,6 +65,11 @@ struct PatchGeo {
 struct PatchArgs {
   const float* x;
   int N, Cin, Hi, Wi, Hv, Wv, pad, up;
+  // "deferred InstanceNorm" (ops.Deferred): the tensor this patch is cut from is a generator layer's activated output a
+  // whose InstanceNorm + style, b = a * s[n,ci] + t[n,ci], has not been written out - the AFF kernels apply it while the
+  // patch goes from the prefetch registers to LDS (elements in the zero padding of b stay zero).  [N][Cin] each, or null.
+  const float* aff_s;
+  const float* aff_t;
 };
 
 // Descriptor of one staging item: LDS offset + channel, and the global offset relative to
@@ -288,18 +293,33 @@ __device__ __forceinline__ void lds_store4(float* dst, float4 v) {
   }
 }
 
-template <class G, int CI_T, int PLANE, bool A16>
+template <class G, int CI_T, int PLANE, bool A16, bool AFF = false>
 __device__ __forceinline__ void x_store(const XRegs<G, XStage<G, CI_T, PLANE>::PT>& r,
-                                        const XStage<G, CI_T, PLANE>& st, float* Xs, int tid) {
+                                        const XStage<G, CI_T, PLANE>& st, float* Xs, int tid,
+                                        const float* aff_tab = nullptr, int tab_ci0 = 0, int tab_t = 0, int ci_left = 0) {
   constexpr int PT = XStage<G, CI_T, PLANE>::PT;
   constexpr int NITEMS = XStage<G, CI_T, PLANE>::NITEMS;
+  static_assert(!AFF || G::XMODE == XVEC, "affine-on-load: plain vector staging only");
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int l = st.loff[i] & 0xfffff;
     if constexpr (G::XMODE == XSCALAR) {
       if (tid + i * 256 < NITEMS) Xs[l] = r.v[i];
     } else if constexpr (G::XMODE == XVEC) {
-      if (tid + i * 256 < NITEMS) lds_store4<A16>(Xs + l, r.v[i]);
+      if constexpr (AFF) {
+        // b = a * s + t for the elements INSIDE the image (a whole float4 is inside or outside: W % 4 == 0); the loads
+        // returned zeros for the others, which is what the zero padding of b holds.  aff_tab (LDS): s at [tab_ci0 + ci],
+        // t at [tab_t + tab_ci0 + ci]; ci_left = channels left from this chunk's first one
+        const int ci = (st.loff[i] >> 20) & 0x3ff;
+        const bool ok = st.goff[i] >= 0 && ci < ci_left;
+        // (not-ok lanes must not touch the table: uninitialised LDS may hold a NaN, and 0 * NaN is a NaN)
+        const float sv = ok ? aff_tab[tab_ci0 + ci] : 0.f, tv = ok ? aff_tab[tab_t + tab_ci0 + ci] : 0.f;
+        float4 v = r.v[i];
+        v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+        if (tid + i * 256 < NITEMS) lds_store4<A16>(Xs + l, v);
+      } else {
+        if (tid + i * 256 < NITEMS) lds_store4<A16>(Xs + l, r.v[i]);
+      }
     } else {
       const float4 v = r.v[i];
       const float4 a = float4{v.x, v.x, v.y, v.y}, b = float4{v.z, v.z, v.w, v.w};
@@ -866,16 +886,18 @@ __global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_k
 
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
-template <class Cfg, bool MASK = false, bool SPLITK = false>
+constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the AFF kernels keep in LDS
+template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
   constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, WPT = Cfg::WPT, NWI = Cfg::NWI;
   using XS_t = XStage<G, CI_T, PLANE>;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS + (AFF ? 2 * AFF_MAXC : 0)];
   float* Xs = smem;
   float* Ws = smem + Cfg::XS;
+  [[maybe_unused]] float* afftab = smem + Cfg::XS + Cfg::WS;     // AFF: s[0 .. Cin) | t at + AFF_MAXC of THIS image
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
@@ -956,10 +978,19 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
   };
   load_x(c_begin);
   load_w(c_begin);
+  if constexpr (AFF) {      // (visible to every wave after the first barrier of the chunk loop)
+    static_assert(!AFF || (G::XMODE == XVEC && G::NI == 1 && !SPLITK), "AFF: vector staging, one image per tile");
+    for (int c = tid; c < p.in.Cin; c += 256) {
+      afftab[c] = p.in.aff_s[(long long)n0 * p.in.Cin + c];
+      afftab[AFF_MAXC + c] = p.in.aff_t[(long long)n0 * p.in.Cin + c];
+    }
+  }
 
   for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
     __syncthreads();  // every wave is done reading the previous chunk
-    x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);   // every staging mode goes through the register prefetch
+    // every staging mode goes through the register prefetch
+    if constexpr (AFF) x_store<G, CI_T, PLANE, true, true>(xr, xst, Xs, tid, afftab, ci0, AFF_MAXC, p.in.Cin - ci0);
+    else x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
@@ -1119,7 +1150,7 @@ struct WgCfg {
   static_assert(G::PX_T % (4 * WK_) == 0, "K-steps must split evenly over waves");
 };
 
-template <class Cfg>
+template <class Cfg, bool AFF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, NBC = Cfg::NBC, WK = Cfg::WK;
@@ -1127,9 +1158,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int TW = G::TW, TH = G::TH, NI = G::NI, CO_T = Cfg::CO_T, CI_T = Cfg::CI_T, PX_T = G::PX_T;
   constexpr int GPT = Cfg::GPT, NGI = Cfg::NGI;
   using XS_t = XStage<G, CI_T, PLANE>;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::GS + Cfg::XS];
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::GS + Cfg::XS + (AFF ? 2 * CI_T : 0)];
   float* Gs = smem;
   float* Xs = smem + Cfg::GS;
+  // AFF (deferred InstanceNorm, see PatchArgs): s | t of this workgroup's CI_T input channels for the CURRENT tile's image
+  [[maybe_unused]] float* afftab = smem + Cfg::GS + Cfg::XS;
+  [[maybe_unused]] float aff_reg = 0.f;
+  static_assert(!AFF || (G::XMODE == XVEC && G::NI == 1 && 2 * CI_T <= 256), "AFF: vector staging, one image per tile");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WK, wk = wave % WK;
@@ -1185,6 +1220,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     xst.init(p.in, tid, n0, oy0, ox0);
     if constexpr (G::XMODE != XSCALAR)
       x_load<G, CI_T, PLANE>(xr, xst, p.in.x + (long long)n0 * p.in.Cin * plane, ci0, p.in.Cin, plane);
+    if constexpr (AFF) {
+      if (tid < 2 * CI_T) {
+        const int c = ci0 + (tid % CI_T);
+        const float* src = tid < CI_T ? p.in.aff_s : p.in.aff_t;
+        aff_reg = (c < p.in.Cin && n0 < p.in.N) ? src[(long long)n0 * p.in.Cin + c] : 0.f;
+      }
+    }
     const float* gb = p.gy + (long long)n0 * p.Cout * oplane;
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
@@ -1201,9 +1243,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   int tile = split;
   if (tile < n_tiles) load_tile(tile);
   while (tile < n_tiles) {
+    if constexpr (AFF) {      // nobody reads the table between the previous tile's second barrier and this one
+      if (tid < 2 * CI_T) afftab[tid] = aff_reg;
+    }
     __syncthreads();
     if constexpr (G::XMODE == XSCALAR)
       x_stage_scalar<G, CI_T, PLANE>(xst, p.in, p.in.x + (long long)xst.n0_ * p.in.Cin * plane, ci0, Xs, tid);
+    else if constexpr (AFF)
+      x_store<G, CI_T, PLANE, false, true>(xr, xst, Xs, tid, afftab, 0, CI_T, p.in.Cin - ci0);
     else
       x_store<G, CI_T, PLANE, false>(xr, xst, Xs, tid);
 #pragma unroll
@@ -1966,6 +2013,95 @@ int ganlab_conv_wgrad_act_f32(const float* gy, const float* y, const float* x, f
               g->Cin, hw4, g->Cout, y, slope, gb ? 1 : 0);
     GL_LAUNCH(pw_cross_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, gw, (int)blocks, B, b0,
               g->Cin, g->Cout, g->Cin, 1, scale, gb, bias_scale);
+  }
+  return GL_CHECK_LAUNCH();
+}
+
+// ---- deferred InstanceNorm: affine-on-load variants (see PatchArgs, mod.hip) ------------------------------------------
+static bool aff_wgrad_roll_ok(const ganlab_conv_geom* g, const void* x, const void* gy) {
+  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  return !(roll_env && roll_env[0] == '0') &&
+         gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy);
+}
+
+int ganlab_conv_aff_supported(const ganlab_conv_geom* g) {
+  if (!geom_ok(g) || g->ks != 3 || g->pad != 1 || g->up != 0 || (g->Win & 3) || g->Win < 32 || g->Hin < 8) return 0;
+  if ((long long)g->Cin * g->Hin * g->Win * 16 >= 0x7fffffffLL) return 0;
+  int bits = 0;
+  if (g->Cout > 16 && g->Cin <= AFF_MAXC) bits |= 1;
+  if (aff_wgrad_roll_ok(g, nullptr, nullptr) || g->Cout > 32) bits |= 2;     // rolling window, or the thick 8x8-tile kernel
+  return bits;
+}
+
+int ganlab_conv_fwd_aff_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                            float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream) {
+  if (!(ganlab_conv_aff_supported(g) & 1)) return GANLAB_EUNSUPPORTED;
+  if (!x || !wp || !y || !aff_s || !aff_t || !aligned16(x) || !aligned16(wp) || !aligned16(y)) return GANLAB_EINVAL;
+  ConvArgs a{};
+  a.in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, 0);
+  a.in.aff_s = aff_s; a.in.aff_t = aff_t;
+  a.wp = wp; a.bias = bias; a.y = y;
+  a.Cout = g->Cout; a.Ho = g->Hin; a.Wo = g->Win;
+  a.Cin_p = round_up_c(g->Cin, cin_pad(3)); a.Cout_p = round_up_c(g->Cout, 64);
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  a.ksplit = 1;
+  a.tiles_x = ceil_div(a.Wo, 32); a.tiles_y = ceil_div(a.Ho, 8); a.tiles_n = g->N;
+  hipStream_t st = gl_stream(stream);
+  if (g->Cout <= 32) {
+    using Cfg = FwdCfg<3, 2, 5, 3, 0, XVEC>;
+    a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+    GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  } else {
+    using Cfg = FwdCfg<3, 4, 5, 3, 0, XVEC>;
+    a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+    GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  }
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_conv_wgrad_aff_f32(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
+                              const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!(ganlab_conv_aff_supported(g) & 2)) return GANLAB_EUNSUPPORTED;
+  if (!gy || !x || !gw || !aff_s || !aff_t || !aligned16(x) || !aligned16(gy)) return GANLAB_EINVAL;
+  PatchArgs in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, 0);
+  in.aff_s = aff_s; in.aff_t = aff_t;
+  const int ho = g->Hin, wo = g->Win;
+  const WgPlan pl = plan_wgrad(in, gy, 3, g->Cout, ho, wo);
+  const long long nw = (long long)g->Cout * g->Cin * 9;
+  if (!workspace || workspace_bytes < (size_t)(pl.slots + 32) * nw * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipStream_t st = gl_stream(stream);
+  int slots = pl.slots;
+  if (aff_wgrad_roll_ok(g, x, gy) &&
+      workspace_bytes >= (size_t)(gl_wgrad_roll_slots(g->N, g->Cin, g->Cout, g->Hin, g->Win) + 32) * nw * sizeof(float)) {
+    const int rc = gl_wgrad_roll_launch(x, gy, (float*)workspace, g->N, g->Cin, g->Cout, g->Hin, g->Win, st, aff_s, aff_t);
+    if (rc != GANLAB_OK) return rc;
+    slots = gl_wgrad_roll_slots(g->N, g->Cin, g->Cout, g->Hin, g->Win);
+  } else {
+    if (pl.thin || pl.geom != WG_A || pl.xmode != XVEC) return GANLAB_EUNSUPPORTED;
+    using Cfg = WgThickA<3, XVEC>;
+    WgradArgs a{};
+    a.in = in; a.gy = gy; a.part = (float*)workspace;
+    a.Cout = g->Cout; a.Ho = ho; a.Wo = wo;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.tiles_n = pl.tiles_n;
+    a.tiles_co = pl.tiles_co; a.tiles_ci = pl.tiles_ci; a.S = pl.S;
+    { static const int v = [] { const char* e = getenv("GANLAB_WGRAD_XCD"); return (e && e[0] == '0') ? 0 : 1; }(); a.xcd = v; }
+    const long long grid = (long long)pl.tiles_co * pl.tiles_ci * pl.S;
+    GL_LAUNCH((conv_wgrad_kernel<Cfg, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  }
+  const unsigned nblk = (unsigned)((nw + 255) / 256);
+  const int groups = slots >= 64 ? 32 : 1;
+  float* ws = (float*)workspace;
+  if (groups == 1) {
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, st, (const float*)ws, gw, nw, slots, 1, scale);
+  } else {
+    float* stage2 = ws + (long long)slots * nw;
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk, groups), dim3(256), 0, st, (const float*)ws, stage2, nw, slots, groups, 1.0f);
+    GL_LAUNCH(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, st, (const float*)stage2, gw, nw, groups, 1, scale);
   }
   return GL_CHECK_LAUNCH();
 }

@@ -91,6 +91,10 @@ struct S2Args {
   int tiles_x, tiles_y, tiles_co;
   float bias_scale, slope;
   int act;
+  // T only - deferred InstanceNorm (ops.Deferred): x is a generator layer's activated output a, the operand is
+  // b = a * s[n,ci] + t[n,ci] inside the image and 0 in the padding; applied between the prefetch registers and LDS
+  const float* aff_s;   // [N][Cin] or null
+  const float* aff_t;
 };
 
 // TWL_ = 5: 32x8 low-res tiles; TWL_ = 4: 16x16 tiles for 16-pixel-wide outputs (a 32-wide tile would be half empty:
@@ -282,13 +286,15 @@ struct TCfg {
   static constexpr int NWI = 16 * CI_T * CO_T / 4, WPT = ceil_div_c(NWI, 256);
 };
 
-template <class Cfg>
+constexpr int S2_AFF_MAXC = 512;
+template <class Cfg, bool AFF = false>
 __global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel(S2Args p) {
   constexpr int MB = Cfg::MB, NBL = Cfg::NBL, CI_T = Cfg::CI_T, PLANE = Cfg::PLANE, RP = Cfg::RP, COP = Cfg::COP;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS + (AFF ? 2 * S2_AFF_MAXC : 0)];
   float* Xs = smem;
   float* Ws = smem + Cfg::XS;
+  [[maybe_unused]] float* afftab = smem + Cfg::XS + Cfg::WS;      // AFF: s[0 .. Cin) | t at + S2_AFF_MAXC of THIS image
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
   const int co_t = bid % p.tiles_co;
@@ -364,11 +370,26 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel
     }
   };
   load(0);
+  if constexpr (AFF) {      // (visible to every wave after the first barrier of the chunk loop)
+    for (int c = tid; c < p.Cin; c += 256) {
+      afftab[c] = p.aff_s[(long long)n * p.Cin + c];
+      afftab[S2_AFF_MAXC + c] = p.aff_t[(long long)n * p.Cin + c];
+    }
+  }
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < XPT; ++i)
-      if (xl[i] != -1) *reinterpret_cast<float4*>(Xs + (xl[i] & 0xfffff)) = xr[i];
+      if (xl[i] != -1) {
+        float4 v = xr[i];
+        if constexpr (AFF) {   // elements inside the image only (the loads returned zeros for the padding: it stays zero)
+          const int ci = (xl[i] >> 20) & 0x3ff;
+          const bool ok = xg[i] >= 0 && ci0 + ci < p.Cin;
+          const float sv = ok ? afftab[ci0 + ci] : 0.f, tv = ok ? afftab[S2_AFF_MAXC + ci0 + ci] : 0.f;
+          v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+        }
+        *reinterpret_cast<float4*>(Xs + (xl[i] & 0xfffff)) = v;
+      }
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
@@ -695,7 +716,11 @@ int run_S(S2Args a, hipStream_t st) {
 int run_T(S2Args a, hipStream_t st) {
   if (gl_s2_roll_supported(1, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.x, a.y))
     return gl_s2_roll_launch(1, a.x, a.wp, a.bias, a.y, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.Cin_p, a.Cout_p, a.bias_scale,
-                             a.act, a.slope, st);
+                             a.act, a.slope, st, a.aff_s, a.aff_t);
+  if (a.aff_s != nullptr) {       // deferred-InstanceNorm input: the 32-channel-tile kernel only (ganlab_conv_s2_aff_supported)
+    if (a.Cout <= 16 || a.Cin > S2_AFF_MAXC) return GANLAB_EUNSUPPORTED;
+    return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>, true>, a, st);
+  }
   if (a.Cout <= 16) return launch_s2<TCfg<1, 4>>(conv_s2_up_kernel<TCfg<1, 4>>, a, st);
   if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
   // 32 output channels per workgroup for the thick layers as well: the 64-channel tile keeps 128 accumulator registers
@@ -716,6 +741,33 @@ W2Plan plan_w2(int N, int Cl, int Ch, int Hl, int Wl) {
   pl.S = (int)S;
   pl.slots = pl.S;          // one slot per workgroup (its four waves own four different tap rows)
   return pl;
+}
+
+// slot reduction + fold of the 16-tap gradient back onto the 3x3 parameter (shared by the plain and the AFF entry point)
+static int s2_finish_wgrad(float* ws, int slots, long long nk, float* gw, const ganlab_conv_geom* g, int Cl, int Ch,
+                           float scale, hipStream_t st) {
+  float* stage2 = ws + (long long)slots * nk;
+  // slots -> 32 groups -> 1 with the wide reduce kernel (16*Cl*Ch threads); the fold kernel has only Cl*Ch threads
+  // (512 for the 16 -> 32 layer), so every slot it still had to add up cost it 16 serial strided reads per thread
+  const float* folded_src = ws;
+  int fold_groups = slots;
+  if (fold_groups >= 64) {
+    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 32), dim3(256), 0, st, (const float*)ws,
+              stage2, nk, slots, 32);
+    folded_src = stage2;
+    fold_groups = 32;
+  }
+  if (fold_groups > 2) {
+    float* dst = folded_src == ws ? stage2 : ws;
+    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 1), dim3(256), 0, st, folded_src, dst, nk,
+              fold_groups, 1);
+    folded_src = dst;
+    fold_groups = 1;
+  }
+  const long long nw = (long long)g->Cout * g->Cin;
+  GL_LAUNCH(fold_s2_kernel, dim3((unsigned)((nw + 127) / 128)), dim3(128), 0, st, folded_src, gw, g->Cout, g->Cin, Cl,
+            Ch, fold_groups, g->up ? 1 : 0, g->pool ? 1 : 0, scale);
+  return GL_CHECK_LAUNCH();
 }
 
 }  // namespace
@@ -767,6 +819,48 @@ int ganlab_conv_s2_dgrad_f32(const float* gy, const float* wp, float* gx, const 
   return g->pool ? run_T(a, gl_stream(stream)) : run_S(a, gl_stream(stream));
 }
 
+// ---- deferred InstanceNorm on the low-resolution input of an up layer (S2Args::aff_s) --------------------------------
+int ganlab_conv_s2_aff_supported(const ganlab_conv_geom* g) {
+  int hl, wl;
+  if (!s2_ok(g, &hl, &wl) || !g->up) return 0;
+  int bits = 0;
+  if (gl_s2_roll_supported(1, g->N, g->Cin, g->Cout, hl, wl, nullptr, nullptr) || (g->Cout > 16 && g->Cin <= S2_AFF_MAXC))
+    bits |= 1;
+  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  if (!(roll_env && roll_env[0] == '0') && gl_wgrad_s2_roll_supported(g->N, g->Cin, g->Cout, hl, wl, nullptr, nullptr))
+    bits |= 2;
+  return bits;
+}
+
+int ganlab_conv_s2_fwd_aff_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                               float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream) {
+  int hl, wl;
+  if (!(ganlab_conv_s2_aff_supported(g) & 1) || !s2_ok(g, &hl, &wl)) return GANLAB_EUNSUPPORTED;
+  if (!x || !wp || !y || !aff_s || !aff_t || !aligned16(x) || !aligned16(wp) || !aligned16(y)) return GANLAB_EINVAL;
+  S2Args a{};
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.aff_s = aff_s; a.aff_t = aff_t;
+  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.Hl = hl; a.Wl = wl;
+  a.Cin_p = round_up_c(g->Cin, 16); a.Cout_p = round_up_c(g->Cout, 64);
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  return run_T(a, gl_stream(stream));
+}
+
+int ganlab_conv_s2_wgrad_aff_f32(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
+                                 const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  int hl, wl;
+  if (!(ganlab_conv_s2_aff_supported(g) & 2) || !s2_ok(g, &hl, &wl)) return GANLAB_EUNSUPPORTED;
+  if (!gy || !x || !gw || !aff_s || !aff_t || !aligned16(gy) || !aligned16(x)) return GANLAB_EINVAL;
+  const int Cl = g->Cin, Ch = g->Cout;            // up layer: low = x (deferred), high = gy
+  const long long nk = 16LL * Cl * Ch;
+  const int slots = gl_wgrad_s2_roll_slots(g->N, Cl, Ch, hl, wl);
+  if (!workspace || workspace_bytes < (size_t)(slots + 32) * nk * sizeof(float)) return GANLAB_EWORKSPACE;
+  hipStream_t st = gl_stream(stream);
+  const int rc = gl_wgrad_s2_roll_launch(x, gy, (float*)workspace, g->N, Cl, Ch, hl, wl, st, aff_s, aff_t);
+  if (rc != GANLAB_OK) return rc;
+  return s2_finish_wgrad((float*)workspace, slots, nk, gw, g, Cl, Ch, scale, st);
+}
+
 size_t ganlab_conv_s2_wgrad_workspace(const ganlab_conv_geom* g) {
   int hl, wl;
   if (!s2_ok(g, &hl, &wl)) return 0;
@@ -807,29 +901,7 @@ int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const g
     if (pl.nba == 2) GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<2>>, dim3(wgrid), dim3(256), 0, st, a);
     else GL_LAUNCH(conv_s2_wgrad_kernel<WCfg<1>>, dim3(wgrid), dim3(256), 0, st, a);
   }
-  float* ws = (float*)workspace;
-  float* stage2 = ws + (long long)slots * nk;
-  // slots -> 32 groups -> 1 with the wide reduce kernel (16*Cl*Ch threads); the fold kernel has only Cl*Ch threads
-  // (512 for the 16 -> 32 layer), so every slot it still had to add up cost it 16 serial strided reads per thread
-  const float* folded_src = ws;
-  int fold_groups = slots;
-  if (fold_groups >= 64) {
-    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 32), dim3(256), 0, st, (const float*)ws,
-              stage2, nk, slots, 32);
-    folded_src = stage2;
-    fold_groups = 32;
-  }
-  if (fold_groups > 2) {
-    float* dst = folded_src == ws ? stage2 : ws;
-    GL_LAUNCH(reduce_s2_slots_kernel, dim3((unsigned)((nk + 255) / 256), 1), dim3(256), 0, st, folded_src, dst, nk,
-              fold_groups, 1);
-    folded_src = dst;
-    fold_groups = 1;
-  }
-  const long long nw = (long long)g->Cout * g->Cin;
-  GL_LAUNCH(fold_s2_kernel, dim3((unsigned)((nw + 127) / 128)), dim3(128), 0, st, folded_src, gw, g->Cout, g->Cin, Cl,
-            Ch, fold_groups, g->up ? 1 : 0, g->pool ? 1 : 0, scale);
-  return GL_CHECK_LAUNCH();
+  return s2_finish_wgrad((float*)workspace, slots, nk, gw, g, Cl, Ch, scale, st);
 }
 
 }  // extern "C"

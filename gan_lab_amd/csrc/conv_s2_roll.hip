@@ -40,6 +40,8 @@ struct SRArgs {
   int cols, strips, spu;   // column strips per row, row strips per column, steps (2 low rows) per strip
   float bias_scale, slope;
   int act;
+  const float* aff_s;      // T only: deferred InstanceNorm of the input (conv_s2.hip, S2Args), [N][Cin] or null
+  const float* aff_t;
 };
 
 // ===================================================================================================================
@@ -198,8 +200,10 @@ constexpr int TR_Q = 10;                  // float4 per (row, channel): low colu
 constexpr int TR_ITEMS = 2 * 32 * TR_Q;   // 640 float4 per 2-row prefetch
 constexpr int TR_PT = (TR_ITEMS + 255) / 256;   // 3
 
+template <bool AFF>
 __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_kernel(SRArgs p) {
   __shared__ __attribute__((aligned(16))) float ring[TR_SLOTS * TR_SLOT];      // 36864 B
+  __shared__ float afftab[AFF ? 64 : 1];    // s | t of this image's (<= 32) input channels
   constexpr int NG = 32, PD = 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int py = wv & 1, jrow = wv >> 1;    // this wave: output row parity, low row 2t + jrow of every step
@@ -257,14 +261,29 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_kernel(SRArgs p) {
       xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
   };
-  auto store_rows = [&](int rel0) {
+  auto store_rows = [&](int rel0, bool on) {
 #pragma unroll
     for (int i = 0; i < TR_PT; ++i) {
       const int k = (lo[i] >> 20) & 1;
-      if (tid + i * 256 < TR_ITEMS)
-        *reinterpret_cast<float4*>(ring + ((rel0 + k) % TR_SLOTS) * TR_SLOT + (lo[i] & 0xfffff)) = xr[i];
+      if (tid + i * 256 < TR_ITEMS) {
+        float4 v = xr[i];
+        if constexpr (AFF) {    // the load's validity test again: rows / columns / channels outside stay zero
+          const int vy = Ys - 1 + rel0 + k, ci = (lo[i] & 0xfffff) / TR_CP;
+          const bool ok = on && gbase[i] != SR_OOB && (unsigned)vy < (unsigned)p.Hl;
+          const float sv = ok ? afftab[ci] : 0.f, tv = ok ? afftab[32 + ci] : 0.f;
+          v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+        }
+        *reinterpret_cast<float4*>(ring + ((rel0 + k) % TR_SLOTS) * TR_SLOT + (lo[i] & 0xfffff)) = v;
+      }
     }
   };
+  if constexpr (AFF) {
+    if (tid < 64) {
+      const int c = tid & 31;
+      afftab[tid] = c < p.Cin ? (tid < 32 ? p.aff_s : p.aff_t)[(long long)n * p.Cin + c] : 0.f;
+    }
+    __syncthreads();
+  }
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -272,9 +291,9 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_kernel(SRArgs p) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) acc[ph][blk] = f32x4{0.f, 0.f, 0.f, 0.f};
   load_rows(0, true);
-  store_rows(0);
+  store_rows(0, true);
   load_rows(2, true);
-  store_rows(2);
+  store_rows(2, true);
   __syncthreads();
   const int lane_off = kk * TR_CP + px + 4;
   for (int t = 0; t < nsteps; ++t) {
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_kernel(SRArgs p) {
       if (g == 2) load_rows(2 * t + 4, t + 1 < nsteps);
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_rows(2 * t + 4);             // the two slots no wave reads in this step
+    store_rows(2 * t + 4, t + 1 < nsteps);             // the two slots no wave reads in this step
     const int Y = Ys + 2 * t + jrow;
     const int orow = (2 * Y + py) * Wh * 4;
 #pragma unroll
@@ -336,13 +355,18 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_kernel(SRArgs p) {
 
 inline bool sr_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// strips per column: enough workgroups for ~three rounds of the chip (3 per CU fit), at least 8 steps each
-void sr_plan(SRArgs& a) {
+// Strips per column: many more workgroups than the chip holds at once (3 per CU for S, 4 for T), at least 8 steps each (a
+// strip's six-row prologue is not overlapped).  Measured (tools/s2_roll_bench.py, 16 <-> 32 channels at 1024^2, batch 32):
+// 2560 workgroups of 64 steps 0.723 / 0.748 / 0.749 / 0.740 of the fp32 MFMA peak (S fwd, T dgrad, T fwd, S dgrad); a
+// "balanced" split - exactly one or two full rounds, 1536 / 1024 workgroups of 86 / 128 steps - 0.711 / 0.735 / 0.740 /
+// 0.734: the workgroups of a round run in lockstep, and more, shorter ones drift apart and cover each other's barriers.
+void sr_plan(SRArgs& a, int target) {
   a.cols = a.Wl / 32;
   const int steps = a.Hl / 2;
   const long long columns = (long long)a.cols * a.N;
   int kk = 1;
-  while (kk < steps && columns * kk < 2304 && (steps + kk) / (kk + 1) >= 8) ++kk;
+  while (kk < steps && columns * kk < target && (steps + kk) / (kk + 1) >= 8) ++kk;
+  if (const char* e = getenv("GANLAB_S2_ROLL_STRIPS")) { if (atoi(e) > 0) kk = atoi(e); }    // tuning knob
   a.spu = (steps + kk - 1) / kk;
   a.strips = (steps + a.spu - 1) / a.spu;
 }
@@ -364,15 +388,18 @@ bool gl_s2_roll_supported(int is_T, int N, int Cin, int Cout, int Hl, int Wl, co
 }
 
 int gl_s2_roll_launch(int is_T, const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Cout,
-                      int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st) {
+                      int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st,
+                      const float* aff_s, const float* aff_t) {
+  if (aff_s != nullptr && !is_T) return GANLAB_EUNSUPPORTED;
   SRArgs a{};
-  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.aff_s = aff_s; a.aff_t = aff_t;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl; a.Cin_p = Cin_p; a.Cout_p = Cout_p;
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
-  sr_plan(a);
+  sr_plan(a, 4096);
   const long long grid = (long long)a.cols * a.strips * N;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  if (is_T) GL_LAUNCH(conv_s2_up_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (is_T && aff_s != nullptr) GL_LAUNCH(conv_s2_up_roll_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else if (is_T) GL_LAUNCH(conv_s2_up_roll_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
   else GL_LAUNCH(conv_s2_down_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }

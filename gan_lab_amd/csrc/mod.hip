@@ -1,21 +1,20 @@
 // "Deferred InstanceNorm": the generator layer chain of stylegan/architectures.py:497-526 without its normalisation
 // passes.  A layer ends in   b = (a - mean[n,c]) * rstd[n,c] * (ys[n,c] + 1) + yb[n,c] = a * s[n,c] + t[n,c]
 // (InstanceNorm + AdaIN of the activated tensor a).  Round 1 ran that as its own HBM round trip (read a, write b) and the
-// next convolution read b again.  Here the CONSUMER applies it - without touching a single activation:
-//   * the scale folds into PER-SAMPLE weights  w_eff[n][tap][ci][co] = w[tap][ci][co] * s[n,ci]  (these kernels process
-//     one image per workgroup, so it is a weight pointer per image; StyleGAN2's weight modulation, applied to AdaIN);
-//   * the shift is a per-sample bias  sum_ci t[n,ci] * sum_tap w[tap][ci][co]  - except on the one-pixel border, where the
-//     taps that fall into the ZERO padding of b must not contribute: a 3x3 table of (row class, column class) per (n, co),
-//     `btab`, built on the host from the weight's partial tap sums, added in the epilogue;
-//   * toRGB is 1x1 (no padding): per-sample weights and bias only.
-// The same forward kernel can also finish the layer it computes (conv -> + noise_w * noise + bias -> LeakyReLU) and
-// accumulate the InstanceNorm statistics of ITS output in the epilogue (per-lane fp32 sums of a step's 16 values, fp64
-// across steps, fixed-order finish), so a plain 3x3 layer of the generator is ONE pass from a_in to a_out.
+// next convolution read b again.  Here the CONSUMER applies it: every kernel that stages a patch of b through registers
+// into LDS computes  a * s + t  on the way (one fma per element, with the per-image (s, t) table in LDS) and leaves the
+// elements that fall into the zero padding of b at zero - "affine on load" (conv.hip / conv_s2.hip / conv_s2_roll.hip /
+// wgrad_roll.hip, template flag AFF).  Shared packed weights, no border special case, and the weight gradient contracts
+// the same on-the-fly b, so nothing is accumulated per image.  (Round 2 folded s into PER-SAMPLE packed weights and t into a
+// border-class bias table, with per-image weight gradients recombined on the host: more launches, ATen glue, and only the
+// thinnest layers.)
+// This file: the thin rolling-window layer (Cin, Cout <= 16, W % 64 == 0, H % 4 == 0 - the 1024^2 layers) that also FINISHES
+// the layer it computes (conv -> + noise_w * noise + bias -> LeakyReLU) and accumulates the InstanceNorm statistics of ITS
+// output in the epilogue (per-lane fp32 sums of a step's 16 values, fp64 across steps, fixed-order finish), so a plain 3x3
+// layer of the generator is ONE pass from a_in to a_out; and toRGB (1x1, linear): per-sample weights w * s and bias
+// b + w.t built by a small kernel.
 // Backward: the input gradient is the plain kernel on the shared weights (it IS d/db, which the InstanceNorm backward
-// kernels of round 1 take); the weight gradient is accumulated PER IMAGE (wgrad_roll.hip's kernel, slots grouped by image)
-// and recombined with s / t on [N, Cout, Cin, 9] tensors by the caller (gan_lab_amd/ops.py::_ConvMod).
-// Geometry: the thin rolling-window layers (Cin, Cout <= 16, W % 64 == 0, H % 4 == 0) - at StyleGAN-1024 the two 1024^2
-// layers, half of the generator's activation bytes.
+// kernels of round 1 take); the weight gradient is the rolling-window kernel with AFF on its x operand.
 #include "common.h"
 
 namespace {
@@ -30,8 +29,9 @@ constexpr int RM_OOB = (int)0x80000000;
 
 struct RMArgs {
   const float* x;        // (N, Cin, H, W): the producer's activated tensor a
-  const float* wmod;     // [N][9][16][16] per-sample packed weights (scale and s folded in), or [1][...] with wstride 0
-  const float* btab;     // [N][3][3][16] border-class bias, or null
+  const float* wp;       // [9][Cin_p][Cout_p] packed weights (ganlab_conv_pack_f32, scale folded in), shared by the images
+  const float* aff_s;    // [N][Cin] deferred InstanceNorm + style of the INPUT: b = a * s + t inside the image; or null
+  const float* aff_t;
   const float* bias;     // [Cout] (x bias_scale), or null
   const float* noise;    // (N, 1, H, W) or null
   const float* noise_w;  // [Cout]
@@ -39,7 +39,7 @@ struct RMArgs {
   double* spart;         // [(n*Cout + co)*chunks + chunk][2] statistics partials, or null
   int N, Cin, Cout, H, W;
   int tiles_x, tiles_y, strips_x, strip;
-  long long wstride;
+  int Cin_p, Cout_p;
   float bias_scale, slope;
   int act;
 };
@@ -47,6 +47,7 @@ struct RMArgs {
 __global__ __launch_bounds__(256, 3) void conv_fwd_rollmod_kernel(RMArgs p) {
   __shared__ __attribute__((aligned(16))) float ring[RM_SLOTS * RM_SLOT];
   __shared__ double sred[4][16][2];
+  __shared__ float afftab[32];           // s | t of this image's (<= 16) input channels
   constexpr int C4N = 4, NSTEP = 36, PD = 3, NB = 4;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
@@ -71,10 +72,15 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_rollmod_kernel(RMArgs p) {
     gbase[i] = (e < RM_ITEMS && ci < p.Cin && (unsigned)vx < (unsigned)p.W) ? (ci * plane + vx) * 4 : RM_OOB;
     lo[i] = (ci * RM_RP + 4 * q) | (k << 20);
   }
-  const float* wn_ = p.wmod + (long long)n0 * p.wstride;
+  const bool aff = p.aff_s != nullptr;
+  if (aff && tid < 32) {
+    const int c = tid & 15;
+    afftab[tid] = c < p.Cin ? (tid < 16 ? p.aff_s : p.aff_t)[(long long)n0 * p.Cin + c] : 0.f;
+  }
   float wreg[NSTEP];
 #pragma unroll
-  for (int st = 0; st < NSTEP; ++st) wreg[st] = wn_[((st / C4N) * 16 + (st % C4N) * 4 + (lane >> 4)) * 16 + (lane & 15)];
+  for (int st = 0; st < NSTEP; ++st)
+    wreg[st] = p.wp[(long long)((st / C4N) * p.Cin_p + (st % C4N) * 4 + (lane >> 4)) * p.Cout_p + (lane & 15)];
   const int co_lane = lane & 15;
   const bool co_ok = co_lane < p.Cout;
   const float bv = (p.bias != nullptr && co_ok) ? p.bias[co_lane] * p.bias_scale : 0.f;
@@ -113,11 +119,20 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_rollmod_kernel(RMArgs p) {
 #pragma unroll
     for (int i = 0; i < RM_PT; ++i) {
       const int k = lo[i] >> 20;
-      if (tid + i * 256 < RM_ITEMS && k < nrows)
-        *reinterpret_cast<float4*>(ring + ((rel0 + k) % RM_SLOTS) * RM_SLOT + (lo[i] & 0xfffff)) = xr[i];
+      if (tid + i * 256 < RM_ITEMS && k < nrows) {
+        float4 v = xr[i];
+        if (aff) {            // the load's validity test again: rows / columns / channels outside the image stay zero
+          const int vy = oy_first - 1 + rel0 + k, ci = (lo[i] & 0xfffff) / RM_RP;
+          const bool ok = gbase[i] != RM_OOB && (unsigned)vy < (unsigned)p.H;
+          const float sv = ok ? afftab[ci] : 0.f, tv = ok ? afftab[16 + ci] : 0.f;
+          v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+        }
+        *reinterpret_cast<float4*>(ring + ((rel0 + k) % RM_SLOTS) * RM_SLOT + (lo[i] & 0xfffff)) = v;
+      }
     }
   };
 
+  __syncthreads();           // the (s, t) table
   load_rows(0, 4);
   store_rows(0, 4);
   load_rows(4, 2);
@@ -148,16 +163,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_rollmod_kernel(RMArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- epilogue of output row oy: border-class bias, noise, bias, LeakyReLU, statistics, 16-byte stores ----
+    // ---- epilogue of output row oy: noise, bias, LeakyReLU, statistics, 16-byte stores ----
     const int oy = oy_first + 4 * t + wn;
-    float bt[3] = {0.f, 0.f, 0.f};
-    if (p.btab != nullptr && co_ok) {
-      const int ry = oy == 0 ? 0 : (oy == p.H - 1 ? 2 : 1);
-      const float* bp = p.btab + ((long long)n0 * 9 + ry * 3) * 16 + co_lane;
-      bt[0] = bp[0];
-      bt[1] = bp[16];
-      bt[2] = bp[32];
-    }
     const int orow = oy * p.W * 4;
     float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -169,8 +176,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_rollmod_kernel(RMArgs p) {
       u32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int xx = x0 + r;
-        float v = acc[nb][r] + bv + (xx == 0 ? bt[0] : (xx == p.W - 1 ? bt[2] : bt[1])) + nwv * nz[r];
+        float v = acc[nb][r] + bv + nwv * nz[r];
         if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
         ssum += v;
         ssq += v * v;
@@ -226,19 +232,55 @@ __global__ void rm_stats_finish_kernel(const double* __restrict__ spart, float* 
   rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// wmod[n][tap][ci16][co16] = scale * w[co][ci][tap] * (s ? s[n][ci] : 1); channel padding is zero
-__global__ void rm_pack_kernel(const float* __restrict__ w, const float* __restrict__ s, float* __restrict__ out, int N,
-                               int Cout, int Cin, float scale) {
-  const long long total = (long long)N * 9 * 256;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int co = (int)(i & 15), ci = (int)((i >> 4) & 15);
-    const long long t2 = i >> 8;
-    const int tap = (int)(t2 % 9);
-    const long long n = t2 / 9;
-    float v = 0.f;
-    if (co < Cout && ci < Cin) v = scale * w[((long long)co * Cin + ci) * 9 + tap] * (s ? s[n * Cin + ci] : 1.f);
-    out[i] = v;
+// per-sample toRGB operands from the shared weight and the deferred (s, t):  weff[n][ci][4] = scale * w[co][ci] * s[n,ci],
+// beff[n][4] = bias[co] * bias_scale + scale * sum_ci w[co][ci] * t[n,ci]      (Cout <= 4, Cin <= 16; one block per image)
+__global__ void rm_torgb_prep_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                     const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ weff,
+                                     float* __restrict__ beff, int Cin, int Cout, float scale, float bias_scale) {
+  const int n = blockIdx.x, i = threadIdx.x;          // 64 threads: (ci = i >> 2, co = i & 3)
+  const int ci = i >> 2, co = i & 3;
+  if (ci < Cin) weff[((long long)n * Cin + ci) * 4 + co] = co < Cout ? scale * w[co * Cin + ci] * s[(long long)n * Cin + ci] : 0.f;
+  if (i < 4) {
+    float b = 0.f;
+    if (i < Cout) {
+      for (int c = 0; c < Cin; ++c) b += w[i * Cin + c] * t[(long long)n * Cin + c];
+      b = b * scale + (bias ? bias[i] * bias_scale : 0.f);
+    }
+    beff[(long long)n * 4 + i] = b;
   }
+}
+
+// weight / bias gradient of the modulated toRGB from the per-image cross sums (rm_torgb_cross_kernel: out[n][68]):
+//   gw[co][ci] = scale * sum_n ( s[n,ci] * cross[n][ci][co] + t[n,ci] * gsum[n][co] ),  gb[co] = bias_scale * sum_n gsum[n][co]
+__global__ void rm_torgb_wgrad_kernel(const float* __restrict__ out, const float* __restrict__ s,
+                                      const float* __restrict__ t, float* __restrict__ gw, float* __restrict__ gb, int N,
+                                      int Cin, int Cout, float scale, float bias_scale) {
+  const int i = threadIdx.x;                           // 64 threads: (ci = i >> 2, co = i & 3)
+  const int ci = i >> 2, co = i & 3;
+  if (ci < Cin && co < Cout && gw != nullptr) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n)
+      a += s[(long long)n * Cin + ci] * out[(long long)n * 68 + ci * 4 + co] + t[(long long)n * Cin + ci] * out[(long long)n * 68 + 64 + co];
+    gw[co * Cin + ci] = a * scale;
+  }
+  if (i < Cout && gb != nullptr) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += out[(long long)n * 68 + 64 + i];
+    gb[i] = a * bias_scale;
+  }
+}
+
+// s = rstd * (ys + 1), t = yb - mean * s  per (n, c) from the statistics and the style (N, 2C) = [ys | yb] (or null)
+__global__ void in_affine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ style, float* __restrict__ s, float* __restrict__ t, int N, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  const float ys = style ? style[(long long)(n * 2 + 0) * C + c] + 1.f : 1.f;
+  const float yb = style ? style[(long long)(n * 2 + 1) * C + c] : 0.f;
+  const float sv = rstd[i] * ys;
+  s[i] = sv;
+  t[i] = yb - mean[i] * sv;
 }
 
 // ---- toRGB with per-sample weights / bias -----------------------------------------------------------------------
@@ -363,25 +405,17 @@ int ganlab_mod_conv_stat_chunks(const ganlab_conv_geom* g) {
   return a.tiles_x * a.strips_x;
 }
 
-int ganlab_mod_conv_pack_f32(const float* w, const float* s, float* out, int N, int Cout, int Cin, float scale,
-                             void* stream) {
-  if (!w || !out || N <= 0 || Cout <= 0 || Cin <= 0 || Cout > 16 || Cin > 16) return GANLAB_EINVAL;
-  const long long total = (long long)N * 9 * 256;
-  GL_LAUNCH(rm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gl_stream(stream), w, s, out, N, Cout,
-            Cin, scale);
-  return GL_CHECK_LAUNCH();
-}
-
-int ganlab_mod_conv_fwd_f32(const float* x, const float* wmod, int per_sample, const float* btab, const float* bias,
+int ganlab_mod_conv_fwd_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
                             const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
                             const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps,
                             void* workspace, size_t workspace_bytes, void* stream) {
-  if (!rm_geom_ok(g) || !x || !wmod || !y || !rm_aligned16(x) || !rm_aligned16(y) || (noise && (!noise_w || !rm_aligned16(noise))))
+  if (!rm_geom_ok(g) || !x || !wp || !y || !rm_aligned16(x) || !rm_aligned16(y) || (noise && (!noise_w || !rm_aligned16(noise))) ||
+      ((aff_s == nullptr) != (aff_t == nullptr)))
     return GANLAB_EINVAL;
   RMArgs a{};
-  a.x = x; a.wmod = wmod; a.btab = btab; a.bias = bias; a.noise = noise; a.noise_w = noise_w; a.y = y;
+  a.x = x; a.wp = wp; a.aff_s = aff_s; a.aff_t = aff_t; a.bias = bias; a.noise = noise; a.noise_w = noise_w; a.y = y;
   a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.H = g->Hin; a.W = g->Win;
-  a.wstride = per_sample ? 9 * 256 : 0;
+  a.Cin_p = 16; a.Cout_p = 64;      // ganlab_conv_pack_f32's padding of a (<= 16) x (<= 16) 3x3 weight
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
   rm_grid(g, a);
   const int chunks = a.tiles_x * a.strips_x;
@@ -410,6 +444,34 @@ int ganlab_mod_torgb_fwd_f32(const float* x, const float* weff, const float* bef
   if (blocks > 128) blocks = 128;
   GL_LAUNCH(rm_torgb_fwd_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, gl_stream(stream), x, weff, beff, y, N,
             Cin, Cout, hw4);
+  return GL_CHECK_LAUNCH();
+}
+
+/* per-sample toRGB operands: weff [N][Cin][4], beff [N][4] (see rm_torgb_prep_kernel); w is the (Cout, Cin, 1, 1) parameter */
+int ganlab_mod_torgb_prep_f32(const float* w, const float* bias, const float* s, const float* t, float* weff, float* beff,
+                              int N, int Cin, int Cout, float scale, float bias_scale, void* stream) {
+  if (!w || !s || !t || !weff || !beff || N <= 0 || Cin <= 0 || Cin > 16 || Cout <= 0 || Cout > 4) return GANLAB_EINVAL;
+  GL_LAUNCH(rm_torgb_prep_kernel, dim3((unsigned)N), dim3(64), 0, gl_stream(stream), w, bias, s, t, weff, beff, Cin, Cout,
+            scale, bias_scale);
+  return GL_CHECK_LAUNCH();
+}
+
+/* gw (Cout, Cin) and gb (Cout) of the modulated toRGB from ganlab_mod_torgb_cross_f32's N x 68 output; either may be null */
+int ganlab_mod_torgb_wgrad_f32(const float* cross, const float* s, const float* t, float* gw, float* gb, int N, int Cin,
+                               int Cout, float scale, float bias_scale, void* stream) {
+  if (!cross || !s || !t || N <= 0 || Cin <= 0 || Cin > 16 || Cout <= 0 || Cout > 4) return GANLAB_EINVAL;
+  GL_LAUNCH(rm_torgb_wgrad_kernel, dim3(1), dim3(64), 0, gl_stream(stream), cross, s, t, gw, gb, N, Cin, Cout, scale,
+            bias_scale);
+  return GL_CHECK_LAUNCH();
+}
+
+/* s = rstd * (ys + 1), t = yb - mean * s per (n, c): the deferred InstanceNorm + style as a per-plane affine */
+int ganlab_in_affine_f32(const float* mean, const float* rstd, const float* style, float* s, float* t, int N, int C,
+                         void* stream) {
+  if (!mean || !rstd || !s || !t || N <= 0 || C <= 0) return GANLAB_EINVAL;
+  const long long total = (long long)N * C;
+  GL_LAUNCH(in_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gl_stream(stream), mean, rstd, style, s, t,
+            N, C);
   return GL_CHECK_LAUNCH();
 }
 

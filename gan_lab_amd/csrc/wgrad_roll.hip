@@ -47,10 +47,16 @@ struct WRArgs {
   int xcd;                // XCD-aware block mapping (A/B knob)
   int per_image;          // S = N * S_img workgroups per channel pair: workgroup `split` = (image split % N, j = split / N)
   int S_img;              // walks units j, j + S_img, ... of its own image only; slot `split` -> groups of N = per image
+  // deferred InstanceNorm (ops.Deferred): x is a generator layer's activated output a; the operand of the contraction is
+  // b = a * s[n,ci] + t[n,ci] inside the image, 0 in the padding - applied on the way from the prefetch registers to LDS
+  const float* aff_s;     // [N][Cin] or null
+  const float* aff_t;
 };
 
+template <bool AFF>   // AFF: its own instantiation - the plain kernel sits at the 168-VGPR cap of three workgroups per CU
 __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[WR_SMEM];
+  __shared__ float afftab[AFF ? 32 : 1];   // s | t of this workgroup's 16 input channels for the current unit's image
   float* ring = smem;
   float* gbuf = smem + WR_SLOTS * WR_XSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
     const int ci = t & 15, k = t >> 4;
     xch[i] = (e < WR_XITEMS && ci0 + ci < p.Cin) ? (ci0 + ci) * plane * 4 : WR_OOB;
     xlo[i] = ci * WR_XP + 4 * q + 1;
-    xk[i] = k;
+    xk[i] = k | (ci << 8);
     xcol[i] = 4 * q - 4;
   }
   // gy items: thread = (co = tid >> 4, q = tid & 15), item i = row i of the step
@@ -109,8 +115,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
     auto load_x = [&](int rel0, int nrows) {
 #pragma unroll
       for (int i = 0; i < WR_XPT; ++i) {
-        const int vy = y0 - 1 + rel0 + xk[i], vx = ox0 + xcol[i];
-        const bool ok = xch[i] != WR_OOB && xk[i] < nrows && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+        const int k = xk[i] & 255;
+        const int vy = y0 - 1 + rel0 + k, vx = ox0 + xcol[i];
+        const bool ok = xch[i] != WR_OOB && k < nrows && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
         const int off = ok ? xch[i] + (vy * p.W + vx) * 4 : WR_OOB;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
@@ -119,11 +126,19 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
     auto store_x = [&](int rel0, int nrows) {
 #pragma unroll
       for (int i = 0; i < WR_XPT; ++i) {
-        if (tid + i * 256 < WR_XITEMS && xk[i] < nrows) {
-          float* d = ring + ((rel0 + xk[i]) % WR_SLOTS) * WR_XSLOT + xlo[i];
-          d[0] = xr[i].x;
-          *reinterpret_cast<float2*>(d + 1) = float2{xr[i].y, xr[i].z};
-          d[3] = xr[i].w;
+        const int k = xk[i] & 255;
+        if (tid + i * 256 < WR_XITEMS && k < nrows) {
+          float4 v = xr[i];
+          if constexpr (AFF) {          // the same validity test as the load: padding / channel padding stays zero
+            const int vy = y0 - 1 + rel0 + k, vx = ox0 + xcol[i], ci = xk[i] >> 8;
+            const bool ok = xch[i] != WR_OOB && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
+            const float sv = ok ? afftab[ci] : 0.f, tv = ok ? afftab[16 + ci] : 0.f;
+            v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+          }
+          float* d = ring + ((rel0 + k) % WR_SLOTS) * WR_XSLOT + xlo[i];
+          d[0] = v.x;
+          *reinterpret_cast<float2*>(d + 1) = float2{v.y, v.z};
+          d[3] = v.w;
         }
       }
     };
@@ -140,6 +155,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_roll_kernel(WRArgs p) {
       for (int i = 0; i < WR_GPT; ++i) *reinterpret_cast<float4*>(gbuf + i * WR_GROW + glo) = gr[i];
     };
 
+    if constexpr (AFF) {                   // (nobody reads the table between the previous unit's last barrier and this one)
+      if (tid < 32) {
+        const int c = ci0 + (tid & 15);
+        afftab[tid] = c < p.Cin ? (tid < 16 ? p.aff_s : p.aff_t)[(long long)n * p.Cin + c] : 0.f;
+      }
+    }
     __syncthreads();                       // the previous unit's last step has been read
     load_x(0, 4);
     load_g(0, true);
@@ -242,14 +263,17 @@ struct W2RArgs {
   int tiles_cl, tiles_ch, S;
   int units;
   int xcd;
+  const float* aff_s;     // deferred InstanceNorm on the LOW operand (up layer: low = x): [N][Cl] or null
+  const float* aff_t;
 };
 
-template <int NBA>
+template <int NBA, bool AFF>
 __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
   constexpr int CL_T = 16 * NBA, LROW = CL_T * W2_LP;
   constexpr int LITEMS = W2_RL * CL_T * W2_LQ, LPT = LITEMS / 256;      // 256 / 512 float4 per step: 1 / 2 per thread
   static_assert(LITEMS % 256 == 0, "low staging items");
   __shared__ __attribute__((aligned(16))) float smem[WR_SLOTS * W2_HSLOT + W2_RL * LROW];
+  __shared__ float afftab[AFF ? 2 * CL_T : 1];   // s | t of this workgroup's low channels for the current unit's image
   float* ring = smem;
   float* lbuf = smem + WR_SLOTS * W2_HSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wa = tid >> 6;          // wa = tap row a of this wave
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
     const int cl = t % CL_T, j = t / CL_T;
     lch[i] = (cl0 + cl < p.Cl) ? (cl0 + cl) * lplane * 4 : WR_OOB;
     llo[i] = j * LROW + cl * W2_LP + 4 * q;
-    lrow[i] = j;
+    lrow[i] = j | (cl << 8);
     lq[i] = q;
   }
 
@@ -333,17 +357,32 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
     auto load_l = [&](int t, bool on) {
 #pragma unroll
       for (int i = 0; i < LPT; ++i) {
-        const int off = (on && lch[i] != WR_OOB) ? lch[i] + ((Y0 + W2_RL * t + lrow[i]) * p.Wl + X0 + 4 * lq[i]) * 4
+        const int off = (on && lch[i] != WR_OOB) ? lch[i] + ((Y0 + W2_RL * t + (lrow[i] & 255)) * p.Wl + X0 + 4 * lq[i]) * 4
                                                  : WR_OOB;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_l, off, 0, 0);
         lr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
       }
     };
-    auto store_l = [&]() {
+    auto store_l = [&]() {       // (only called for rows that were loaded: every low pixel of the tile is inside the image)
 #pragma unroll
-      for (int i = 0; i < LPT; ++i) *reinterpret_cast<float4*>(lbuf + llo[i]) = lr[i];
+      for (int i = 0; i < LPT; ++i) {
+        float4 v = lr[i];
+        if constexpr (AFF) {
+          const int cl = lrow[i] >> 8;
+          const bool ok = lch[i] != WR_OOB;
+          const float sv = ok ? afftab[cl] : 0.f, tv = ok ? afftab[CL_T + cl] : 0.f;
+          v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+        }
+        *reinterpret_cast<float4*>(lbuf + llo[i]) = v;
+      }
     };
 
+    if constexpr (AFF) {
+      if (tid < 2 * CL_T) {
+        const int c = cl0 + (tid % CL_T);
+        afftab[tid] = c < p.Cl ? (tid < CL_T ? p.aff_s : p.aff_t)[(long long)n * p.Cl + c] : 0.f;
+      }
+    }
     __syncthreads();
     load_h(0, 4);
     load_l(0, true);
@@ -472,69 +511,14 @@ int gl_wgrad_roll_slots(int N, int Cin, int Cout, int H, int W) {
 }
 
 int gl_wgrad_roll_launch(const float* x, const float* gy, float* part, int N, int Cin, int Cout, int H, int W,
-                         hipStream_t st) {
+                         hipStream_t st, const float* aff_s, const float* aff_t) {
   WRArgs a{};
-  a.x = x; a.gy = gy; a.part = part;
+  a.x = x; a.gy = gy; a.part = part; a.aff_s = aff_s; a.aff_t = aff_t;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   wr_plan(a);
   const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
-  GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-  return GL_CHECK_LAUNCH();
-}
-
-// ---- per-image weight gradient (mod.hip's deferred InstanceNorm: the caller recombines the images with s[n,ci]) ------
-__global__ void wr_reduce_groups_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int slots,
-                                        int groups, float scale) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int g = blockIdx.y;
-  float s0 = 0.f, s1 = 0.f;
-  int k = g;
-  for (; k + groups < slots; k += 2 * groups) {
-    s0 += part[(long long)k * n + i];
-    s1 += part[(long long)(k + groups) * n + i];
-  }
-  if (k < slots) s0 += part[(long long)k * n + i];
-  out[(long long)g * n + i] = (s0 + s1) * scale;
-}
-
-static void wr_plan_per_image(WRArgs& a) {
-  wr_plan(a);
-  const int base = a.tiles_ci * a.tiles_co;
-  int s_img = 768 / (a.N * base);
-  const int units_img = a.cols * a.strips;
-  if (s_img > units_img) s_img = units_img;
-  if (s_img < 1) s_img = 1;
-  a.per_image = 1;
-  a.S_img = s_img;
-  a.S = a.N * s_img;
-}
-
-extern "C" size_t ganlab_mod_conv_wgrad_workspace(const ganlab_conv_geom* g) {
-  if (!g || !gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, nullptr, nullptr)) return 0;
-  WRArgs a{};
-  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.H = g->Hin; a.W = g->Win;
-  wr_plan_per_image(a);
-  return (size_t)a.S * g->Cout * g->Cin * 9 * sizeof(float);
-}
-
-/* out[n][Cout][Cin][9] = scale * wgrad of image n alone (gy, x: one image's planes each) */
-extern "C" int ganlab_mod_conv_wgrad_f32(const float* gy, const float* x, float* out, const ganlab_conv_geom* g,
-                                         float scale, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!g || !gy || !x || !out ||
-      !gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy))
-    return GANLAB_EINVAL;
-  WRArgs a{};
-  a.x = x; a.gy = gy; a.part = (float*)workspace;
-  a.N = g->N; a.Cin = g->Cin; a.Cout = g->Cout; a.H = g->Hin; a.W = g->Win;
-  wr_plan_per_image(a);
-  const long long nw = (long long)g->Cout * g->Cin * 9;
-  if (!workspace || workspace_bytes < (size_t)a.S * nw * sizeof(float)) return GANLAB_EWORKSPACE;
-  hipStream_t st = gl_stream(stream);
-  const long long grid = (long long)a.tiles_co * a.tiles_ci * a.S;
-  GL_LAUNCH(conv_wgrad_roll_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-  GL_LAUNCH(wr_reduce_groups_kernel, dim3((unsigned)((nw + 255) / 256), (unsigned)g->N), dim3(256), 0, st,
-            (const float*)workspace, out, nw, a.S, g->N, scale);
+  if (aff_s != nullptr) GL_LAUNCH(conv_wgrad_roll_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_wgrad_roll_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -585,14 +569,19 @@ int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl) {
 }
 
 int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, int N, int Cl, int Ch, int Hl, int Wl,
-                            hipStream_t st) {
+                            hipStream_t st, const float* aff_s, const float* aff_t) {
   W2RArgs a{};
-  a.low = low; a.high = high; a.part = part;
+  a.low = low; a.high = high; a.part = part; a.aff_s = aff_s; a.aff_t = aff_t;
   a.N = N; a.Cl = Cl; a.Ch = Ch; a.Hl = Hl; a.Wl = Wl;
   w2r_plan(a);
   const long long grid = (long long)a.tiles_cl * a.tiles_ch * a.S;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  if (a.Cl > 16) GL_LAUNCH(conv_s2_wgrad_roll_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else GL_LAUNCH(conv_s2_wgrad_roll_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (aff_s != nullptr) {
+    if (a.Cl > 16) GL_LAUNCH((conv_s2_wgrad_roll_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    else GL_LAUNCH((conv_s2_wgrad_roll_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  } else {
+    if (a.Cl > 16) GL_LAUNCH((conv_s2_wgrad_roll_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    else GL_LAUNCH((conv_s2_wgrad_roll_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  }
   return GL_CHECK_LAUNCH();
 }

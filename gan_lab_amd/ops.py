@@ -1288,14 +1288,9 @@ class Deferred(object):
 
 def _affine_from_stats(mean, rstd, style, n, c):
     """s = rstd * (ys + 1), t = yb - mean * s  as (N, C) tensors (style: (N, 2C) = [ys | yb] or None)."""
-    if style is not None:
-        st = style.view(n, 2, c)
-        s_ = rstd.view(n, c) * (st[:, 0] + 1.0)
-        t_ = st[:, 1] - mean.view(n, c) * s_
-    else:
-        s_ = rstd.view(n, c).clone()
-        t_ = -mean.view(n, c) * s_
-    return s_.contiguous(), t_.contiguous()
+    s_, t_ = _new((n, c), mean), _new((n, c), mean)
+    check(_lib.lib().ganlab_in_affine_f32(_p(mean), _p(rstd), _p(style), _p(s_), _p(t_), n, c, _st()), 'in_affine')
+    return s_, t_
 
 
 def _layer_tail_backward(ctx, saved_tail, gout):
@@ -1390,44 +1385,128 @@ def materialize(x):
     return x
 
 
+_AFF_OK = {}      # (kind, shape, weight shape) -> bool: the support queries are pure functions of the geometry
+
+
+def mod_conv_shape_ok(shape, weight, padding=1):
+    """Can the 3x3 layer ``weight`` consume a deferred tensor of ``shape`` through the thin rolling-window kernel that also
+    finishes the layer (noise, bias, LeakyReLU, statistics in its epilogue)?"""
+    if get_compute_dtype() != 'f32' or padding != 1:
+        return False
+    key = ('mod', tuple(int(v) for v in shape), tuple(weight.shape))
+    hit = _AFF_OK.get(key)
+    if hit is None:
+        n, cin, h, w = key[1]
+        hit = False
+        if tuple(weight.shape[1:]) == (cin, 3, 3):
+            g = ConvGeom(n, cin, h, w, int(weight.shape[0]), 3, 1, 0, 0)
+            hit = bool(_lib.lib().ganlab_mod_conv_supported(ctypes.byref(g)))
+        _AFF_OK[key] = hit
+    return hit
+
+
 def mod_conv_ok(d, weight, padding=1):
-    """Can the 3x3 layer ``weight`` consume the deferred tensor ``d`` through the modulated rolling-window kernel?"""
-    if not isinstance(d, Deferred) or get_compute_dtype() != 'f32':
+    return isinstance(d, Deferred) and mod_conv_shape_ok(d.a.shape, weight, padding)
+
+
+def conv_aff_ok(shape, weight, up=False, padding=1):
+    """Can the 3x3 conv ``weight`` (behind a nearest 2x upsample when ``up``) read a deferred tensor of ``shape`` through
+    the affine-on-load kernels - forward AND weight gradient?"""
+    if get_compute_dtype() != 'f32' or padding != 1:
         return False
-    n, cin, h, w = d.a.shape
-    if tuple(weight.shape[1:]) != (cin, 3, 3) or padding != 1:
-        return False
-    g = ConvGeom(int(n), int(cin), int(h), int(w), int(weight.shape[0]), 3, 1, 0, 0)
-    return bool(_lib.lib().ganlab_mod_conv_supported(ctypes.byref(g)))
+    key = ('up' if up else 'plain', tuple(int(v) for v in shape), tuple(weight.shape))
+    hit = _AFF_OK.get(key)
+    if hit is None:
+        n, cin, h, w = key[1]
+        hit = False
+        if tuple(weight.shape[1:]) == (cin, 3, 3):
+            g = ConvGeom(n, cin, h, w, int(weight.shape[0]), 3, 1, 1 if up else 0, 0)
+            L = _lib.lib()
+            hit = (L.ganlab_conv_s2_aff_supported(ctypes.byref(g)) if up else L.ganlab_conv_aff_supported(ctypes.byref(g))) == 3
+        _AFF_OK[key] = hit
+    return hit
 
 
 def deferrable(x):
-    """A layer output of this shape can stay un-normalised for a modulated consumer (thin layer on a 64-aligned plane)."""
+    """A layer output of this shape can stay un-normalised for an affine-on-load consumer: the fused statistics pass
+    takes it (plane >= 32x32, rows of whole float4s)."""
     import os
     if os.environ.get('GANLAB_DEFER') == '0':          # A/B knob: keep the two-pass layer tail of round 1
         return False
     n, c, h, w = x.shape
-    return get_compute_dtype() == 'f32' and c <= 16 and w % 64 == 0 and h % 4 == 0 and h >= 8
+    return get_compute_dtype() == 'f32' and h * w >= STATS_MIN_PLANE and w % 4 == 0 and h % 2 == 0
 
 
-def _border_tap_sums(weight, scale):
-    """W_class[ry][rx][co][ci] = scale * sum of w[co][ci][ky][kx] over the taps that stay INSIDE the image for a pixel of
-    row class ry / column class rx (0: first row / column, 1: interior, 2: last): (3, 3, Cout, Cin)."""
-    w = weight.detach() * scale
-    rows = (w[:, :, 1:, :], w, w[:, :, :2, :])          # first row: ky = 0 reads row -1 (outside); last row: ky = 2
-    out = []
-    for wy in rows:
-        cols = (wy[:, :, :, 1:], wy, wy[:, :, :, :2])
-        out.append(torch.stack([c_.sum(dim=(2, 3)) for c_ in cols]))
-    return torch.stack(out)
+def k_conv_fwd_aff(a, s_, t_, w, g, scale):
+    """conv(up2?(a*s + t), w) * scale with the affine applied while the patch is staged (zero padding stays zero)."""
+    a, w = _c(a, 'conv input'), _c(w, 'conv weight')
+    assert tuple(a.shape) == g.in_shape and tuple(s_.shape) == (g.N, g.Cin) and tuple(t_.shape) == (g.N, g.Cin)
+    _note('fwd', g)
+    y = _new(g.out_shape, a)
+    L = _lib.lib()
+    if g.up:
+        assert g.s2
+        wp = _packed(w, PACK_FWD, scale, s2_up=1)
+        check(L.ganlab_conv_s2_fwd_aff_f32(_p(a), _p(wp), _p(s_), _p(t_), None, _p(y), g.ref(), 1.0, ACT_NONE, 0.2, _st()),
+              'conv_s2_fwd_aff')
+    else:
+        wp = _packed(w, PACK_FWD, scale)
+        check(L.ganlab_conv_fwd_aff_f32(_p(a), _p(wp), _p(s_), _p(t_), None, _p(y), g.ref(), 1.0, ACT_NONE, 0.2, _st()),
+              'conv_fwd_aff')
+    return y
+
+
+def k_conv_wgrad_aff(gy, a, s_, t_, g, scale):
+    """Weight gradient of conv(up2?(a*s + t), w): the x operand is normalised on the fly, like the forward's."""
+    gy, a = _c(gy, 'conv grad_out'), _c(a, 'conv input')
+    assert tuple(gy.shape) == g.out_shape and tuple(a.shape) == g.in_shape
+    _note('wgrad', g)
+    L = _lib.lib()
+    gw = _new((g.Cout, g.Cin, 3, 3), a)
+    if g.up:
+        ws = torch.empty((max(L.ganlab_conv_s2_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=a.device)
+        check(L.ganlab_conv_s2_wgrad_aff_f32(_p(gy), _p(a), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4,
+                                             _st()), 'conv_s2_wgrad_aff')
+    else:
+        ws = torch.empty((max(L.ganlab_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=a.device)
+        check(L.ganlab_conv_wgrad_aff_f32(_p(gy), _p(a), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4,
+                                          _st()), 'conv_wgrad_aff')
+    return gw
+
+
+class _ConvAff(Function):
+    """y = scale * conv(up2?(b), w) for the deferred tensor b = a*s + t (``Deferred``): the consumer's half of the
+    deferred InstanceNorm.  Backward: d/da := d loss / d b (the contract of ``Deferred``) from the plain input-gradient
+    kernel on the shared weights; the weight gradient contracts gy with the same on-the-fly b.  First order only."""
+
+    @staticmethod
+    def forward(ctx, a, s_, t_, w, g, scale):
+        ctx.save_for_backward(a, s_, t_, w)
+        ctx.g, ctx.scale = g, scale
+        return k_conv_fwd_aff(a, s_, t_, w, g, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        a, s_, t_, w = ctx.saved_tensors
+        ga = k_conv_dgrad(gy, w, ctx.g, ctx.scale) if ctx.needs_input_grad[0] else None
+        gw = k_conv_wgrad_aff(gy, a, s_, t_, ctx.g, ctx.scale) if (ctx.needs_input_grad[3] and _want_param_grads()) else None
+        return ga, None, None, gw, None, None
+
+
+def conv_aff(d, weight, scale, up=False):
+    """3x3 'same' conv (behind a nearest 2x upsample when ``up``) of a ``Deferred`` tensor; see ``conv_aff_ok``."""
+    n, cin, h, w = d.a.shape
+    g = Geom(n, cin, h, w, weight.shape[0], 3, 1, 1 if up else 0, 0)
+    return _ConvAff.apply(d.a, d.s, d.t, weight, g, float(scale))
 
 
 class _ConvModTail(Function):
-    """A plain 3x3 generator layer consuming a deferred input and producing a deferred output in ONE pass over the
+    """A plain thin 3x3 generator layer consuming a deferred input and producing a deferred output in ONE pass over the
     activations:  a_out = act(conv(a_in * s + t (zero padded), w) * scale + noise_w*noise + bias)  with the InstanceNorm
     statistics of a_out from the epilogue (csrc/mod.hip).  Backward: InstanceNorm backward of the incoming d/db_out (round-1
-    kernels) -> gz; d/db_in = plain input-gradient kernel on the shared weights; the weight gradient is accumulated per
-    image and recombined with s / t here."""
+    kernels) -> gz; d/db_in = plain input-gradient kernel on the shared weights; the weight gradient is the rolling-window
+    kernel with the affine on its x operand."""
 
     @staticmethod
     def forward(ctx, a_in, s_in, t_in, w, bias, noise, noise_w, style, scale, bias_scale, act, slope, eps):
@@ -1437,19 +1516,15 @@ class _ConvModTail(Function):
         L = _lib.lib()
         g = Geom(n, cin, h, wd, cout, 3, 1, 0)
         _note('fwd', g)
-        wmod = _new((n * 9 * 256,), a_in)
-        check(L.ganlab_mod_conv_pack_f32(_p(w), _p(s_in), _p(wmod), n, cout, cin, scale, _st()), 'mod_conv_pack')
-        wcls = _border_tap_sums(w, scale)                                  # (3, 3, Cout, Cin)
-        btab = _new((n, 3, 3, 16), a_in).zero_()
-        btab[..., :cout] = torch.einsum('ni,yxoi->nyxo', t_in, wcls)
+        wp = _packed(w, PACK_FWD, scale)
         noise = _c(noise) if noise is not None else None
         y = _new((n, cout, h, wd), a_in)
         mean, rstd = _new((n, cout), a_in), _new((n, cout), a_in)
         chunks = L.ganlab_mod_conv_stat_chunks(g.ref())
         ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
-        check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wmod), 1, _p(btab), _p(bias), _p(noise), _p(noise_w), _p(y), _p(mean),
-                                        _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws), ws.numel() * 8, _st()),
-              'mod_conv_fwd')
+        check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wp), _p(s_in), _p(t_in), _p(bias), _p(noise), _p(noise_w), _p(y),
+                                        _p(mean), _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws), ws.numel() * 8,
+                                        _st()), 'mod_conv_fwd')
         style_c = _c(style) if style is not None else None
         s_, t_ = _affine_from_stats(mean, rstd, style_c, n, cout)
         ctx.save_for_backward(a_in, s_in, t_in, w, y, mean, rstd, style_c, noise)
@@ -1474,63 +1549,25 @@ class _ConvModTail(Function):
         if ctx.needs_input_grad[0]:
             ga = k_conv_dgrad(gz, w, g, ctx.scale)              # d/d(a_in*s + t): shared weights, plain kernel
         if ctx.needs_input_grad[3] and _want_param_grads():
-            gw = _mod_conv_wgrad(gz, a_in, s_in, t_in, g, ctx.scale)
+            gw = k_conv_wgrad_aff(gz, a_in, s_in, t_in, g, ctx.scale)
         return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None
 
 
-def _mod_conv_wgrad(gz, a_in, s_in, t_in, g, scale):
-    """gw[o,i,ky,kx] = scale * sum_n ( s[n,i] * W_n[o,i,ky,kx] + t[n,i] * B_n[o,ky,kx] ):  W_n = weight gradient of image n
-    on the raw tensor a (per-image rolling-window kernel), B_n = sum of gz[n,o] over the pixels whose tap (ky,kx) stays
-    inside the image (total minus border rows / columns, plus the corners counted twice)."""
-    L = _lib.lib()
-    n, cout, h, w = gz.shape
-    cin = a_in.shape[1]
-    _note('wgrad', g)
-    wn = _new((n, cout, cin, 9), gz)
-    ws = torch.empty((max(L.ganlab_mod_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=gz.device)
-    check(L.ganlab_mod_conv_wgrad_f32(_p(gz), _p(a_in), _p(wn), g.ref(), 1.0, _p(ws), ws.numel() * 4, _st()),
-          'mod_conv_wgrad')
-    gw = torch.einsum('ni,noit->oit', s_in, wn)
-    # border sums of gz per (n, o): rows 0 / H-1, columns 0 / W-1, corners
-    tot = k_channel_sum(gz.view(1, n * cout, h, w)).view(n, cout)
-    r0, r1 = gz[:, :, 0, :].sum(-1), gz[:, :, h - 1, :].sum(-1)
-    c0, c1 = gz[:, :, :, 0].sum(-1), gz[:, :, :, w - 1].sum(-1)
-    # tap ky of the weight multiplies x[y + ky - 1]: it is outside for y = 0 when ky = 0 and for y = H-1 when ky = 2
-    rows = (tot - r0, tot, tot - r1)
-    rc = {(0, 0): gz[:, :, 0, 0], (0, 2): gz[:, :, 0, w - 1], (2, 0): gz[:, :, h - 1, 0], (2, 2): gz[:, :, h - 1, w - 1]}
-    rsub = {0: r0, 2: r1}
-    csub = {0: c0, 2: c1}
-    bn = torch.empty((n, cout, 3, 3), dtype=torch.float32, device=gz.device)
-    for ky in range(3):
-        for kx in range(3):
-            v = rows[ky]
-            if kx != 1:
-                v = v - csub[kx]
-                if ky != 1:
-                    v = v + rc[(ky, kx)]
-            bn[:, :, ky, kx] = v
-    gw = gw + torch.einsum('ni,not->oit', t_in, bn.view(n, cout, 9))
-    return (gw * scale).view(cout, cin, 3, 3)
-
-
 class _ToRGBMod(Function):
-    """toRGB (1x1, stylegan/architectures.py torgb) of a deferred tensor: per-sample weights w*s and bias b + w.t."""
+    """toRGB (1x1, stylegan/architectures.py torgb) of a deferred tensor: per-sample weights w*s and bias b + w.t, built
+    and folded back by two small kernels (csrc/mod.hip)."""
 
     @staticmethod
     def forward(ctx, a, s_, t_, w, bias, scale, bias_scale):
         a, w = _c(a), _c(w)
         n, cin, h, wd = a.shape
         cout = w.shape[0]
-        w2 = w.view(cout, cin) * scale
-        weff = torch.zeros((n, cin, 4), dtype=torch.float32, device=a.device)
-        weff[:, :, :cout] = s_.view(n, cin, 1) * w2.t().unsqueeze(0)
-        beff = torch.zeros((n, 4), dtype=torch.float32, device=a.device)
-        beff[:, :cout] = t_ @ w2.t()
-        if bias is not None:
-            beff[:, :cout] += bias.view(1, cout) * bias_scale
+        L = _lib.lib()
+        weff, beff = _new((n, cin, 4), a), _new((n, 4), a)
+        check(L.ganlab_mod_torgb_prep_f32(_p(w), _p(bias), _p(s_), _p(t_), _p(weff), _p(beff), n, cin, cout, scale,
+                                          bias_scale, _st()), 'mod_torgb_prep')
         y = _new((n, cout, h, wd), a)
-        check(_lib.lib().ganlab_mod_torgb_fwd_f32(_p(a), _p(weff), _p(beff), _p(y), n, cin, cout, h * wd, _st()),
-              'mod_torgb_fwd')
+        check(L.ganlab_mod_torgb_fwd_f32(_p(a), _p(weff), _p(beff), _p(y), n, cin, cout, h * wd, _st()), 'mod_torgb_fwd')
         ctx.save_for_backward(a, s_, t_, w)
         ctx.scale, ctx.bias_scale = scale, bias_scale
         ctx.bias_shape = bias.shape if bias is not None else None
@@ -1547,17 +1584,17 @@ class _ToRGBMod(Function):
         g = Geom(n, cin, h, wd, cout, 1, 0, 0)
         ga = k_conv_dgrad(gy, w, g, ctx.scale) if ctx.needs_input_grad[0] else None      # d/d(a*s + t)
         gw = gb = None
-        if (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and _want_param_grads():
+        want_w = ctx.needs_input_grad[3]
+        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[4]
+        if (want_w or want_b) and _want_param_grads():
             out = _new((n, 68), a)
             ws = torch.empty((L.ganlab_mod_torgb_cross_workspace(n) + 3) // 4, dtype=torch.float32, device=a.device)
             check(L.ganlab_mod_torgb_cross_f32(_p(a), _p(gy), _p(out), n, cin, cout, h * wd, _p(ws), ws.numel() * 4,
                                                _st()), 'mod_torgb_cross')
-            cross = out[:, :64].view(n, 16, 4)[:, :cin, :cout]          # [n][ci][co]
-            gsum = out[:, 64:64 + cout]                                  # [n][co]
-            gw2 = torch.einsum('ni,nio->oi', s_, cross) + torch.einsum('ni,no->oi', t_, gsum)
-            gw = (gw2 * ctx.scale).view(cout, cin, 1, 1) if ctx.needs_input_grad[3] else None
-            if ctx.bias_shape is not None and ctx.needs_input_grad[4]:
-                gb = (gsum.sum(0) * ctx.bias_scale).view(ctx.bias_shape)
+            gw = _new((cout, cin, 1, 1), a) if want_w else None
+            gb = _new(tuple(ctx.bias_shape), a) if want_b else None
+            check(L.ganlab_mod_torgb_wgrad_f32(_p(out), _p(s_), _p(t_), _p(gw), _p(gb), n, cin, cout, ctx.scale,
+                                               ctx.bias_scale, _st()), 'mod_torgb_wgrad')
         return ga, None, None, gw, gb, None, None
 
 

@@ -231,10 +231,11 @@ class StyleGenerator(StyleGAN):
                              f'(0,{final_stage}] or `None`.')
 
     # -- forward -------------------------------------------------------------------------------------
-    def _layer(self, n, layer, out, w, noise, defer_out=False):
+    def _layer(self, n, layer, out, w, noise, consumer=None):
         """One gen_layers entry on fused kernels.  ``out`` may be an ``ops.Deferred`` (the previous layer's output with its
-        InstanceNorm + style not yet applied); ``defer_out``: the consumer of THIS layer's output has a modulated kernel,
-        so return a ``Deferred`` where the shape allows (csrc/mod.hip)."""
+        InstanceNorm + style not yet applied: this layer's convolution applies it while it stages its input, csrc/mod.hip);
+        ``consumer``: what reads THIS layer's output - ('conv' | 'upconv' | 'torgb', module) or None - so that the output
+        can stay deferred where that reader has an affine-on-load kernel for its shape."""
         blur = False
         mods = list(layer[2])
         bias = mods.pop(0) if mods and isinstance(mods[0], Conv2dBias) else None
@@ -244,29 +245,36 @@ class StyleGenerator(StyleGAN):
         name = 'lrelu' if act is not None else None
         slope = act.negative_slope if act is not None else 0.2
         y = layer[3](w)                                                # (B, 2C) style
+        plain_in = self.use_instancenorm and not self.use_pixelnorm
         head = []
         if n:
             head = list(layer[0]) if isinstance(layer[0], nn.Sequential) else [layer[0]]
             blur = bool(head) and isinstance(head[-1], Blur2d)
-            conv = head[0] if (len(head) == 1 and isinstance(head[0], Conv2dEx)) else None
-            if isinstance(out, ops.Deferred) and conv is not None and conv.conv2d.bias is None and bias is not None \
-                    and self.use_instancenorm and not self.use_pixelnorm \
-                    and ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):
-                # plain 3x3 layer, deferred in -> deferred out in ONE pass over the activations (conv with per-sample
-                # weights, noise + bias + LeakyReLU + InstanceNorm statistics in its epilogue)
-                nz = layer[1].draw(out.a[:, :1], noise[n] if noise is not None else None) if self.use_noise else None
-                nw = layer[1].noise_weight if nz is not None else None
-                d = ops.conv_mod_tail(out, conv.conv2d.weight, conv.scale, bias_t, nz, nw, y, bias_scale=bias_scale,
-                                      act=name, slope=slope, eps=IN_EPS)
-                return d if defer_out else ops.materialize(d)
-            out = ops.materialize(out)
-            out = fused_sequential(head[:-1] if blur else head, out)   # (up+)conv MFMA kernel
+            body = head[:-1] if blur else head
+            up = len(body) == 2 and isinstance(body[0], Upsample2x)
+            conv = body[-1] if (body and isinstance(body[-1], Conv2dEx) and len(body) == (2 if up else 1)) else None
+            if isinstance(out, ops.Deferred) and conv is not None and conv.conv2d.bias is None:
+                if not up and not blur and bias is not None and plain_in and \
+                        ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):
+                    # thin plain 3x3 layer, deferred in -> deferred out in ONE pass over the activations (affine on load,
+                    # noise + bias + LeakyReLU + InstanceNorm statistics in the conv's epilogue)
+                    nz = layer[1].draw(out.a[:, :1], noise[n] if noise is not None else None) if self.use_noise else None
+                    nw = layer[1].noise_weight if nz is not None else None
+                    d = ops.conv_mod_tail(out, conv.conv2d.weight, conv.scale, bias_t, nz, nw, y, bias_scale=bias_scale,
+                                          act=name, slope=slope, eps=IN_EPS)
+                    return d if self._defer_ok(d.a.shape, consumer) else ops.materialize(d)
+                if ops.conv_aff_ok(out.a.shape, conv.conv2d.weight, up, conv.padding):
+                    out = ops.conv_aff(out, conv.conv2d.weight, conv.scale, up=up)     # (up+)conv with the affine on load
+                else:
+                    out = fused_sequential(body, ops.materialize(out))
+            else:
+                out = fused_sequential(body, ops.materialize(out))    # (up+)conv MFMA kernel
         else:
             out = ops.materialize(out)
         nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
         nw = layer[1].noise_weight if nz is not None else None
-        if self.use_instancenorm and not self.use_pixelnorm:
-            if defer_out and ops.deferrable(out):
+        if plain_in:
+            if ops.deferrable(out) and self._defer_ok(out.shape, consumer):
                 # blur + noise + bias + LeakyReLU + statistics in one pass; the normalisation is left to the consumer
                 return ops.layer_tail_deferred(out, bias_t, nz, nw, y, bias_scale=bias_scale, act=name, slope=slope,
                                                blur=blur, eps=IN_EPS)
@@ -279,16 +287,40 @@ class StyleGenerator(StyleGAN):
         # use_instancenorm=False: the style is applied to the un-normalised activations
         return ops.instnorm_style(out, y, IN_EPS) if self.use_instancenorm else ops.style_mod(out, y)
 
-    def _consumer_is_modulated(self, n, L):
-        """Can the consumer of layer n's output take a deferred tensor?  The next layer when it is a plain 3x3 conv (no
-        upsample / blur), or toRGB behind the last layer; never the tensor that also feeds prev_torgb while fading in."""
+    def _consumer(self, n, L):
+        """Who reads layer n's output: ('conv' | 'upconv', Conv2dEx) for the next layer's (upsample +) 3x3 conv, ('torgb',
+        Conv2dEx) behind the last layer; None where the tensor has a second reader (prev_torgb while fading in) or the next
+        layer is not of that shape."""
         if self.fade_in_phase and n == L - 3:
-            return False
+            return None
         if n == L - 1:
-            return True
+            return ('torgb', self.torgb)
         nxt = self.gen_layers[n + 1][0]
         head = list(nxt) if isinstance(nxt, nn.Sequential) else [nxt]
-        return len(head) == 1 and isinstance(head[0], Conv2dEx)
+        if head and isinstance(head[-1], Blur2d):
+            head = head[:-1]
+        if len(head) == 1 and isinstance(head[0], Conv2dEx):
+            return ('conv', head[0])
+        if len(head) == 2 and isinstance(head[0], Upsample2x) and isinstance(head[1], Conv2dEx):
+            return ('upconv', head[1])
+        return None
+
+    @staticmethod
+    def _defer_ok(shape, consumer):
+        """Can ``consumer`` read a deferred tensor of ``shape``?"""
+        if consumer is None:
+            return False
+        kind, mod = consumer
+        n, c, h, w = (int(v) for v in shape)
+        if mod.conv2d.bias is not None and kind != 'torgb':
+            return False
+        if kind == 'torgb':
+            return tuple(mod.conv2d.weight.shape[1:]) == (c, 1, 1) and mod.conv2d.weight.shape[0] <= 4 and c <= 16 and \
+                (h * w) % 4 == 0
+        if kind == 'conv':
+            return ops.mod_conv_shape_ok(shape, mod.conv2d.weight, mod.padding) or \
+                ops.conv_aff_ok(shape, mod.conv2d.weight, False, mod.padding)
+        return ops.conv_aff_ok(shape, mod.conv2d.weight, True, mod.padding)
 
     def _new_w(self, bs, dev):
         z2 = gen_rand_latent_vars(num_samples=bs, length=self.len_latent, distribution=self.latent_distribution,
@@ -310,9 +342,9 @@ class StyleGenerator(StyleGAN):
         if self.use_truncation_trick:
             if self.training:
                 with torch.no_grad():  # running average of w for the eval-time truncation trick (:427-437)
-                    wm = w.detach().mean(dim=0)
-                    self.w_ewma = wm.clone() if self.w_ewma is None else \
-                        wm * (1. - self.w_ewma_beta) + self.w_ewma * self.w_ewma_beta
+                    wm = ops.k_channel_sum(w.detach(), None, 1.0 / bs)          # mean over the batch (HIP kernel)
+                    self.w_ewma = wm if self.w_ewma is None else \
+                        ops.k_axpby(wm, self.w_ewma, 1. - self.w_ewma_beta, self.w_ewma_beta)
             elif self.trunc_cutoff_stage is not None:
                 w = self.w_ewma.expand_as(w) + self.w_eval_psi * (w - self.w_ewma.expand_as(w))
         out = self.const_input.expand(bs, -1, -1, -1)
@@ -331,7 +363,7 @@ class StyleGenerator(StyleGAN):
                 elif self.use_truncation_trick and not self.training and self.trunc_cutoff_stage is not None and \
                         n == 2 * self.trunc_cutoff_stage:
                     w = (w - self.w_ewma.expand_as(w)).div(self.w_eval_psi) + self.w_ewma.expand_as(w)
-            out = self._layer(n, layer, out, w, noise, defer_out=self._consumer_is_modulated(n, L))
+            out = self._layer(n, layer, out, w, noise, consumer=self._consumer(n, L))
             if self.fade_in_phase and n == L - 3:
                 pre_fade = out
         if isinstance(out, ops.Deferred) and ops.torgb_mod_ok(out, self.torgb.conv2d.weight):

@@ -356,27 +356,47 @@ int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, vo
 int ganlab_u8_box_decode_f32(const unsigned char* in_nhwc, float* out_nchw, int N, int Hs, int Ws, int C, int factor,
                              const float* mean, const float* stdv, const unsigned char* flip, void* stream);
 
-/* ---- deferred InstanceNorm ("modulated" consumers; csrc/mod.hip) ----------------------------------------------------
+/* ---- deferred InstanceNorm: "affine on load" consumers (csrc/mod.hip, template flag AFF in the conv kernels) ------------
  * The generator layer of stylegan/architectures.py:497-526 ends in b = a*s[n,c] + t[n,c] (InstanceNorm + AdaIN of the
- * activated tensor a).  These entry points let the CONSUMER of b read a instead: thin 3x3 layers (Cin, Cout <= 16,
- * W % 64 == 0, H % 4 == 0) through per-sample packed weights (w * s) + a border-class bias table for t, toRGB (1x1)
- * through per-sample weights / bias.  Replaces the second pass of ganlab_instnorm_style_fwd_f32 + the plain conv. */
+ * activated tensor a; custom_layers.py:98-99 + stylegan/architectures.py:524-526).  These entry points let the CONSUMER of
+ * b read a instead and apply the per-(sample, channel) affine while the patch goes from registers to LDS - elements in the
+ * zero padding of b stay zero.  aff_s / aff_t: [N][Cin] floats.  Replaces the second pass of ganlab_instnorm_style_fwd_f32
+ * followed by the plain kernel; the input gradient of such a layer is the plain ganlab_conv_dgrad_f32 / _s2_dgrad_f32 (it is
+ * d loss / d b, which the InstanceNorm backward takes). */
+/* s = rstd*(ys+1), t = yb - mean*s per (n, c); style = (N, 2C) = [ys | yb] or NULL */
+int ganlab_in_affine_f32(const float* mean, const float* rstd, const float* style, float* s, float* t, int N, int C,
+                         void* stream);
+/* plain 3x3 'same' layer on planes >= 32 wide with more than 16 output channels: bit 0 = forward, bit 1 = weight gradient */
+int ganlab_conv_aff_supported(const ganlab_conv_geom* g);
+/* ganlab_conv_fwd_f32 on b = a*s + t */
+int ganlab_conv_fwd_aff_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                            float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+/* ganlab_conv_wgrad_f32 with b = a*s + t as the x operand (workspace: ganlab_conv_wgrad_workspace) */
+int ganlab_conv_wgrad_aff_f32(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
+                              const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* Upsample + conv3x3 (up = 1) with a deferred low-resolution input: bit 0 = forward, bit 1 = weight gradient */
+int ganlab_conv_s2_aff_supported(const ganlab_conv_geom* g);
+int ganlab_conv_s2_fwd_aff_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                               float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_s2_wgrad_aff_f32(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
+                                 const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+/* thin 3x3 layer (Cin, Cout <= 16, W % 64 == 0, H % 4 == 0) that also finishes itself */
 int ganlab_mod_conv_supported(const ganlab_conv_geom* g);
 /* statistics chunks per (n, co) plane written by the forward: workspace = N*Cout*chunks*2 doubles */
 int ganlab_mod_conv_stat_chunks(const ganlab_conv_geom* g);
-/* out[n][tap 9][ci 16][co 16] = scale * w[co][ci][tap] * (s ? s[n][ci] : 1); s == NULL: one shared image (N = 1) */
-int ganlab_mod_conv_pack_f32(const float* w, const float* s, float* out, int N, int Cout, int Cin, float scale,
-                             void* stream);
-/* y = act(conv(x, wmod[n]) + btab[n][row class][col class][co] + bias*bias_scale + noise_w*noise) and, when mean / rstd
- * are given, the InstanceNorm statistics (biased variance, eps) of y from the same pass.  btab: [N][3][3][16] or NULL. */
-int ganlab_mod_conv_fwd_f32(const float* x, const float* wmod, int per_sample, const float* btab, const float* bias,
+/* y = act(conv(a*s + t, w) + bias*bias_scale + noise_w*noise) and, when mean / rstd are given, the InstanceNorm statistics
+ * (biased variance, eps) of y from the same pass.  wp: ganlab_conv_pack_f32(GANLAB_PACK_FWD); aff_s / aff_t NULL: plain input. */
+int ganlab_mod_conv_fwd_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
                             const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
                             const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps,
                             void* workspace, size_t workspace_bytes, void* stream);
-size_t ganlab_mod_conv_wgrad_workspace(const ganlab_conv_geom* g);
-/* out[n][Cout][Cin][9] = scale * weight gradient of image n alone (the caller recombines the images with s / t) */
-int ganlab_mod_conv_wgrad_f32(const float* gy, const float* x, float* out, const ganlab_conv_geom* g, float scale,
-                              void* workspace, size_t workspace_bytes, void* stream);
+/* toRGB (1x1, linear) of a deferred tensor: weff[n][ci][4] = scale*w[co][ci]*s[n,ci], beff[n][4] = bias*bias_scale + scale*w.t */
+int ganlab_mod_torgb_prep_f32(const float* w, const float* bias, const float* s, const float* t, float* weff, float* beff,
+                              int N, int Cin, int Cout, float scale, float bias_scale, void* stream);
+/* gw (Cout, Cin) / gb (Cout) (either may be NULL) from ganlab_mod_torgb_cross_f32's N x 68 sums */
+int ganlab_mod_torgb_wgrad_f32(const float* cross, const float* s, const float* t, float* gw, float* gb, int N, int Cin,
+                               int Cout, float scale, float bias_scale, void* stream);
 /* y[n,co] = sum_ci weff[n][ci][4] * x[n,ci] + beff[n][4]   (Cout <= 4) */
 int ganlab_mod_torgb_fwd_f32(const float* x, const float* weff, const float* beff, float* y, int N, int Cin, int Cout,
                              long long HW, void* stream);

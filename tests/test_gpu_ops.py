@@ -915,8 +915,8 @@ def test_integration_snippet_forward_vs_oracle(ops):
                          ids=['16->16@64x64', '12->10 ragged 24x128', 'two steps'])
 def test_deferred_instancenorm_chain_equals_composed(ops, shape):
     """csrc/mod.hip: a generator block's tail with the InstanceNorm + style left to its consumers - blurred layer ->
-    (deferred) -> plain 3x3 layer with per-sample weights, border-class bias, noise + bias + LeakyReLU + statistics in
-    the epilogue -> (deferred) -> toRGB with per-sample weights - against the SAME chain composed from the round-1 ops
+    (deferred) -> thin plain 3x3 layer that applies the affine while staging its input and has noise + bias + LeakyReLU +
+    statistics in its epilogue -> (deferred) -> toRGB with per-sample weights - against the SAME chain composed from the round-1 ops
     (layer_tail: two passes; conv2d; layer_tail; conv2d 1x1): image and every gradient (input, both conv weights, biases,
     noise weights, styles).  Reference semantics: stylegan/architectures.py:497-526."""
     n, c0, h, w, c1 = shape
@@ -961,3 +961,56 @@ def test_deferred_instancenorm_chain_equals_composed(ops, shape):
     d = ops.layer_tail_deferred(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
     ref = ops.layer_tail(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
     assert torch.equal(ops.materialize(d), ref)
+
+
+AFF_CASES = [
+    # N, C0 (deferred tensor), H, W, C1, up   - the consumers of a deferred tensor at the wider generator layers
+    (2, 32, 16, 64, 32, False),     # 32 -> 32 plain: 32-channel-tile forward, rolling-window weight gradient
+    (2, 64, 32, 32, 64, False),     # 64 -> 64 plain: 64-channel-tile forward, thick 8x8-tile weight gradient
+    (3, 40, 24, 48, 72, False),     # ragged: channel padding in both directions, partial tiles, two co tiles
+    (2, 128, 32, 32, 96, False),    # several K-chunks
+    (2, 64, 16, 32, 32, True),      # up-conv 64 -> 32 (tile kernel), 16-tap rolling weight gradient on the LOW operand
+    (2, 32, 16, 32, 16, True),      # up-conv 32 -> 16: the rolling-window T kernel
+    (3, 24, 12, 64, 10, True),      # the same with channel padding, two column strips
+    (1, 96, 20, 32, 48, True),      # ragged rows
+]
+
+
+@pytest.mark.parametrize('case', AFF_CASES, ids=[str(c) for c in AFF_CASES])
+def test_affine_on_load_consumers_equal_materialised(ops, case):
+    """Deferred InstanceNorm at the wider layers (VERDICT r02 #2b): layer A's tail leaves its output un-normalised
+    (``layer_tail_deferred``), layer B's (upsample +) conv applies a*s + t while it stages its input (AFF kernels of
+    conv.hip / conv_s2.hip / conv_s2_roll.hip), the weight gradient contracts the same on-the-fly tensor (conv.hip /
+    wgrad_roll.hip) - against the materialised chain ``layer_tail`` -> ``conv2d``: output and every gradient (x, bias, noise
+    weight, style of A; weight of B).  Reference semantics: stylegan/architectures.py:497-526 followed by :292-334."""
+    n, c0, h, w, c1, up = case
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+
+    def leaf(*s, scale=1.0):
+        return (rnd(gen, *s) * scale).cuda().requires_grad_(True)
+    x0 = leaf(n, c0, h, w)
+    b0, nw0, st0 = leaf(1, c0, 1, 1, scale=0.3), leaf(1, c0, 1, 1, scale=0.3), leaf(n, 2 * c0, scale=0.5)
+    w1 = leaf(c1, c0, 3, 3)
+    nz0 = rnd(gen, n, 1, h, w).cuda()
+    s1 = 1.0 / np.sqrt(c0 * 9)
+    cot = rnd(gen, n, c1, 2 * h if up else h, 2 * w if up else w).cuda()
+    params = [x0, b0, nw0, st0, w1]
+
+    def composed():
+        a = ops.layer_tail(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+        return ops.conv2d(a, w1, None, scale=s1, padding=1, up=up)
+
+    def deferred():
+        d = ops.layer_tail_deferred(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+        assert ops.conv_aff_ok(d.a.shape, w1, up, 1), 'this shape must take the affine-on-load kernels'
+        return ops.conv_aff(d, w1, s1, up=up)
+
+    outs, grads = [], []
+    for fn in (composed, deferred):
+        y = fn()
+        g = torch.autograd.grad((y * cot).sum(), params)
+        outs.append(y.detach())
+        grads.append([t_.detach() for t_ in g])
+    assert_close(outs[1], outs[0], 2e-5, 'output')
+    for name, a, b in zip(['x0', 'bias0', 'noise_w0', 'style0', 'w1'], grads[1], grads[0]):
+        assert_close(a, b, 2e-4, 'grad ' + name)
