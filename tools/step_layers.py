@@ -54,6 +54,9 @@ def main():
     ops.k_conv_dgrad_act = wrap('dgrad', ops.k_conv_dgrad_act, 3)
     ops.k_conv_wgrad_act = wrap('wgrad', ops.k_conv_wgrad_act, 3)
     ops.k_conv_fwd_mask = wrap('fwd', ops.k_conv_fwd_mask, 3)
+    # deferred-InstanceNorm consumers (affine on load): k_conv_fwd_aff(a, s, t, w, g, scale), k_conv_wgrad_aff(gy, a, s, t, g, ..)
+    ops.k_conv_fwd_aff = wrap('fwd', ops.k_conv_fwd_aff, 4)
+    ops.k_conv_wgrad_aff = wrap('wgrad', ops.k_conv_wgrad_aff, 4)
     torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s0.record()
