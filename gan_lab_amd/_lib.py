@@ -31,6 +31,13 @@ class ConvGeom(ctypes.Structure):
 
 _GP = ctypes.POINTER(ConvGeom)
 
+
+class PackDesc(ctypes.Structure):
+    """Mirror of `ganlab_pack_desc` (include/ganlab_hip.h): one weight re-layout of ganlab_pack_many's table."""
+    _fields_ = [('src', _c_p), ('dst', _c_p), ('kind', _c_int), ('Cout', _c_int), ('Cin', _c_int), ('ks', _c_int),
+                ('mode', _c_int), ('up', _c_int), ('scale', _c_f), ('reserved', _c_int), ('total', _c_ll),
+                ('block0', _c_ll)]
+
 # name -> (restype, argtypes): must list every function declared in include/ganlab_hip.h
 SIGNATURES = {
     'ganlab_abi_version': (_c_int, []),
@@ -63,6 +70,8 @@ SIGNATURES = {
     'ganlab_conv_dgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
     'ganlab_conv_wgrad_bf16_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_pack_desc_size': (_c_int, []),
+    'ganlab_pack_many': (_c_int, [_c_p, _c_int, _c_ll, _c_p]),
     'ganlab_in_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ganlab_conv_aff_supported': (_c_int, [_GP]),
     'ganlab_conv_fwd_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
@@ -180,6 +189,9 @@ def lib():
         if handle.ganlab_conv_geom_size() != ctypes.sizeof(ConvGeom):
             raise GanlabLibraryError(f'ConvGeom mirror is {ctypes.sizeof(ConvGeom)} bytes, the library\'s '
                                      f'ganlab_conv_geom {handle.ganlab_conv_geom_size()}: header and binding disagree')
+        if handle.ganlab_pack_desc_size() != ctypes.sizeof(PackDesc):
+            raise GanlabLibraryError(f'PackDesc mirror is {ctypes.sizeof(PackDesc)} bytes, the library\'s '
+                                     f'ganlab_pack_desc {handle.ganlab_pack_desc_size()}: header and binding disagree')
         _LIB = handle
     return _LIB
 

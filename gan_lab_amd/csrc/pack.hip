@@ -1,0 +1,96 @@
+// ONE launch for every weight re-layout of a network (launch count): after an optimiser step rewrites a
+// parameter arena, all packed forms the training step uses - [tap][ci][co] forward / input-gradient layouts of conv.hip,
+// the 16-tap K4 layouts of conv_s2.hip, the bf16 layouts of conv_bf16.hip; 60-190 small launches per step before - are
+// rebuilt from a device-resident descriptor table: block b finds its descriptor by binary search over the block
+// offsets and converts 256 consecutive output elements with the SAME element formula as the single-weight kernels
+// (pack_kernel, pack_s2_kernel, pack_bf16_kernel), so the results are bit-identical.  The table is built once per set of
+// weights (the pointers are stable: parameters live in flat arenas) by gan_lab_amd/ops.py.
+#include "common.h"
+
+namespace {
+
+constexpr int round_up_c(int v, int m) { return (v + m - 1) / m * m; }
+
+__device__ __forceinline__ float comb_s2(int up, int a, int k) {          // conv_s2.hip: the 4x3 combination matrices
+  if (up) {
+    const int lo = (a == 0) ? 2 : (a == 1 ? 1 : 0), hi = (a == 0) ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 0));
+    return (k >= lo && k <= hi) ? 1.f : 0.f;
+  }
+  const int lo = (a <= 1) ? 0 : (a == 2 ? 1 : 2), hi = (a == 0) ? 0 : (a == 1 ? 1 : 2);
+  return (k >= lo && k <= hi) ? 0.5f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void pack_many_kernel(const ganlab_pack_desc* __restrict__ descs, int n_desc) {
+  // binary search: last descriptor whose first block is <= blockIdx.x
+  int lo = 0, hi = n_desc - 1;
+  const long long b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const ganlab_pack_desc d = descs[lo];
+  const long long e = (b - d.block0) * 256 + threadIdx.x;
+  if (e >= d.total) return;
+  const float* w = d.src;
+  if (d.kind == GANLAB_PACKKIND_PLAIN) {
+    const int KK = d.ks * d.ks, dgrad = d.mode == GANLAB_PACK_DGRAD;
+    const int rows = dgrad ? d.Cout : d.Cin, cols = dgrad ? d.Cin : d.Cout;
+    const int rows_p = round_up_c(rows, d.ks == 1 ? 32 : 16), cols_p = round_up_c(cols, 64);
+    const int col = (int)(e % cols_p);
+    const long long t = e / cols_p;
+    const int row = (int)(t % rows_p), tap = (int)(t / rows_p);
+    float v = 0.f;
+    if (row < rows && col < cols) {
+      const int co = dgrad ? row : col, ci = dgrad ? col : row, st = dgrad ? (KK - 1 - tap) : tap;
+      v = d.scale * w[((long long)co * d.Cin + ci) * KK + st];
+    }
+    reinterpret_cast<float*>(d.dst)[e] = v;
+  } else if (d.kind == GANLAB_PACKKIND_S2) {
+    const int transpose = d.mode;
+    const int rows = transpose ? d.Cout : d.Cin, cols = transpose ? d.Cin : d.Cout;
+    const int rows_p = round_up_c(rows, 16), cols_p = round_up_c(cols, 64);
+    const int col = (int)(e % cols_p);
+    const long long t = e / cols_p;
+    const int row = (int)(t % rows_p), tap = (int)(t / rows_p);
+    float v = 0.f;
+    if (row < rows && col < cols) {
+      const int co = transpose ? row : col, ci = transpose ? col : row;
+      const int a = tap >> 2, bb = tap & 3;
+      const float* ws = w + ((long long)co * d.Cin + ci) * 9;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v += comb_s2(d.up, a, ky) * comb_s2(d.up, bb, kx) * ws[ky * 3 + kx];
+      v *= d.scale;
+    }
+    reinterpret_cast<float*>(d.dst)[e] = v;
+  } else {      // GANLAB_PACKKIND_BF16: [chunk = ci/32][tap][kg = (ci%32)/8][CO][ci%8]
+    const int dg = d.mode == GANLAB_PACK_DGRAD;
+    const int CO = dg ? d.Cin : d.Cout;
+    const int j = (int)(e & 7);
+    long long t = e >> 3;
+    const int co = (int)(t % CO);
+    t /= CO;
+    const int kg = (int)(t & 3);
+    t >>= 2;
+    const int tap = (int)(t % 9);
+    const int chunk = (int)(t / 9);
+    const int ci = chunk * 32 + kg * 8 + j;
+    const float v = dg ? w[((long long)ci * d.Cin + co) * 9 + (8 - tap)] : w[((long long)co * d.Cin + ci) * 9 + tap];
+    reinterpret_cast<__bf16*>(d.dst)[e] = (__bf16)(v * d.scale);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ganlab_pack_desc_size(void) { return (int)sizeof(ganlab_pack_desc); }
+
+int ganlab_pack_many(const ganlab_pack_desc* descs_device, int n_desc, long long total_blocks, void* stream) {
+  if (!descs_device || n_desc <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return GANLAB_EINVAL;
+  GL_LAUNCH(pack_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, gl_stream(stream), descs_device, n_desc);
+  return GL_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -776,8 +776,13 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
   const long long n = pl / C;
   const float m = mean[pl], r = rstd[pl];
   const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
-  const float inv = 1.f / (float)(hw4 * 4);
-  const float k = r * ys, a1 = s1[pl] * inv, a2 = s2[pl] * inv;
+  // The element formula runs in fp64 and is rounded ONCE, to the float that is stored; the bias / noise-weight sums add
+  // the unrounded values.  A bias in front of an InstanceNorm has an analytically ZERO gradient (sum over the plane of
+  // g - mean g - xhat * mean(g xhat)): summing float-rounded elements leaves sqrt(HW) * eps of noise per plane where the
+  // reference's own fp32 path leaves the same kind - in fp64 the cancellation is carried out.  ~10 fp64 operations per
+  // element of an HBM-bound pass (78 TFLOP/s of fp64 vector rate against 0.5 G elements per 2 GiB tensor).
+  const double inv = 1.0 / (double)(hw4 * 4);
+  const double k = (double)r * (double)ys, a1 = (double)s1[pl] * inv, a2 = (double)s2[pl] * inv, md = (double)m, rd = (double)r;
   const float4* pg = reinterpret_cast<const float4*>(gy) + pl * hw4;
   const float4* px = reinterpret_cast<const float4*>(x) + pl * hw4;
   const float4* pn = (want_nw && noise) ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
@@ -786,19 +791,21 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_act_kernel(
   const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
   for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
     float g[4], v[4], o[4];
+    double td[4];
     *reinterpret_cast<float4*>(g) = pg[i];
     *reinterpret_cast<float4*>(v) = px[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float t = k * (g[j] - a1 - (v[j] - m) * r * a2);
-      if (act == GANLAB_ACT_LRELU && !(v[j] > 0.f)) t *= slope;
-      o[j] = t;
+      double t = k * ((double)g[j] - a1 - ((double)v[j] - md) * rd * a2);
+      if (act == GANLAB_ACT_LRELU && !(v[j] > 0.f)) t *= (double)slope;
+      td[j] = t;
+      o[j] = (float)t;
     }
     po[i] = *reinterpret_cast<float4*>(o);
-    sb += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
+    sb += (td[0] + td[1]) + (td[2] + td[3]);
     if (pn) {
       const float4 z = pn[i];
-      snw += ((double)o[0] * z.x + (double)o[1] * z.y) + ((double)o[2] * z.z + (double)o[3] * z.w);
+      snw += (td[0] * z.x + td[1] * z.y) + (td[2] * z.z + td[3] * z.w);
     }
   }
   const long long slot = ((long long)c * N + n) * chunks + blockIdx.x;

@@ -167,28 +167,99 @@ def pool_fusable(N, Cin, Hin, Win, Cout, ks, pad):
 
 
 # ---- packed-weight cache ------------------------------------------------------------------------
-# Packing (OIHW -> [tap][ci][co], eq-LR scale folded in) costs one tiny kernel; D weights are used
-# by 3 forward + several dgrad passes per step, so the result is cached until the weights change.
-# The entry keeps an alias of the weight alive so its address cannot be recycled under the key.
+# Packing (OIHW -> [tap][ci][co], eq-LR scale folded in) costs one tiny kernel; D weights are used by 3 forward + several
+# dgrad passes per step, so the result is cached until the weights change.  The entry keeps an alias of the weight alive so
+# its address cannot be recycled under the key.
+# Who changes weights: (i) in-place torch ops - seen through ``w._version`` in the key; (ii) the fused optimiser, which
+# rewrites a whole parameter arena through raw pointers - it reports the byte ranges it touched
+# (``bump_weight_epoch(ranges)``), every cached entry inside such a range is stale, and the FIRST request for one of them
+# re-packs ALL of them in ONE launch from a device-resident descriptor table (csrc/pack.hip: 60-190 pack launches per
+# training step before).  Entries outside the range (the other network) stay valid.  ``bump_weight_epoch()`` without
+# ranges drops everything (growth events, graph capture).
+class _PackEntry(object):
+    __slots__ = ('w', 'out', 'serial', 'ptr', 'desc')
+
+
 _PACK_CACHE = {}
-_PACK_EPOCH = [0]
+_PACK_SERIAL = [0]
+_PACK_RANGES = {}        # (lo, hi) byte range -> serial of its last rewrite
+_PACK_TABLES = {}        # (lo, hi) -> (entry keys, device descriptor table, total blocks)
+_KIND_PLAIN, _KIND_S2, _KIND_BF16 = 0, 1, 2
 
 
-def bump_weight_epoch():
-    """Called by the fused optimiser after it rewrites parameters through raw pointers."""
-    _PACK_EPOCH[0] += 1
-    _PACK_CACHE.clear()
+def bump_weight_epoch(ranges=None):
+    """Called by the fused optimiser after it rewrites parameters through raw pointers (``ranges``: [(lo, hi)] device
+    address ranges), or without arguments to drop every packed weight."""
+    _PACK_SERIAL[0] += 1
+    if ranges is None:
+        _PACK_CACHE.clear()
+        _PACK_TABLES.clear()
+        _PACK_RANGES.clear()
+        return
+    for r in ranges:
+        _PACK_RANGES[(int(r[0]), int(r[1]))] = _PACK_SERIAL[0]
+
+
+def _stale_range(e):
+    for r, ser in _PACK_RANGES.items():
+        if ser > e.serial and r[0] <= e.ptr < r[1]:
+            return r
+    return None
+
+
+def _repack_range(r):
+    """Re-pack every cached entry whose weight lives in the rewritten range ``r`` with ONE launch."""
+    L = _lib.lib()
+    ser = _PACK_RANGES[r]
+    items = [(k, e) for k, e in _PACK_CACHE.items() if r[0] <= e.ptr < r[1] and e.serial < ser]
+    keys = tuple(k for k, _ in items)
+    tab = _PACK_TABLES.get(r)
+    if tab is None or tab[0] != keys:
+        arr = (_lib.PackDesc * len(items))()
+        blocks = 0
+        for i, (_, e) in enumerate(items):
+            kind, cout, cin, ks, mode, up, scale, total = e.desc
+            d = arr[i]
+            d.src, d.dst = e.w.data_ptr(), e.out.data_ptr()
+            d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = kind, cout, cin, ks, mode, up, scale, \
+                total, blocks
+            blocks += (total + 255) // 256
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        tab = (keys, host.to(items[0][1].w.device), blocks)
+        _PACK_TABLES[r] = tab
+    check(L.ganlab_pack_many(tab[1].data_ptr(), len(items), tab[2], _st()), 'pack_many')
+    now = _PACK_SERIAL[0]
+    for _, e in items:
+        e.serial = now
+
+
+def _pack_lookup(key):
+    e = _PACK_CACHE.get(key)
+    if e is None:
+        return None
+    r = _stale_range(e)
+    if r is not None:
+        _repack_range(r)
+    return e.out
+
+
+def _pack_store(key, w, out, desc):
+    if len(_PACK_CACHE) > 1024:
+        bump_weight_epoch()
+    e = _PackEntry()
+    e.w, e.out, e.serial, e.ptr, e.desc = w.detach(), out, _PACK_SERIAL[0], w.data_ptr(), desc
+    _PACK_CACHE[key] = e
+    # a new entry changes the entry set of its range: the table is rebuilt at the next re-pack (keys differ)
+    return out
 
 
 def _packed(w, mode, scale, s2_up=None):
     """mode: PACK_FWD / PACK_DGRAD.  s2_up: None -> plain [tap][ci][co] packing; 0 / 1 -> K4 packing of the
     stride-2 kernels for a down (pool) / up layer."""
-    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0], s2_up)
-    hit = _PACK_CACHE.get(key)
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), s2_up)
+    hit = _pack_lookup(key)
     if hit is not None:
-        return hit[1]
-    if len(_PACK_CACHE) > 512:
-        _PACK_CACHE.clear()
+        return hit
     cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
     L = _lib.lib()
     if s2_up is not None:
@@ -200,8 +271,7 @@ def _packed(w, mode, scale, s2_up=None):
         rc = L.ganlab_conv_s2_pack_f32(_p(w), _p(out), cout, cin, int(s2_up), tr, scale, _st())
         if rc != n:
             raise _lib.GanlabLibraryError(f'conv_s2_pack failed ({rc})')
-        _PACK_CACHE[key] = (w.detach(), out)
-        return out
+        return _pack_store(key, w, out, (_KIND_S2, cout, cin, 3, tr, int(s2_up), float(scale), int(n)))
     n = L.ganlab_conv_pack_f32(None, None, cout, cin, ks, mode, scale, None)
     if n <= 0:
         raise _lib.GanlabLibraryError(f'conv_pack size query failed ({n}) for weight {tuple(w.shape)}')
@@ -209,17 +279,14 @@ def _packed(w, mode, scale, s2_up=None):
     rc = L.ganlab_conv_pack_f32(_p(w), _p(out), cout, cin, ks, mode, scale, _st())
     if rc != n:
         raise _lib.GanlabLibraryError(f'conv_pack failed ({rc})')
-    _PACK_CACHE[key] = (w.detach(), out)
-    return out
+    return _pack_store(key, w, out, (_KIND_PLAIN, cout, cin, ks, mode, 0, float(scale), int(n)))
 
 
 def _packed_bf16(w, mode, scale):
-    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), _PACK_EPOCH[0], 'bf16')
-    hit = _PACK_CACHE.get(key)
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), 'bf16')
+    hit = _pack_lookup(key)
     if hit is not None:
-        return hit[1]
-    if len(_PACK_CACHE) > 512:
-        _PACK_CACHE.clear()
+        return hit
     cout, cin = w.shape[0], w.shape[1]
     L = _lib.lib()
     n = L.ganlab_conv_pack_bf16(None, None, cout, cin, mode, scale, None)
@@ -229,8 +296,7 @@ def _packed_bf16(w, mode, scale):
     rc = L.ganlab_conv_pack_bf16(_p(w), out.data_ptr(), cout, cin, mode, scale, _st())
     if rc != n:
         raise _lib.GanlabLibraryError(f'conv_pack_bf16 failed ({rc})')
-    _PACK_CACHE[key] = (w.detach(), out)
-    return out
+    return _pack_store(key, w, out, (_KIND_BF16, cout, cin, 3, mode, 0, float(scale), int(n)))
 
 
 # ---- "input gradient only" mode ---------------------------------------------------------------------

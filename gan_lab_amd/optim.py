@@ -118,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        ops.bump_weight_epoch()  # packed conv weights are stale after this
+        touched = []
         for group in self.param_groups:
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
@@ -149,6 +149,11 @@ class FusedAdam(torch.optim.Optimizer):
                 gv = torch.as_strided(p0.grad.reshape(-1), (r['n'],), (1,))
                 ops.adam_step(pv, gv, r['m'], r['v'], group['lr'], b1, b2, group['eps'], group['weight_decay'],
                               bc1, bc2)
+                touched.append((r['start'], r['end']))
+        # packed conv weights inside the rewritten memory are stale: they are re-packed (all of them, one launch) at
+        # their next use; the other network's stay valid
+        if touched:
+            ops.bump_weight_epoch(touched)
 
     @staticmethod
     def _carry(old, run):

@@ -123,6 +123,7 @@ class ProGANLearner(GANLearner):
         """Flat parameter / gradient arenas for G and D (+ the EWMA shadow of G)."""
         dev = self.config.dev
         self.reducer.abandon()                   # hooks of the arenas this call replaces (growth / checkpoint load)
+        ops.bump_weight_epoch()                  # packed weights of the old arenas (their aliases keep the memory alive)
         self.arena_g = ParamArena(self.gen_model.named_parameters(), dev)
         self.arena_d = ParamArena(self.disc_model.named_parameters(), dev)
         # Replicas start from rank 0's values at construction AND after every growth event: the new blocks and the

@@ -356,6 +356,29 @@ int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, vo
 int ganlab_u8_box_decode_f32(const unsigned char* in_nhwc, float* out_nchw, int N, int Hs, int Ws, int C, int factor,
                              const float* mean, const float* stdv, const unsigned char* flip, void* stream);
 
+/* ---- all weight re-layouts of a network in ONE launch (csrc/pack.hip) -------------------------------------------------
+ * The packed forms ganlab_conv_pack_f32 / ganlab_conv_s2_pack_f32 / ganlab_conv_pack_bf16 produce, rebuilt for a whole
+ * table of weights after the optimiser rewrote them (Conv2dEx.forward multiplies by wscale on every call,
+ * custom_layers.py:202-211; here the scaled re-layout is cached between optimiser steps).  `descs_device`: device copy of
+ * n_desc descriptors sorted by block0; descriptor i owns blocks [block0, block0 + ceil(total / 256)). */
+#define GANLAB_PACKKIND_PLAIN 0
+#define GANLAB_PACKKIND_S2 1
+#define GANLAB_PACKKIND_BF16 2
+typedef struct ganlab_pack_desc {
+  const float* src;      /* OIHW parameter */
+  void* dst;             /* packed buffer of `total` elements (float, or bf16 for GANLAB_PACKKIND_BF16) */
+  int kind;              /* GANLAB_PACKKIND_* */
+  int Cout, Cin, ks;
+  int mode;              /* PLAIN / BF16: GANLAB_PACK_FWD or _DGRAD; S2: transpose flag */
+  int up;                /* S2: 1 = up layer, 0 = down (pooled) layer */
+  float scale;
+  int reserved;
+  long long total;
+  long long block0;
+} ganlab_pack_desc;
+int ganlab_pack_desc_size(void);
+int ganlab_pack_many(const ganlab_pack_desc* descs_device, int n_desc, long long total_blocks, void* stream);
+
 /* ---- deferred InstanceNorm: "affine on load" consumers (csrc/mod.hip, template flag AFF in the conv kernels) ------------
  * The generator layer of stylegan/architectures.py:497-526 ends in b = a*s[n,c] + t[n,c] (InstanceNorm + AdaIN of the
  * activated tensor a; custom_layers.py:98-99 + stylegan/architectures.py:524-526).  These entry points let the CONSUMER of

@@ -196,16 +196,16 @@ def _judge_outliers(tag, bad, hip, cpu, exact, gmax64):
     return still, judged, ties
 
 
-def _layer_of(key):
-    """'g.gen_layers.10.1.noise_weight' -> 'g.gen_layers.10'; 'd.disc_blocks.3.0.0.conv2d.weight' -> 'd.disc_blocks.3'."""
-    parts = key.split('.')
-    return '.'.join(parts[:3]) if len(parts) > 3 and parts[2].isdigit() else '.'.join(parts[:2])
-
-
-def _assert_ties_in_one_layer(rep):
-    """The LeakyReLU tie exemption is a REPORT of one flipped mask bit; two layers showing it at once is not that."""
-    layers = {_layer_of(k) for k in rep.get('lrelu_tie_channels', {})}
-    assert len(layers) <= 1, rep['lrelu_tie_channels']
+def _assert_ties_are_rare(rep, n_entries):
+    """The LeakyReLU tie exemption is a REPORT of flipped mask bits, not a waiver: it may only concern a small part of
+    the network.  How often a flip must be expected: two fp32 implementations (and float64) disagree on a pre-activation
+    by ~1e-6 of its scale, so about 1e-6 of a layer's activations sit on the other side of zero - 4 x 128 x 128^2 = 8.4 M
+    activations at a 128^2 generator layer: a handful of flips per layer and step, each moving ONE channel's bias /
+    noise-weight sum (65 k terms of random sign) by ~0.8 / sqrt(65 k) = 3e-3 of its size.  Mid-resolution layers
+    therefore show one or two such channels on most draws (on the CPU fp32 path as well, in other channels); what must
+    not happen is the exemption carrying a sizeable share of the entries."""
+    ties = rep.get('lrelu_tie_channels', {})
+    assert len(ties) <= max(2, n_entries // 12), (len(ties), n_entries, ties)
 
 
 CASES = [('stylegan', 1024, 4, 'nonsaturating', 'r1'), ('progan', 256, 4, 'wgan', 'wgan-gp')]
@@ -257,7 +257,7 @@ def test_full_width_step_vs_oracle(kind, res, b, loss, gp, capsys):
         assert rep[k] <= TOL, (k, rep)
     assert not still, still
     assert len(ed) >= 20 and len(eg) >= 20
-    _assert_ties_in_one_layer(rep)
+    _assert_ties_are_rare(rep, len(ed) + len(eg))
 
 
 def test_stylegan128_bf16_b8_step_vs_oracle(capsys):
@@ -438,7 +438,7 @@ def test_learner_step_full_width_b8_vs_oracle(capsys):
         print(f'\nlearner d_step + g_step, StyleGAN-{res} b{b} full width, vs FunctionalGAN:', rep)
     assert rep['loss_d'] <= TOL and rep['loss_g'] <= TOL, rep
     assert not still, still
-    _assert_ties_in_one_layer(rep)
+    _assert_ties_are_rare(rep, len(ed) + len(eg))
     assert len(ed) >= 20 and len(eg) >= 20 and n_upd > 10 ** 6
     assert worst_upd[0] <= 2e-2, rep
     assert worst_lag[0] <= 1e-4, rep

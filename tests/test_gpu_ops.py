@@ -1014,3 +1014,51 @@ def test_affine_on_load_consumers_equal_materialised(ops, case):
     assert_close(outs[1], outs[0], 2e-5, 'output')
     for name, a, b in zip(['x0', 'bias0', 'noise_w0', 'style0', 'w1'], grads[1], grads[0]):
         assert_close(a, b, 2e-4, 'grad ' + name)
+
+
+def test_batched_repack_equals_single_packs(ops):
+    """csrc/pack.hip: after the fused optimiser reports the memory it rewrote, the FIRST request for a stale packed weight
+    re-packs every cached entry of that range in one launch - bit-identical to packing each weight on its own, entries
+    outside the range untouched (same buffers), new values picked up (Conv2dEx.forward re-scales on every call,
+    custom_layers.py:202-211; here the scaled re-layout is cached between optimiser steps)."""
+    from gan_lab_amd import _lib
+    gen = torch.Generator().manual_seed(5)
+    arena = torch.zeros(200000, device='cuda')
+    other = (rnd(gen, 24, 16, 3, 3)).cuda()                       # a weight OUTSIDE the rewritten range
+    shapes = [(32, 16, 3, 3), (16, 32, 3, 3), (64, 64, 3, 3), (3, 16, 1, 1), (40, 24, 3, 3)]
+    ws, off = [], 0
+    for sh in shapes:
+        n = int(np.prod(sh))
+        ws.append(arena[off:off + n].view(sh))
+        ws[-1].copy_(rnd(gen, *sh))
+        off += (n + 3) // 4 * 4
+
+    def requests():
+        out = []
+        for w in ws:
+            if w.shape[2] == 3:
+                out += [ops._packed(w, _lib.PACK_FWD, 0.1), ops._packed(w, _lib.PACK_DGRAD, 0.1),
+                        ops._packed(w, _lib.PACK_FWD, 0.2, s2_up=1), ops._packed(w, _lib.PACK_DGRAD, 0.2, s2_up=1),
+                        ops._packed(w, _lib.PACK_FWD, 0.3, s2_up=0), ops._packed(w, _lib.PACK_DGRAD, 0.3, s2_up=0)]
+                if w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+                    out += [ops._packed_bf16(w, _lib.PACK_FWD, 0.5), ops._packed_bf16(w, _lib.PACK_DGRAD, 0.5)]
+            else:
+                out += [ops._packed(w, _lib.PACK_FWD, 0.1), ops._packed(w, _lib.PACK_DGRAD, 0.1)]
+        return out
+    ops.bump_weight_epoch()
+    first = requests()
+    o_other = ops._packed(other, _lib.PACK_FWD, 0.7)
+    o_other_before = o_other.clone()
+    # the "optimiser": rewrite the arena through a raw view (no version bump on the parameter views), report the range
+    arena.mul_(-1.5)
+    ops.bump_weight_epoch([(arena.data_ptr(), arena.data_ptr() + arena.numel() * 4)])
+    again = requests()                                              # first call re-packs the whole range in one launch
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(first, again)), 're-packed in place'
+    assert ops._packed(other, _lib.PACK_FWD, 0.7).data_ptr() == o_other.data_ptr() and torch.equal(o_other, o_other_before)
+    batched = [t_.clone() for t_ in again]
+    ops.bump_weight_epoch()                                         # drop everything: single-weight kernels
+    single = requests()
+    assert len(single) == len(batched) >= 20
+    for a, b in zip(batched, single):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    ops.bump_weight_epoch()
