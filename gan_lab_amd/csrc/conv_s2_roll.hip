@@ -50,12 +50,16 @@ struct SRArgs {
 constexpr int SR_TW = 32;                 // low pixels per strip (64 high)
 constexpr int SR_CP = 80;                 // floats per channel row: E[e] = high[2(X0+e)] at e, O'[o] = high[2(X0+o)-1] at 41+o
 constexpr int SR_SLOT = 16 * SR_CP;       // one high row, 16 channels
-constexpr int SR_SLOTS = 10;              // rows 4t .. 4t+5 are read while 4t+6 .. 4t+9 are written
+#ifndef SR_NSLOTS
+#define SR_NSLOTS 10
+#endif
+constexpr int SR_SLOTS = SR_NSLOTS;       // 10: rows 4t .. 4t+5 are read while 4t+6 .. 4t+9 are written (one barrier per step); 6: they
+                                          // overwrite rows 4t .. 4t+3 behind a second barrier (31 KB instead of 51)
 constexpr int SR_Q = 18;                  // float4 per (row, channel): high columns 2X0-4 .. 2X0+67
 constexpr int SR_ITEMS = 4 * 16 * SR_Q;   // 1152 float4 per 4-row prefetch
 constexpr int SR_PT = (SR_ITEMS + 255) / 256;   // 5
 
-__global__ __launch_bounds__(256, 3) void conv_s2_down_roll_kernel(SRArgs p) {
+__global__ __launch_bounds__(256, (SR_NSLOTS == 6 ? 4 : 3)) void conv_s2_down_roll_kernel(SRArgs p) {
   __shared__ __attribute__((aligned(16))) float ring[SR_SLOTS * SR_SLOT];      // 51200 B: three workgroups per CU
   constexpr int NG = 16, PD = 2;            // 16 operand groups of 8 MFMAs per step; LDS prefetch distance
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_down_roll_kernel(SRArgs p) {
       if (g == 1) load_rows(4 * t + 6, t + 1 < nsteps ? 4 : 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_rows(4 * t + 6, 4);          // the four slots no wave reads in this step
+    if constexpr (SR_SLOTS == 10) store_rows(4 * t + 6, 4);          // the four slots no wave reads in this step
     const int Y = Ys + 2 * t + jrow;
     const int orow = Y * p.Wl * 4;
 #pragma unroll
@@ -185,6 +189,10 @@ __global__ __launch_bounds__(256, 3) void conv_s2_down_roll_kernel(SRArgs p) {
       acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                   // rows 4t .. 4t+3 are free for the next step's prefetch; 4t+6 .. 4t+9 complete
+    if constexpr (SR_SLOTS == 6) {
+      store_rows(4 * t + 6, 4);        // = the slots of rows 4t .. 4t+3
+      __syncthreads();
+    }
   }
 }
 

@@ -72,19 +72,38 @@ __global__ void blur3x3_kernel(const float* __restrict__ x, float* __restrict__ 
 // The neighbours come from the adjacent lanes (lane-1 holds columns x0-4..x0-1 of the same row whenever
 // q > 0) - only the first / last lane of a wave touches memory for them.  MASKED: the operand is
 // in * lrelu'(m) (the masked centre values are returned in cen).
-template <bool MASKED>
+// LeakyReLU masks as BITS (1 = the activation was positive): bit e of the NCHW-linear element index e, 32 per word.  A
+// pass that only needs sign(y) reads 1/32 of the bytes of y (the critic's conv -> LeakyReLU -> blur keeps no other use for
+// y in its backward: progan/architectures.py:261-284).  Rows must be whole words: W % 32 == 0.
+__device__ __forceinline__ unsigned mask_nibble(const unsigned* __restrict__ bits, long long e) {   // e % 4 == 0
+  return (bits[e >> 5] >> (unsigned)(e & 31)) & 0xFu;
+}
+__device__ __forceinline__ unsigned mask_bit(const unsigned* __restrict__ bits, long long e) {
+  return (bits[e >> 5] >> (unsigned)(e & 31)) & 1u;
+}
+
+template <bool MASKED, bool BITS = false>
 __device__ __forceinline__ void blur_row(const float* __restrict__ in, const float* __restrict__ m, long long ro,
                                          int x0, int q, int w4, bool valid, float slope, float (&hrow)[4],
-                                         float (&cen)[4]) {
+                                         float (&cen)[4], const unsigned* __restrict__ mb = nullptr,
+                                         long long mplane = 0) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid) {
     v = *reinterpret_cast<const float4*>(in + ro + x0);
     if (MASKED) {
-      const float4 mm = *reinterpret_cast<const float4*>(m + ro + x0);
-      v.x = mm.x > 0.f ? v.x : v.x * slope;
-      v.y = mm.y > 0.f ? v.y : v.y * slope;
-      v.z = mm.z > 0.f ? v.z : v.z * slope;
-      v.w = mm.w > 0.f ? v.w : v.w * slope;
+      if (BITS) {
+        const unsigned nb = mask_nibble(mb, mplane + ro + x0);
+        v.x = (nb & 1u) ? v.x : v.x * slope;
+        v.y = (nb & 2u) ? v.y : v.y * slope;
+        v.z = (nb & 4u) ? v.z : v.z * slope;
+        v.w = (nb & 8u) ? v.w : v.w * slope;
+      } else {
+        const float4 mm = *reinterpret_cast<const float4*>(m + ro + x0);
+        v.x = mm.x > 0.f ? v.x : v.x * slope;
+        v.y = mm.y > 0.f ? v.y : v.y * slope;
+        v.z = mm.z > 0.f ? v.z : v.z * slope;
+        v.w = mm.w > 0.f ? v.w : v.w * slope;
+      }
     }
   }
   const int lane = threadIdx.x & 63;
@@ -97,7 +116,10 @@ __device__ __forceinline__ void blur_row(const float* __restrict__ in, const flo
   if (valid && (need_l || need_r)) {
     const long long eo = ro + x0 + (need_l ? -1 : 4);
     e = in[eo];
-    if (MASKED) e = m[eo] > 0.f ? e : e * slope;
+    if (MASKED) {
+      if (BITS) e = mask_bit(mb, mplane + eo) ? e : e * slope;
+      else e = m[eo] > 0.f ? e : e * slope;
+    }
   }
   if (q == 0) l = 0.f;
   else if (lane == 0) l = e;
@@ -112,9 +134,10 @@ __device__ __forceinline__ void blur_row(const float* __restrict__ in, const flo
 
 // vectorised blur: one thread = 4 columns x R rows (W % 4 == 0, H % R == 0): R+2 row segments are read once
 // as float4 (edges by lane shuffle) and combined separably
-template <int R>
+template <int R, bool BITS = false>
 __global__ __launch_bounds__(256) void blur3x3_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          long long planes, int H, int W) {
+                                                          long long planes, int H, int W,
+                                                          unsigned* __restrict__ bits = nullptr) {
   const int w4 = W >> 2, hr = H / R;
   const long long total = planes * hr * w4;
   // all lanes of a wave run the same number of iterations (the shuffles need their neighbours alive)
@@ -130,10 +153,28 @@ __global__ __launch_bounds__(256) void blur3x3_vec_kernel(const float* __restric
     const float* px = x + pl * H * W;
     const int y0 = R * rr, x0 = 4 * q;
     float h[R + 2][4], cen[4];
+    [[maybe_unused]] unsigned nib[R];
 #pragma unroll
     for (int k = 0; k < R + 2; ++k) {
       const int yy = y0 - 1 + k;
       blur_row<false>(px, nullptr, (long long)yy * W, x0, q, w4, (unsigned)yy < (unsigned)H, 0.f, h[k], cen);
+      if constexpr (BITS) {
+        if (k >= 1 && k <= R)
+          nib[k - 1] = (cen[0] > 0.f ? 1u : 0u) | (cen[1] > 0.f ? 2u : 0u) | (cen[2] > 0.f ? 4u : 0u) | (cen[3] > 0.f ? 8u : 0u);
+      }
+    }
+    if constexpr (BITS) {
+      // BITS: the sign bits of the INPUT's own R rows, for the LeakyReLU backward of whoever produced it.  W % 32 == 0, so
+      // 8 consecutive lanes hold 32 consecutive pixels of one row and a group of 8 is live or dead as a whole
+      const int sh = 4 * (threadIdx.x & 7);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        unsigned wv = nib[k] << sh;
+        wv |= __shfl_xor(wv, 1, 64);
+        wv |= __shfl_xor(wv, 2, 64);
+        wv |= __shfl_xor(wv, 4, 64);
+        if (live && (threadIdx.x & 7) == 0) bits[(pl * H * W + (long long)(y0 + k) * W + x0) >> 5] = wv;
+      }
     }
     if (live) {
       float* py = y + pl * H * W + (long long)y0 * W + x0;
@@ -189,7 +230,7 @@ enum { BF_FWD = 0, BF_A = 1, BF_AT = 2 };
 // STATS (BF_FWD only): grid (chunks, C, N) - a block stays inside ONE (n, c) plane and also accumulates sum / sum of
 // squares of its outputs in fp64 (the InstanceNorm statistics of the next op: stylegan/architectures.py:524-526 reads
 // the tensor this kernel writes); block partials go to spart[((n*C + c)*chunks + chunk)*2 + {0,1}].
-template <int MODE, int R, bool STATS = false>
+template <int MODE, int R, bool STATS = false, bool BITS = false>   // BITS: y is a bit mask (mask_nibble), modes BF_A / BF_AT
 __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in, const float* __restrict__ y,
                                                          const float* __restrict__ noise,
                                                          const float* __restrict__ bias,
@@ -218,8 +259,9 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < R + 2; ++k) {
       const int yy = y0 - 1 + k;
-      blur_row<MODE == BF_AT>(in + plane, MODE == BF_AT ? y + plane : nullptr, (long long)yy * W, x0, q, w4,
-                              (unsigned)yy < (unsigned)H, slope, h[k], cen[k]);
+      blur_row<MODE == BF_AT, BITS>(in + plane, (MODE == BF_AT && !BITS) ? y + plane : nullptr, (long long)yy * W, x0, q,
+                                    w4, (unsigned)yy < (unsigned)H, slope, h[k], cen[k],
+                                    reinterpret_cast<const unsigned*>(y), plane);
     }
     if (!live) continue;
     const long long co = (long long)y0 * W + x0;
@@ -243,12 +285,21 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
           }
         }
       } else if (MODE == BF_A) {
-        float m[4];
-        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(y + plane + co + k * W);
+        if constexpr (BITS) {
+          const unsigned nb = mask_nibble(reinterpret_cast<const unsigned*>(y), plane + co + (long long)k * W);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[j] = m[j] > 0.f ? o[j] : o[j] * slope;
-          s0 += (double)o[j];
+          for (int j = 0; j < 4; ++j) {
+            o[j] = ((nb >> j) & 1u) ? o[j] : o[j] * slope;
+            s0 += (double)o[j];
+          }
+        } else {
+          float m[4];
+          *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(y + plane + co + k * W);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = m[j] > 0.f ? o[j] : o[j] * slope;
+            s0 += (double)o[j];
+          }
         }
       } else {
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
@@ -305,6 +356,14 @@ inline int blur_rows_mode(int H, int mode) {
     if (rows_ == 8) GL_LAUNCH((blur_fused_kernel<MODE, 8>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);      \
     else if (rows_ == 4) GL_LAUNCH((blur_fused_kernel<MODE, 4>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__); \
     else GL_LAUNCH((blur_fused_kernel<MODE, 2>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);                \
+  } while (0)
+
+#define BLUR_FUSED_LAUNCH_BITS(MODE, ...)                                                                            \
+  do {                                                                                                               \
+    const int rows_ = blur_rows_mode(H, MODE);                                                                       \
+    if (rows_ == 8) GL_LAUNCH((blur_fused_kernel<MODE, 8, false, true>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);      \
+    else if (rows_ == 4) GL_LAUNCH((blur_fused_kernel<MODE, 4, false, true>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__); \
+    else GL_LAUNCH((blur_fused_kernel<MODE, 2, false, true>), dim3(chunks, C), dim3(256), 0, ST, __VA_ARGS__);                \
   } while (0)
 
 inline int blur_fused_chunks(int N, int H, int W) {
@@ -1325,6 +1384,27 @@ int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W,
   return GL_CHECK_LAUNCH();
 }
 
+/* sign-bit masks (bit e of the NCHW-linear element index e set iff x[e] > 0): whole words per row */
+int ganlab_mask_bits_supported(int H, int W) { return (H >= 2 && (H & 1) == 0 && W >= 32 && (W & 31) == 0) ? 1 : 0; }
+
+/* y = blur(x) AND bits = sign bits of x (planes*H*W/32 words) in the same pass: the critic's conv -> LeakyReLU -> blur
+ * (progan/architectures.py:261-284) keeps only the SIGN of the LeakyReLU output for its backward */
+int ganlab_blur3x3_bits_f32(const float* x, float* y, unsigned* bits, long long planes, int H, int W, void* stream) {
+  if (!x || !y || !bits || planes <= 0) return GANLAB_EINVAL;
+  if (!ganlab_mask_bits_supported(H, W) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) != 0)
+    return GANLAB_EUNSUPPORTED;
+  if ((H & 7) == 0 && H >= 256)
+    GL_LAUNCH((blur3x3_vec_kernel<8, true>), dim3(ew_blocks(planes * (H / 8) * (W / 4))), dim3(256), 0, ST, x, y, planes, H,
+              W, bits);
+  else if ((H & 3) == 0)
+    GL_LAUNCH((blur3x3_vec_kernel<4, true>), dim3(ew_blocks(planes * (H / 4) * (W / 4))), dim3(256), 0, ST, x, y, planes, H,
+              W, bits);
+  else
+    GL_LAUNCH((blur3x3_vec_kernel<2, true>), dim3(ew_blocks(planes * (H / 2) * (W / 4))), dim3(256), 0, ST, x, y, planes, H,
+              W, bits);
+  return GL_CHECK_LAUNCH();
+}
+
 int ganlab_up2_f32(const float* x, float* y, long long planes, int H, int W, float scale, void* stream) {
   if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return GANLAB_EINVAL;
   GL_LAUNCH(up2_kernel, dim3(ew_blocks(planes * H * W * 4)), dim3(256), 0, ST, x, y, planes, H, W, scale);
@@ -1490,6 +1570,38 @@ int ganlab_blur_act_bwd_f32(const float* g, const float* y, float* out, float* g
   BLUR_FUSED_LAUNCH(BF_A, g, y, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, out,
                     (double*)workspace, N, C, H, W, chunks, 1.f, 0, slope, gb ? 1 : 0);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, bias_scale);
+  return GL_CHECK_LAUNCH();
+}
+
+/* ganlab_blur_act_bwd_f32 with the activation's sign bits (ganlab_blur3x3_bits_f32) in place of y */
+int ganlab_blur_act_bwd_bits_f32(const float* g, const unsigned* ybits, float* out, float* gb, int N, int C, int H, int W,
+                                 float slope, float bias_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !ybits || !out || N <= 0 || C <= 0) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W) || !ganlab_mask_bits_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  const int chunks = blur_fused_chunks(N, H, W);
+  if (gb && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(double))) return GANLAB_EWORKSPACE;
+  BLUR_FUSED_LAUNCH_BITS(BF_A, g, reinterpret_cast<const float*>(ybits), (const float*)nullptr, (const float*)nullptr,
+                         (const float*)nullptr, out, (double*)workspace, N, C, H, W, chunks, 1.f, 0, slope, gb ? 1 : 0);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, bias_scale);
+  return GL_CHECK_LAUNCH();
+}
+
+/* ganlab_act_bwd_blur_f32 (its adjoint) with sign bits in place of y */
+int ganlab_act_bwd_blur_bits_f32(const float* g, const unsigned* ybits, const float* noise, float* out, float* gb,
+                                 float* gnw, int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!g || !ybits || !out || N <= 0 || C <= 0 || (gnw && !noise)) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W) || !ganlab_mask_bits_supported(H, W)) return GANLAB_EUNSUPPORTED;
+  const int chunks = blur_fused_chunks(N, H, W);
+  const int sums = (gb || gnw) ? 1 : 0;
+  if (sums && (!workspace || workspace_bytes < (size_t)2 * C * chunks * sizeof(double))) return GANLAB_EWORKSPACE;
+  BLUR_FUSED_LAUNCH_BITS(BF_AT, g, reinterpret_cast<const float*>(ybits), gnw ? noise : (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, out, (double*)workspace, N, C, H, W, chunks, 1.f, 0,
+                         slope, sums);
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace, gb, C, chunks, bias_scale);
+  if (gnw)
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)workspace + (size_t)C * chunks, gnw, C,
+              chunks, 1.f);
   return GL_CHECK_LAUNCH();
 }
 

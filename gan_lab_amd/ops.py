@@ -567,6 +567,33 @@ def k_blur(x):
     return y
 
 
+_MASK_BITS = [None]
+
+
+def mask_bits_ok(x):
+    """The LeakyReLU backward of this (N,C,H,W) activation can run from its sign BITS (rows of whole 32-bit words):
+    GANLAB_MASK_BITS=0 keeps the float tensor (A/B knob)."""
+    if _MASK_BITS[0] is None:
+        import os
+        _MASK_BITS[0] = os.environ.get('GANLAB_MASK_BITS') != '0'
+    return _MASK_BITS[0] and x.dim() == 4 and bool(_lib.lib().ganlab_mask_bits_supported(int(x.shape[2]), int(x.shape[3])))
+
+
+def k_blur_bits(x):
+    """(blur(x), sign bits of x): the bits are all the LeakyReLU backward of x's producer needs (int32 words, bit e of the
+    NCHW-linear element index e set iff x[e] > 0)."""
+    x = _c(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    bits = torch.empty((x.numel() // 32,), dtype=torch.int32, device=x.device)
+    check(_lib.lib().ganlab_blur3x3_bits_f32(_p(x), _p(y), bits.data_ptr(), n * c, h, w, _st()), 'blur3x3_bits')
+    return y, bits
+
+
+def _is_bits(y):
+    return y.dtype == torch.int32
+
+
 def decode_u8(images_u8_nhwc, res, mean, std, flip=None):
     """Real-image input path on the device: (N,Hs,Ws,C) uint8 -> box-downsample by the
     power-of-two factor Hs/res (bit-exact with PIL's BOX resize) -> (N,C,res,res) fp32 ``(v/255 - mean)/std``
@@ -653,25 +680,40 @@ def k_bias_act_stats(x, bias, noise, noise_w, bias_scale, act, slope, eps):
 
 
 def k_blur_act_bwd(g, y, slope, bias_scale, want_gb):
-    g, y = _c(g), _c(y)
-    assert g.shape == y.shape
+    """``y``: the LeakyReLU output, or its sign bits (``k_blur_bits``)."""
+    g = _c(g)
     n, c, h, w = g.shape
     out = torch.empty_like(g)
     gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
     ws = _blur_ws(g) if want_gb else None
+    if _is_bits(y):
+        assert y.numel() * 32 == g.numel()
+        check(_lib.lib().ganlab_blur_act_bwd_bits_f32(_p(g), y.data_ptr(), _p(out), _p(gb), n, c, h, w, slope, bias_scale,
+                                                      _p(ws), ws.numel() * 4 if ws is not None else 0, _st()),
+              'blur_act_bwd_bits')
+        return out, gb
+    y = _c(y)
+    assert g.shape == y.shape
     check(_lib.lib().ganlab_blur_act_bwd_f32(_p(g), _p(y), _p(out), _p(gb), n, c, h, w, slope, bias_scale, _p(ws),
                                              ws.numel() * 4 if ws is not None else 0, _st()), 'blur_act_bwd')
     return out, gb
 
 
 def k_act_bwd_blur(g, y, noise, slope, bias_scale, want_gb, want_gnw):
-    g, y = _c(g), _c(y)
-    assert g.shape == y.shape
+    g = _c(g)
     n, c, h, w = g.shape
     out = torch.empty_like(g)
     gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
     gnw = torch.empty(c, dtype=torch.float32, device=g.device) if want_gnw else None
     ws = _blur_ws(g) if (want_gb or want_gnw) else None
+    if _is_bits(y):
+        assert y.numel() * 32 == g.numel()
+        check(_lib.lib().ganlab_act_bwd_blur_bits_f32(_p(g), y.data_ptr(), _p(_c(noise)) if want_gnw else None, _p(out),
+                                                      _p(gb), _p(gnw), n, c, h, w, slope, bias_scale, _p(ws),
+                                                      ws.numel() * 4 if ws is not None else 0, _st()), 'act_bwd_blur_bits')
+        return out, gb, gnw
+    y = _c(y)
+    assert g.shape == y.shape
     check(_lib.lib().ganlab_act_bwd_blur_f32(_p(g), _p(y), _p(_c(noise)) if want_gnw else None, _p(out), _p(gb),
                                              _p(gnw), n, c, h, w, slope, bias_scale, _p(ws),
                                              ws.numel() * 4 if ws is not None else 0, _st()), 'act_bwd_blur')
@@ -990,9 +1032,9 @@ class _BlurActBwd(Function):
 
     @staticmethod
     def forward(ctx, g, y, slope, bias_scale, want_gb):
-        ctx.save_for_backward(y)
+        ctx.save_for_backward(y)          # the LeakyReLU output, or its sign bits (k_blur_bits)
         ctx.set_materialize_grads(False)
-        ctx.slope, ctx.bias_scale = slope, bias_scale
+        ctx.slope, ctx.bias_scale, ctx.gshape = slope, bias_scale, g.shape
         return k_blur_act_bwd(g, y, slope, bias_scale, want_gb)
 
     @staticmethod
@@ -1000,7 +1042,7 @@ class _BlurActBwd(Function):
         y, = ctx.saved_tensors
         g = gout
         if ggb is not None:
-            shape = y.shape
+            shape = ctx.gshape
             b = _Scale.apply(ggb.view(1, shape[1], 1, 1).expand(shape), ctx.bias_scale)
             g = b if g is None else _Axpby.apply(g, b, 1.0, 1.0)
         if g is None:
@@ -1088,13 +1130,19 @@ class _ConvBiasAct(Function):
         # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
-        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer) else None)
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
         ctx.defer, ctx.in_slope = bool(defer), in_slope
         assert not (defer and blur)
         ctx.bias_shape = bias.shape if bias is not None else None
         # blur=True: the D block's  conv -> bias -> LeakyReLU -> blur  (progan/architectures.py:280-293);
         # forward is conv kernel + blur kernel, backward is ONE pass (blur^T, LeakyReLU', bias gradient)
+        if blur and act != ACT_NONE and mask_bits_ok(y):
+            # the backward only ever needs sign(y): the blur pass emits it as bits and y itself is not kept (a 2 GiB
+            # tensor per pass at the top of the critic; the backward passes read 1/32 of its bytes)
+            out, bits = k_blur_bits(y)
+            ctx.save_for_backward(x, w, bits)
+            return out
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer) else None)
         return k_blur(y) if blur else y
 
     @staticmethod

@@ -356,6 +356,19 @@ int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, vo
 int ganlab_u8_box_decode_f32(const unsigned char* in_nhwc, float* out_nchw, int N, int Hs, int Ws, int C, int factor,
                              const float* mean, const float* stdv, const unsigned char* flip, void* stream);
 
+/* ---- LeakyReLU masks as bits ------------------------------------------------------------------------------------------
+ * The critic's block conv -> bias -> LeakyReLU -> blur (progan/architectures.py:261-284) needs only sign(y) of the LeakyReLU
+ * output y in its backward (nn.LeakyReLU backward: grad * (y > 0 ? 1 : slope)): the blur pass that reads y emits the sign
+ * bits (bit e of the NCHW-linear element index, 32 per word; W % 32 == 0), the backward passes read 1/32 of the bytes and y
+ * itself is not kept. */
+int ganlab_mask_bits_supported(int H, int W);
+int ganlab_blur3x3_bits_f32(const float* x, float* y, unsigned* bits, long long planes, int H, int W, void* stream);
+int ganlab_blur_act_bwd_bits_f32(const float* g, const unsigned* ybits, float* out, float* gb, int N, int C, int H, int W,
+                                 float slope, float bias_scale, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_act_bwd_blur_bits_f32(const float* g, const unsigned* ybits, const float* noise, float* out, float* gb,
+                                 float* gnw, int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* ---- all weight re-layouts of a network in ONE launch (csrc/pack.hip) -------------------------------------------------
  * The packed forms ganlab_conv_pack_f32 / ganlab_conv_s2_pack_f32 / ganlab_conv_pack_bf16 produce, rebuilt for a whole
  * table of weights after the optimiser rewrote them (Conv2dEx.forward multiplies by wscale on every call,

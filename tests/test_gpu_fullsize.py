@@ -167,10 +167,11 @@ def _without_tie_channels(k, hip, ex, scale):
         per = e.flatten(1).max(dim=1).values
     else:
         return None, []
-    if per.numel() <= 8 * MAX_TIE_CHANNELS:
+    if per.numel() < 16:
         return None, []
+    limit = MAX_TIE_CHANNELS if per.numel() > 16 else 1        # a 16-channel layer: ONE channel at most
     order = per.argsort(descending=True)
-    drop = [int(i) for i in order[:MAX_TIE_CHANNELS] if per[i] / scale > TOL]
+    drop = [int(i) for i in order[:limit] if per[i] / scale > TOL]
     keep = torch.ones_like(per, dtype=torch.bool)
     keep[drop] = False
     return (per[keep].max() / scale).item(), drop
@@ -192,7 +193,12 @@ def _judge_outliers(tag, bad, hip, cpu, exact, gmax64):
             if e_rest is not None and dropped and e_rest <= bar:
                 ties[tag + k] = dict(channels=dropped, err_all='%.2e' % e_hip, err_other_channels='%.2e' % e_rest)
             else:
-                still[tag + k] = (e_hip, e_cpu)
+                d = (hip[k].double() - exact[k]).abs()
+                per = d.flatten() if d.dim() <= 1 or k.endswith('bias') or k.endswith('noise_weight') else \
+                    d.flatten(1).max(dim=1).values
+                top = per.flatten().topk(min(3, per.numel()))
+                still[tag + k] = (e_hip, e_cpu, 'worst channels (error / scale): ' + ', '.join(
+                    '%d: %.1e' % (int(i), float(v) / scale) for v, i in zip(top.values, top.indices)))
     return still, judged, ties
 
 

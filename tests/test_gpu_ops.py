@@ -1049,8 +1049,10 @@ def test_batched_repack_equals_single_packs(ops):
     first = requests()
     o_other = ops._packed(other, _lib.PACK_FWD, 0.7)
     o_other_before = o_other.clone()
-    # the "optimiser": rewrite the arena through a raw view (no version bump on the parameter views), report the range
-    arena.mul_(-1.5)
+    # the "optimiser": rewrite the arena through a raw pointer, like FusedAdam's kernel (an in-place torch op would bump the
+    # version counter the views share with their base, i.e. new cache keys), and report the range
+    check = ops.check
+    check(_lib.lib().ganlab_axpby_f32(ops._p(arena), None, ops._p(arena), arena.numel(), -1.5, 0.0, ops._st()), 'axpby')
     ops.bump_weight_epoch([(arena.data_ptr(), arena.data_ptr() + arena.numel() * 4)])
     again = requests()                                              # first call re-packs the whole range in one launch
     assert all(a.data_ptr() == b.data_ptr() for a, b in zip(first, again)), 're-packed in place'
@@ -1062,3 +1064,31 @@ def test_batched_repack_equals_single_packs(ops):
     for a, b in zip(batched, single):
         assert a.dtype == b.dtype and torch.equal(a, b)
     ops.bump_weight_epoch()
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64), (3, 5, 24, 32), (1, 8, 256, 64), (2, 4, 6, 96)],
+                         ids=['16ch 32x64', 'odd channels 24x32', '8-row strips', '2-row strips'])
+def test_leaky_relu_mask_bits_equal_float_masks(ops, shape, monkeypatch):
+    """The critic's conv -> bias -> LeakyReLU -> blur with the LeakyReLU's sign kept as BITS (written by the blur pass,
+    csrc/pointwise.hip) instead of the float tensor: forward, first-order gradients (input, weight, bias) and the R1-shaped
+    second order are BIT-identical to the float-mask path (progan/architectures.py:261-284; nn.LeakyReLU backward)."""
+    n, c, h, w = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()))
+    x0 = rnd(gen, n, c, h, w)
+    wt0, b0 = rnd(gen, c, c, 3, 3), rnd(gen, c)
+    cot = rnd(gen, n, c, h, w).cuda()
+
+    def run(bits_on):
+        monkeypatch.setattr(ops, '_MASK_BITS', [bits_on])
+        x = x0.cuda().requires_grad_(True)
+        wt, b = wt0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        y = ops.conv2d(x, wt, b, scale=0.1, padding=1, act='lrelu', blur=True)
+        gx, = torch.autograd.grad((y * cot).sum(), x, create_graph=True)
+        pen = (gx ** 2).sum()                                       # R1-shaped: differentiate the input gradient again
+        gw2, gb2 = torch.autograd.grad(pen, (wt, b), retain_graph=True, allow_unused=True)
+        gw1, gb1 = torch.autograd.grad((y * cot).sum(), (wt, b))
+        return [t_.detach() for t_ in (y, gx, gw1, gb1, gw2)]
+    a, b_ = run(True), run(False)
+    assert ops.mask_bits_ok(x0.cuda()) or not ops._MASK_BITS[0]
+    for name, u, v in zip(['y', 'gx', 'gw', 'gb', 'gw (second order)'], a, b_):
+        assert torch.equal(u, v), name
