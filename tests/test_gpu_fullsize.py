@@ -421,17 +421,23 @@ def test_learner_step_full_width_b8_vs_oracle(capsys):
                 a for a, _ in j.values()), entries_beyond_strict_rule=len(s_), entries=len(j))
             if s_ and not (ratios[len(ratios) // 2] <= 5.0 and max(a for a, _ in j.values()) <= 3e-2):
                 still.update(s_)
-    # Adam (beta1 = 0) normalises the step to ~lr * sign(g): where |g| is significant the update must agree to 2 % of
-    # the step size; prev_torgb / prev_fromrgb are outside the optimiser in the stabilised phase and must not move
+    # Adam (beta1 = 0, first step) moves every element by lr * g / (|g| + eps), i.e. by ~lr * sign(g): the update is checked
+    # where the SIGN of the gradient is certain - elements above 1e-3 of the tensor's largest and above 8x the largest
+    # difference between the two fp32 paths on that tensor (the generator's entries carry the common-mode noise discussed
+    # above; below that threshold a flipped sign is a full 2 * lr, on either path) - and must agree to 2 % of the step size;
+    # prev_torgb / prev_fromrgb are outside the optimiser in the stabilised phase and must not move
     n_upd, worst_upd = 0, (0.0, None)
-    for tag, new, old, ref, grads in (('g.', new_g, sd_g, cpu['g'], cpu['gg']), ('d.', new_d, sd_d, cpu['d'], cpu['gd'])):
+    for tag, new, old, ref, grads, mine in (('g.', new_g, sd_g, cpu['g'], cpu['gg'], gg),
+                                            ('d.', new_d, sd_d, cpu['d'], cpu['gd'], gd)):
         for k, v0 in old.items():
             du, du_ref = new[k] - v0, ref[k] - v0
             if du_ref.abs().max() == 0:
                 assert du.abs().max() == 0, tag + k
                 continue
             g = grads[k]
-            m = g.abs() > 1e-3 * g.abs().max()
+            m = g.abs() > max(1e-3 * g.abs().max().item(), 8.0 * (mine[k] - g).abs().max().item())
+            if not bool(m.any()):
+                continue
             e = ((du - du_ref)[m].abs().max() / du_ref[m].abs().max()).item()
             n_upd += int(m.sum())
             if e > worst_upd[0]:
