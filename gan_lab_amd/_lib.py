@@ -76,6 +76,10 @@ SIGNATURES = {
                                               _c_p, _c_sz, _c_p]),
     'ganlab_act_bwd_blur_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                               _c_f, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_fwd_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_dgrad_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
+    'ganlab_conv_fwd_mask_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
+    'ganlab_conv_wgrad_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_pack_desc_size': (_c_int, []),
     'ganlab_pack_many': (_c_int, [_c_p, _c_int, _c_ll, _c_p]),
     'ganlab_in_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),

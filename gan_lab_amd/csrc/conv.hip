@@ -1476,11 +1476,22 @@ struct PwArgs {
   // OUTPUT (mask: N x Cout planes), many_to_few its INPUT (mask: N x Cin planes) - the fromRGB activation's backward
   const float* mask;
   float mslope;
+  // masks as sign BITS (bit e of the NCHW-linear element index e, 32 per word; planes of whole words: H*W % 32 == 0):
+  // mask_bits: `mask` points to such words instead of floats; out_bits (few_to_many only): also write the sign bits of y
+  int mask_bits;
+  unsigned* out_bits;
 };
 
 __device__ __forceinline__ float4 pw_masked(float4 v, float4 m, float sl) {
   v.x = m.x > 0.f ? v.x : v.x * sl; v.y = m.y > 0.f ? v.y : v.y * sl;
   v.z = m.z > 0.f ? v.z : v.z * sl; v.w = m.w > 0.f ? v.w : v.w * sl;
+  return v;
+}
+
+__device__ __forceinline__ float4 pw_masked_bits(float4 v, const unsigned* __restrict__ bits, long long e, float sl) {
+  const unsigned nb = (bits[e >> 5] >> (unsigned)(e & 31)) & 0xFu;      // e % 4 == 0
+  v.x = (nb & 1u) ? v.x : v.x * sl; v.y = (nb & 2u) ? v.y : v.y * sl;
+  v.z = (nb & 4u) ? v.z : v.z * sl; v.w = (nb & 8u) ? v.w : v.w * sl;
   return v;
 }
 
@@ -1504,9 +1515,23 @@ __global__ __launch_bounds__(256) void pw_few_to_many_kernel(PwArgs p) {
       if (p.act == GANLAB_ACT_LRELU) {
         a.x = gl_lrelu(a.x, p.slope); a.y = gl_lrelu(a.y, p.slope); a.z = gl_lrelu(a.z, p.slope); a.w = gl_lrelu(a.w, p.slope);
       }
-      if (p.mask != nullptr)
-        a = pw_masked(a, (reinterpret_cast<const float4*>(p.mask) + n * p.Cout * p.hw4 + q)[(long long)co * p.hw4], p.mslope);
+      if (p.mask != nullptr) {
+        if (p.mask_bits)
+          a = pw_masked_bits(a, reinterpret_cast<const unsigned*>(p.mask), ((n * p.Cout + co) * p.hw4 + q) * 4, p.mslope);
+        else
+          a = pw_masked(a, (reinterpret_cast<const float4*>(p.mask) + n * p.Cout * p.hw4 + q)[(long long)co * p.hw4], p.mslope);
+      }
       yb[(long long)co * p.hw4] = a;
+      if (p.out_bits != nullptr) {
+        // sign bits of this output: 8 consecutive lanes hold 32 consecutive pixels of one plane (hw4 % 8 == 0, so a group of
+        // 8 lanes is inside one image and active or inactive as a whole)
+        unsigned wv = ((a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u))
+                      << (4 * (threadIdx.x & 7));
+        wv |= __shfl_xor(wv, 1, 64);
+        wv |= __shfl_xor(wv, 2, 64);
+        wv |= __shfl_xor(wv, 4, 64);
+        if ((threadIdx.x & 7) == 0) p.out_bits[(((n * p.Cout + co) * p.hw4 + q) * 4) >> 5] = wv;
+      }
     }
   }
 }
@@ -1522,10 +1547,16 @@ __global__ __launch_bounds__(256) void pw_many_to_few_kernel(PwArgs p) {
       const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] * p.bias_scale : 0.f;
       a[co] = float4{b, b, b, b};
     }
-    const float4* mb = p.mask != nullptr ? reinterpret_cast<const float4*>(p.mask) + n * p.Cin * p.hw4 + q : nullptr;
+    const float4* mb = (p.mask != nullptr && !p.mask_bits) ? reinterpret_cast<const float4*>(p.mask) + n * p.Cin * p.hw4 + q
+                                                           : nullptr;
     for (int ci = 0; ci < p.Cin; ++ci) {
       float4 v = xb[(long long)ci * p.hw4];
-      if (mb != nullptr) v = pw_masked(v, mb[(long long)ci * p.hw4], p.mslope);
+      if (p.mask != nullptr) {
+        if (p.mask_bits)
+          v = pw_masked_bits(v, reinterpret_cast<const unsigned*>(p.mask), ((n * p.Cin + ci) * p.hw4 + q) * 4, p.mslope);
+        else
+          v = pw_masked(v, mb[(long long)ci * p.hw4], p.mslope);
+      }
 #pragma unroll
       for (int co = 0; co < 4; ++co) {
         const float w = co < p.Cout ? p.wp[(long long)ci * p.Cout_p + co] : 0.f;
@@ -1552,7 +1583,7 @@ __global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restr
                                                             float* __restrict__ part, int N, int B, int b0, int S,
                                                             long long hw4, int Btot,
                                                             const float* __restrict__ mask = nullptr, float mslope = 1.f,
-                                                            int ones = 0) {
+                                                            int ones = 0, int mask_bits = 0) {
   __shared__ float red[4][64];
   float acc[16][4];
 #pragma unroll
@@ -1573,7 +1604,12 @@ __global__ __launch_bounds__(256) void pw_cross_sums_kernel(const float* __restr
     float4 bv[16];        // all loads first (independent, in flight together), then the multiply-adds
 #pragma unroll
     for (int b = 0; b < 16; ++b) bv[b] = b < B ? bb[(long long)b * hw4] : float4{0.f, 0.f, 0.f, 0.f};
-    if (mask != nullptr) {
+    if (mask != nullptr && mask_bits) {
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        if (b < B)
+          bv[b] = pw_masked_bits(bv[b], reinterpret_cast<const unsigned*>(mask), ((n * Btot + b0 + b) * hw4 + q) * 4, mslope);
+    } else if (mask != nullptr) {
       const float4* mk = reinterpret_cast<const float4*>(mask) + (n * Btot + b0) * hw4 + q;
 #pragma unroll
       for (int b = 0; b < 16; ++b)
@@ -1679,7 +1715,7 @@ int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
 int run_conv(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Hi, int Wi,
              int Cout, int ks, int pad, int up, float bias_scale, int act, float slope, hipStream_t st,
              const float* pw_mask = nullptr, float pw_mslope = 1.f, const float* out_mask = nullptr,
-             float* splitk_ws = nullptr, int ksplit = 1) {
+             float* splitk_ws = nullptr, int ksplit = 1, int pw_mask_bits = 0, unsigned* pw_out_bits = nullptr) {
   if (!x || !wp || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Hi <= 0 || Wi <= 0) return GANLAB_EINVAL;
   ConvArgs a{};
   a.in = make_patch(x, N, Cin, Hi, Wi, pad, up);
@@ -1698,13 +1734,16 @@ int run_conv(const float* x, const float* wp, const float* bias, float* y, int N
     q.hw4 = (long long)Hi * Wi / 4;
     q.bias_scale = bias_scale; q.slope = slope; q.act = act;
     q.mask = pw_mask; q.mslope = pw_mslope;
+    q.mask_bits = pw_mask_bits; q.out_bits = pw_out_bits;
+    if ((pw_mask_bits || pw_out_bits != nullptr) && ((q.hw4 & 7) != 0 || (pw_out_bits != nullptr && Cin > 4)))
+      return GANLAB_EUNSUPPORTED;
     const long long items = (long long)N * q.hw4;
     const unsigned blocks = (unsigned)((items + 255) / 256 < 256 * 16 ? (items + 255) / 256 : 256 * 16);
     if (Cin <= 4) GL_LAUNCH(pw_few_to_many_kernel, dim3(blocks), dim3(256), 0, st, q);
     else GL_LAUNCH(pw_many_to_few_kernel, dim3(blocks), dim3(256), 0, st, q);
     return GL_CHECK_LAUNCH();
   }
-  if (pw_mask != nullptr) return GANLAB_EUNSUPPORTED;             // only the streaming 1x1 kernels fold the mask in
+  if (pw_mask != nullptr || pw_out_bits != nullptr) return GANLAB_EUNSUPPORTED;   // only the streaming 1x1 kernels fold the mask in
   if (ksplit > 1) {
     if (splitk_ws == nullptr || out_mask != nullptr || up) return GANLAB_EINVAL;
     const long long total = (long long)N * Cout * a.Ho * a.Wo;
@@ -2011,6 +2050,57 @@ int ganlab_conv_wgrad_act_f32(const float* gy, const float* y, const float* x, f
     const int B = g->Cout - b0 < 16 ? g->Cout - b0 : 16;
     GL_LAUNCH(pw_cross_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gy, x, (float*)workspace, g->N, B, b0,
               g->Cin, hw4, g->Cout, y, slope, gb ? 1 : 0);
+    GL_LAUNCH(pw_cross_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, gw, (int)blocks, B, b0,
+              g->Cin, g->Cout, g->Cin, 1, scale, gb, bias_scale);
+  }
+  return GL_CHECK_LAUNCH();
+}
+
+/* The same four with the LeakyReLU mask as sign BITS (ganlab_mask_bits_supported: planes of whole 32-bit words): the forward
+ * writes y AND its sign bits, the three gradient kernels read the bits instead of y (fromRGB at the top of the critic:
+ * progan/architectures.py:286-292; 16 channels x 1024^2 x batch: 2 GiB of mask reads per pass become 64 MiB). */
+int ganlab_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
+                             const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream) {
+  if (!x || !wp || !y || !ybits) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || ((long long)g->Hin * g->Win) % 32 != 0 || !aligned16(x) || !aligned16(y))
+    return GANLAB_EUNSUPPORTED;
+  return run_conv(x, wp, bias, y, g->N, g->Cin, g->Hin, g->Win, g->Cout, 1, 0, 0, bias_scale, act, slope, gl_stream(stream),
+                  nullptr, 1.f, nullptr, nullptr, 1, 0, ybits);
+}
+
+int ganlab_conv_dgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* wp, float* gx,
+                                   const ganlab_conv_geom* g, float slope, void* stream) {
+  if (!gy || !ybits || !wp || !gx) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || ((long long)g->Hin * g->Win) % 32 != 0 || !aligned16(gy) || !aligned16(gx))
+    return GANLAB_EUNSUPPORTED;
+  return run_conv(gy, wp, nullptr, gx, g->N, g->Cout, g->Hin, g->Win, g->Cin, 1, 0, 0, 0.f, GANLAB_ACT_NONE, 0.f,
+                  gl_stream(stream), reinterpret_cast<const float*>(ybits), slope, nullptr, nullptr, 1, 1);
+}
+
+int ganlab_conv_fwd_mask_bits_f32(const float* x, const float* wp, const unsigned* ybits, float* out,
+                                  const ganlab_conv_geom* g, float slope, void* stream) {
+  if (!x || !ybits || !wp || !out) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || ((long long)g->Hin * g->Win) % 32 != 0 || !aligned16(x) || !aligned16(out))
+    return GANLAB_EUNSUPPORTED;
+  return run_conv(x, wp, nullptr, out, g->N, g->Cin, g->Hin, g->Win, g->Cout, 1, 0, 0, 0.f, GANLAB_ACT_NONE, 0.f,
+                  gl_stream(stream), reinterpret_cast<const float*>(ybits), slope, nullptr, nullptr, 1, 1);
+}
+
+int ganlab_conv_wgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* x, float* gw, float* gb,
+                                   const ganlab_conv_geom* g, float scale, float bias_scale, float slope, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (!gy || !ybits || !x || !gw) return GANLAB_EINVAL;
+  if (!ganlab_conv_act_bwd_fused_supported(g) || ((long long)g->Hin * g->Win) % 32 != 0 || !aligned16(gy) || !aligned16(x))
+    return GANLAB_EUNSUPPORTED;
+  long long blocks = (long long)(workspace_bytes / (64 * sizeof(float)));
+  if (blocks > 1024) blocks = 1024;
+  if (!workspace || blocks < 64) return GANLAB_EWORKSPACE;
+  const long long hw4 = (long long)g->Hin * g->Win / 4;
+  hipStream_t st = gl_stream(stream);
+  for (int b0 = 0; b0 < g->Cout; b0 += 16) {
+    const int B = g->Cout - b0 < 16 ? g->Cout - b0 : 16;
+    GL_LAUNCH(pw_cross_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gy, x, (float*)workspace, g->N, B, b0,
+              g->Cin, hw4, g->Cout, reinterpret_cast<const float*>(ybits), slope, gb ? 1 : 0, 1);
     GL_LAUNCH(pw_cross_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, gw, (int)blocks, B, b0,
               g->Cin, g->Cout, g->Cin, 1, scale, gb, bias_scale);
   }

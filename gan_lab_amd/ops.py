@@ -481,36 +481,68 @@ def conv_act_bwd_fusable(g):
 
 
 def k_conv_dgrad_act(gy, y, w, g, scale, slope):
-    gy, y, w = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(w, 'conv weight')
-    assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape
+    """``y``: the conv's activated output, or its sign bits (``k_conv_fwd_bits``)."""
+    gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
+    assert tuple(gy.shape) == g.out_shape
     _note('dgrad', g)
     gx = _new(g.in_shape, gy)
+    if _is_bits(y):
+        check(_lib.lib().ganlab_conv_dgrad_act_bits_f32(_p(gy), y.data_ptr(), _p(_packed(w, PACK_DGRAD, scale)), _p(gx),
+                                                        g.ref(), slope, _st()), 'conv_dgrad_act_bits')
+        return gx
+    y = _c(y, 'conv output')
+    assert tuple(y.shape) == g.out_shape
     check(_lib.lib().ganlab_conv_dgrad_act_f32(_p(gy), _p(y), _p(_packed(w, PACK_DGRAD, scale)), _p(gx), g.ref(), slope,
                                                _st()), 'conv_dgrad_act')
     return gx
 
 
 def k_conv_fwd_mask(x, w, y, g, scale, slope):
-    x, y, w = _c(x, 'conv input'), _c(y, 'conv output'), _c(w, 'conv weight')
-    assert tuple(x.shape) == g.in_shape and tuple(y.shape) == g.out_shape
+    x, w = _c(x, 'conv input'), _c(w, 'conv weight')
+    assert tuple(x.shape) == g.in_shape
     _note('fwd', g)
-    out = torch.empty_like(y)
+    out = _new(g.out_shape, x)
+    if _is_bits(y):
+        check(_lib.lib().ganlab_conv_fwd_mask_bits_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), y.data_ptr(), _p(out), g.ref(),
+                                                       slope, _st()), 'conv_fwd_mask_bits')
+        return out
+    y = _c(y, 'conv output')
+    assert tuple(y.shape) == g.out_shape
     check(_lib.lib().ganlab_conv_fwd_mask_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), _p(y), _p(out), g.ref(), slope,
                                               _st()), 'conv_fwd_mask')
     return out
 
 
 def k_conv_wgrad_act(gy, y, x, g, scale, slope, bias_scale, want_gb):
-    gy, y, x = _c(gy, 'conv grad_out'), _c(y, 'conv output'), _c(x, 'conv input')
-    assert tuple(gy.shape) == g.out_shape and tuple(y.shape) == g.out_shape and tuple(x.shape) == g.in_shape
+    gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
+    assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     _note('wgrad', g)
     L = _lib.lib()
     gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
     gb = _new((g.Cout,), x) if want_gb else None
     ws = torch.empty((max(L.ganlab_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    if _is_bits(y):
+        check(L.ganlab_conv_wgrad_act_bits_f32(_p(gy), y.data_ptr(), _p(x), _p(gw), _p(gb), g.ref(), scale, bias_scale, slope,
+                                               _p(ws), ws.numel() * 4, _st()), 'conv_wgrad_act_bits')
+        return gw, gb
+    y = _c(y, 'conv output')
+    assert tuple(y.shape) == g.out_shape
     check(L.ganlab_conv_wgrad_act_f32(_p(gy), _p(y), _p(x), _p(gw), _p(gb), g.ref(), scale, bias_scale, slope, _p(ws),
                                       ws.numel() * 4, _st()), 'conv_wgrad_act')
     return gw, gb
+
+
+def k_conv_fwd_bits(x, w, bias, g, scale, bias_scale, act, slope):
+    """fromRGB forward that also writes the sign bits of its activated output (the mask of its own backward)."""
+    x, w = _c(x, 'conv input'), _c(w, 'conv weight')
+    assert tuple(x.shape) == g.in_shape
+    _note('fwd', g)
+    y = _new(g.out_shape, x)
+    bits = torch.empty((y.numel() // 32,), dtype=torch.int32, device=x.device)
+    check(_lib.lib().ganlab_conv_fwd_bits_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), _p(_c(bias, 'bias')) if bias is not None
+                                              else None, _p(y), bits.data_ptr(), g.ref(), bias_scale, act, slope, _st()),
+          'conv_fwd_bits')
+    return y, bits
 
 
 def k_conv_wgrad(gy, x, g, scale):
@@ -577,6 +609,14 @@ def mask_bits_ok(x):
         import os
         _MASK_BITS[0] = os.environ.get('GANLAB_MASK_BITS') != '0'
     return _MASK_BITS[0] and x.dim() == 4 and bool(_lib.lib().ganlab_mask_bits_supported(int(x.shape[2]), int(x.shape[3])))
+
+
+def mask_bits_ok_plane():
+    """The A/B knob alone (GANLAB_MASK_BITS): callers check the plane size themselves."""
+    if _MASK_BITS[0] is None:
+        import os
+        _MASK_BITS[0] = os.environ.get('GANLAB_MASK_BITS') != '0'
+    return _MASK_BITS[0]
 
 
 def k_blur_bits(x):
@@ -1121,6 +1161,23 @@ class _ChanSum(Function):
         return _Scale.apply(g.view(view).expand(shape), ctx.scale), None, None
 
 
+class _GroupBroadcast(Function):
+    """(G,) -> (G*gs, 1, h, w): every sample of group g gets stat[g] on its whole plane (the minibatch-stddev feature map,
+    custom_layers.py:135-139).  Its adjoint is a per-group sum: a channel-sum launch instead of the ATen reduction that
+    autograd derives for ``expand``; the pair is closed under differentiation (R1 differentiates through it)."""
+
+    @staticmethod
+    def forward(ctx, stat, gs, h, w):
+        ctx.dims = (stat.shape[0], gs, h, w)
+        G = stat.shape[0]
+        return stat.view(G, 1, 1, 1, 1).expand(G, gs, 1, h, w).reshape(G * gs, 1, h, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        G, gs, h, w = ctx.dims
+        return _ChanSum.apply(g.reshape(1, G, gs * h * w), None, 1.0), None, None, None
+
+
 class _ConvBiasAct(Function):
     """y = act(s*conv(up?(x), w) + bias*bias_scale) in ONE kernel (bias/LeakyReLU in the MFMA
     epilogue).  Reference: Conv2dEx.forward (+ nn.LeakyReLU) custom_layers.py:202-211."""
@@ -1129,8 +1186,16 @@ class _ConvBiasAct(Function):
     def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False, defer=False, in_slope=None):
         # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
-        y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
+        if act != ACT_NONE and not blur and not defer and in_slope is None and conv_act_bwd_fusable(g) and \
+                (g.Ho * g.Wo) % 32 == 0 and mask_bits_ok_plane():
+            # fromRGB: the gradient kernels take (gy, mask of y); the forward writes that mask as bits next to y
+            y, bits = k_conv_fwd_bits(x, w, bias, g, s, bias_scale, act, slope)
+            ctx.defer, ctx.in_slope = False, None
+            ctx.bias_shape = bias.shape if bias is not None else None
+            ctx.save_for_backward(x, w, bits)
+            return y
+        y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         ctx.defer, ctx.in_slope = bool(defer), in_slope
         assert not (defer and blur)
         ctx.bias_shape = bias.shape if bias is not None else None
@@ -2305,6 +2370,10 @@ def style_mod(x, style):
     ys1 = (st[:, 0] + 1.0).reshape(-1).contiguous()
     yb = st[:, 1].reshape(-1).contiguous()
     return chan_affine(x.reshape(1, n * c, *x.shape[2:]), ys1, yb).reshape(x.shape)
+
+
+def group_broadcast(stat, group_size, h, w):
+    return _GroupBroadcast.apply(stat, int(group_size), int(h), int(w))
 
 
 def mbstd_stat(x, group_size, eps=1e-8):

@@ -152,7 +152,7 @@ def concat_mbstd_layer(x, group_size=4):
     G = b // group_size
     if group_size > 1:
         stat = ops.mbstd_stat(x, group_size)                       # (G,)
-        m = stat.view(G, 1, 1, 1, 1).expand(G, group_size, 1, h, w).reshape(b, 1, h, w)
+        m = ops.group_broadcast(stat, group_size, h, w)            # (b, 1, h, w): one value per group
     else:
         m = torch.zeros(b, 1, h, w, device=x.device, dtype=x.dtype)
     return torch.cat((x, m), dim=1)

@@ -368,6 +368,17 @@ int ganlab_blur_act_bwd_bits_f32(const float* g, const unsigned* ybits, float* o
 int ganlab_act_bwd_blur_bits_f32(const float* g, const unsigned* ybits, const float* noise, float* out, float* gb,
                                  float* gnw, int N, int C, int H, int W, float slope, float bias_scale, void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* fromRGB (1x1, <= 3 input channels, progan/architectures.py:286-292) with its LeakyReLU mask as bits: the forward writes y and
+ * the sign bits of y, the gradient kernels of ganlab_conv_{dgrad_act,fwd_mask,wgrad_act}_f32 read the bits instead of y */
+int ganlab_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
+                             const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_dgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* wp, float* gx,
+                                   const ganlab_conv_geom* g, float slope, void* stream);
+int ganlab_conv_fwd_mask_bits_f32(const float* x, const float* wp, const unsigned* ybits, float* out,
+                                  const ganlab_conv_geom* g, float slope, void* stream);
+int ganlab_conv_wgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* x, float* gw, float* gb,
+                                   const ganlab_conv_geom* g, float scale, float bias_scale, float slope, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---- all weight re-layouts of a network in ONE launch (csrc/pack.hip) -------------------------------------------------
  * The packed forms ganlab_conv_pack_f32 / ganlab_conv_s2_pack_f32 / ganlab_conv_pack_bf16 produce, rebuilt for a whole

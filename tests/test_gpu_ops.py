@@ -1092,3 +1092,29 @@ def test_leaky_relu_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     assert ops.mask_bits_ok(x0.cuda()) or not ops._MASK_BITS[0]
     for name, u, v in zip(['y', 'gx', 'gw', 'gb', 'gw (second order)'], a, b_):
         assert torch.equal(u, v), name
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 64, 64, 16), (3, 3, 64, 96, 24)], ids=['3->16 64x64', '3->24 64x96'])
+def test_fromrgb_mask_bits_equal_float_masks(ops, shape, monkeypatch):
+    """fromRGB (1x1 conv + LeakyReLU, progan/architectures.py:286-292) with its mask as bits: the forward writes y and
+    the sign bits of y, its streaming gradient kernels read the bits - forward, first-order gradients and the R1-shaped
+    second order are BIT-identical to the float-mask path."""
+    n, cin, h, w, cout = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()))
+    x0, wt0, b0 = rnd(gen, n, cin, h, w), rnd(gen, cout, cin, 1, 1), rnd(gen, cout)
+    cot = rnd(gen, n, cout, h, w).cuda()
+
+    def run(bits_on):
+        monkeypatch.setattr(ops, '_MASK_BITS', [bits_on])
+        x = x0.cuda().requires_grad_(True)
+        wt, b = wt0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        g = ops.Geom(n, cin, h, w, cout, 1, 0)
+        assert ops.conv_act_bwd_fusable(g), 'this shape must take the streaming fromRGB kernels'
+        y = ops.conv2d(x, wt, b, scale=0.5, padding=0, act='lrelu')
+        gx, = torch.autograd.grad((y * cot).sum(), x, create_graph=True)
+        gw2, = torch.autograd.grad((gx ** 2).sum(), wt, retain_graph=True)
+        gw1, gb1 = torch.autograd.grad((y * cot).sum(), (wt, b))
+        return [t_.detach() for t_ in (y, gx, gw1, gb1, gw2)]
+    a, b_ = run(True), run(False)
+    for name, u, v in zip(['y', 'gx', 'gw', 'gb', 'gw (second order)'], a, b_):
+        assert torch.equal(u, v), name
