@@ -131,6 +131,8 @@ SIGNATURES = {
     'ganlab_instnorm_bwd_act_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
     'ganlab_instnorm_style_bwd_act_f32': (_c_int, [_c_p] * 11 + [_c_int, _c_int, _c_ll, _c_int, _c_f, _c_f, _c_p, _c_sz,
                                                                  _c_p]),
+    'ganlab_instnorm_style_bwd_act_blur_f32': (_c_int, [_c_p] * 11 + [_c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_f,
+                                                                      _c_p, _c_sz, _c_p]),
     'ganlab_u8_box_decode_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     'ganlab_chan_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_mul_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),

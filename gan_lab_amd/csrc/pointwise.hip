@@ -341,6 +341,111 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
   }
 }
 
+// InstanceNorm + style backward, LeakyReLU' and blur^T in ONE pass (the backward of a BLURRED generator layer's tail:
+// stylegan/architectures.py:497-526 behind Upsample -> conv -> blur).  Round 2 ran instnorm_bwd_apply_act_kernel (read gy, x;
+// write gz) and then the blur (read gz, write out); here the blur's operand is evaluated on the fly,
+//   z = k * (gy - a1 - xhat * a2) * lrelu'(x),   out = blur(z),   sum0[c] += z,  sum1[c] += z * noise,
+// with the 4-columns x R-rows-per-thread scheme of blur_fused_kernel (row halos re-read from L1 / L2): 2R + 1W instead of
+// 3R + 2W.  grid (chunks, C, N): a block stays inside one (n, c) plane, whose five scalars it reads once.  z is evaluated in
+// fp64 and rounded once (see instnorm_bwd_apply_act_kernel); the sums add the unrounded values of the thread's OWN rows.
+// part[(c*N + n)*chunks + chunk] (bias), + C*N*chunks (noise weight).
+template <int R>
+__global__ __launch_bounds__(256) void instnorm_bwd_act_blur_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ style, const float* __restrict__ s1,
+    const float* __restrict__ s2, const float* __restrict__ noise, float* __restrict__ out, double* __restrict__ part,
+    int N, int C, int H, int W, int chunks, int act, float slope, int want_b, int want_nw) {
+  __shared__ double red[4];
+  const int c = blockIdx.y, n = blockIdx.z, chunk = blockIdx.x;
+  const long long pl = (long long)n * C + c, HW = (long long)H * W;
+  const int w4 = W >> 2, hr = H / R;
+  const long long per_n = (long long)hr * w4;
+  const double md = (double)mean[pl], rd = (double)rstd[pl];
+  const double ys = style ? (double)style[((long long)n * 2 + 0) * C + c] + 1.0 : 1.0;
+  const double inv = 1.0 / (double)HW;
+  const double k = rd * ys, a1 = (double)s1[pl] * inv, a2 = (double)s2[pl] * inv;
+  const float* pg = gy + pl * HW;
+  const float* px = x + pl * HW;
+  const float* pn = (want_nw && noise) ? noise + (long long)n * HW : nullptr;
+  float* po = out + pl * HW;
+  const int lane = threadIdx.x & 63;
+  double sb = 0.0, snw = 0.0;
+  auto zval = [&](float g, float v) -> double {
+    double t = k * ((double)g - a1 - ((double)v - md) * rd * a2);
+    if (act == GANLAB_ACT_LRELU && !(v > 0.f)) t *= (double)slope;
+    return t;
+  };
+  for (long long base = chunk * 256LL; base < per_n; base += (long long)chunks * 256) {
+    const long long i = base + threadIdx.x;
+    const bool live = i < per_n;
+    const long long ii = live ? i : per_n - 1;
+    const int rr = (int)(ii / w4), q = (int)(ii - (long long)rr * w4);
+    const int y0 = R * rr, x0 = 4 * q;
+    float h[R + 2][4];
+#pragma unroll
+    for (int kk = 0; kk < R + 2; ++kk) {
+      const int yy = y0 - 1 + kk;
+      const bool valid = (unsigned)yy < (unsigned)H;
+      const long long ro = (long long)yy * W;
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        float g[4], v[4];
+        *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(pg + ro + x0);
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(px + ro + x0);
+        const bool own = live && kk >= 1 && kk <= R;
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (own && pn) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(pn + ro + x0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double t = zval(g[j], v[j]);
+          z[j] = (float)t;
+          if (own) {
+            sb += t;
+            snw += t * (double)nz[j];
+          }
+        }
+      }
+      // horizontal neighbours from the adjacent lanes; the wave's two outer ones evaluate the element beyond their segment
+      float l = __shfl_up(z[3], 1, 64);
+      float r = __shfl_down(z[0], 1, 64);
+      const bool need_l = lane == 0 && q != 0, need_r = lane == 63 && q != w4 - 1;
+      float e = 0.f;
+      if (valid && (need_l || need_r)) {
+        const long long eo = ro + x0 + (need_l ? -1 : 4);
+        e = (float)zval(pg[eo], px[eo]);
+      }
+      if (q == 0) l = 0.f;
+      else if (lane == 0) l = e;
+      if (q == w4 - 1) r = 0.f;
+      else if (lane == 63) r = e;
+      h[kk][0] = l + 2.f * z[0] + z[1];
+      h[kk][1] = z[0] + 2.f * z[1] + z[2];
+      h[kk][2] = z[1] + 2.f * z[2] + z[3];
+      h[kk][3] = z[2] + 2.f * z[3] + r;
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int kk = 0; kk < R; ++kk) {
+      float4 o;
+      o.x = (h[kk][0] + 2.f * h[kk + 1][0] + h[kk + 2][0]) * 0.0625f;
+      o.y = (h[kk][1] + 2.f * h[kk + 1][1] + h[kk + 2][1]) * 0.0625f;
+      o.z = (h[kk][2] + 2.f * h[kk + 1][2] + h[kk + 2][2]) * 0.0625f;
+      o.w = (h[kk][3] + 2.f * h[kk + 1][3] + h[kk + 2][3]) * 0.0625f;
+      *reinterpret_cast<float4*>(po + (long long)(y0 + kk) * W + x0) = o;
+    }
+  }
+  const long long slot = ((long long)c * N + n) * chunks + chunk;
+  if (want_b) {
+    sb = gl_block_sum_256d(sb, red);
+    if (threadIdx.x == 0) part[slot] = sb;
+  }
+  if (want_nw) {
+    if (want_b) __syncthreads();
+    snw = gl_block_sum_256d(snw, red);
+    if (threadIdx.x == 0) part[(long long)C * N * chunks + slot] = snw;
+  }
+}
+
 // rows per thread: R + 2 input rows are read for R output rows (the halo rows come from L1 / L2), so taller strips
 // mean less cache traffic: 8 rows for the large planes, 4 / 2 for the small ones
 // (measured, 32x16x1024^2 / 32x64x256^2: forward 1.13 -> 1.02 ms / 0.27 -> 0.28, blur-then-act' 1.41 -> 1.20 / 0.36 ->
@@ -1507,6 +1612,37 @@ int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const flo
   double* part = reinterpret_cast<double*>(workspace);
   GL_LAUNCH(instnorm_bwd_apply_act_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, gy, x, mean,
             rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part, gb, C, N * chunks, bias_scale);
+  if (gnw)
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part + (size_t)C * N * chunks, gnw, C,
+              N * chunks, 1.f);
+  return GL_CHECK_LAUNCH();
+}
+
+/* ganlab_instnorm_style_bwd_act_f32 followed by the blur (self-adjoint) in one pass: out = blur(gz) for a generator layer whose
+ * tail sits behind Upsample -> conv -> blur; gz itself is not written.  workspace: ganlab_instnorm_bwd_act_workspace. */
+int ganlab_instnorm_style_bwd_act_blur_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                           const float* style, const float* s1, const float* s2, const float* noise,
+                                           float* out, float* gb, float* gnw, int N, int C, int H, int W, int act,
+                                           float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  if (!gy || !x || !mean || !rstd || !s1 || !s2 || !out || N <= 0 || C <= 0 || (gnw && !noise)) return GANLAB_EINVAL;
+  if (!ganlab_blur_fused_supported(H, W) || N > 65535 || C > 65535) return GANLAB_EUNSUPPORTED;
+  const long long HW = (long long)H * W;
+  if ((gb || gnw) && (!workspace || workspace_bytes < ganlab_instnorm_bwd_act_workspace(N, C, HW))) return GANLAB_EWORKSPACE;
+  const int rows = blur_rows(H);
+  const long long per_n = (long long)(H / rows) * (W / 4);
+  int chunks = (int)((per_n + 256 * 4 - 1) / (256 * 4));
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;          // the workspace holds 64 chunks per plane
+  double* part = reinterpret_cast<double*>(workspace);
+  const dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)N);
+  if (rows == 4)
+    GL_LAUNCH(instnorm_bwd_act_blur_kernel<4>, grid, dim3(256), 0, ST, gy, x, mean, rstd, style, s1, s2, noise, out, part, N, C,
+              H, W, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0);
+  else
+    GL_LAUNCH(instnorm_bwd_act_blur_kernel<2>, grid, dim3(256), 0, ST, gy, x, mean, rstd, style, s1, s2, noise, out, part, N, C,
+              H, W, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0);
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part, gb, C, N * chunks, bias_scale);
   if (gnw)
     GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part + (size_t)C * N * chunks, gnw, C,

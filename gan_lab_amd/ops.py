@@ -1415,35 +1415,10 @@ class _LayerTail(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        y, mean, rstd, style, noise = ctx.saved_tensors
-        gout = _c(gout)
-        n, c, hw = _nchw(y)
-        L = _lib.lib()
-        params = _want_param_grads()
-        want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
-        want_nw = ctx.nw_shape is not None and ctx.needs_input_grad[3] and params
-        s1, s2 = _new((n, c), y), _new((n, c), y)
-        check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
-                                                     _st()), 'instnorm_bwd_reduce')
-        gx = gb = gnw = None
-        if ctx.needs_input_grad[0] or want_b or want_nw:
-            gz = torch.empty_like(y)
-            gb = _new((c,), y) if want_b else None
-            gnw = _new((c,), y) if want_nw else None
-            ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
-                             device=y.device) if (want_b or want_nw) else None
-            check(L.ganlab_instnorm_style_bwd_act_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
-                                                      _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
-                                                      hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
-                                                      ws.numel() * 4 if ws is not None else 0, _st()),
-                  'instnorm_bwd_act')
-            if ctx.needs_input_grad[0]:
-                gx = k_blur(gz) if ctx.blur else gz
-        gstyle = None
-        if style is not None and ctx.needs_input_grad[4]:
-            gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)
-        return gx, (gb.view(ctx.bias_shape) if want_b else None), None, \
-            (gnw.view(ctx.nw_shape) if want_nw else None), gstyle, None, None, None, None, None
+        ctx.want_x_grad, ctx.want_bias_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ctx.want_nw_grad, ctx.want_style_grad = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors, gout, blur=ctx.blur)
+        return (gz if ctx.want_x_grad else None), gb, None, gnw, gstyle, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- #
@@ -1472,10 +1447,11 @@ def _affine_from_stats(mean, rstd, style, n, c):
     return s_, t_
 
 
-def _layer_tail_backward(ctx, saved_tail, gout):
+def _layer_tail_backward(ctx, saved_tail, gout, blur=False):
     """Shared by _LayerTail / _LayerTailDeferred / _ConvModTail: InstanceNorm + style backward of ``gout`` (the gradient
     with respect to the normalised tensor), LeakyReLU undone, bias / noise-weight / style gradients from the same pass.
-    Returns (gz, gb, gnw, gstyle)."""
+    ``blur``: the tail sits behind a blur - the (self-adjoint) blur of gz runs in the SAME pass and gz is never written.
+    Returns (gz or blur(gz), gb, gnw, gstyle)."""
     y, mean, rstd, style, noise = saved_tail
     gout = _c(gout)
     n, c, hw = _nchw(y)
@@ -1493,11 +1469,20 @@ def _layer_tail_backward(ctx, saved_tail, gout):
         gnw = _new((c,), y) if want_nw else None
         ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
                          device=y.device) if (want_b or want_nw) else None
-        check(L.ganlab_instnorm_style_bwd_act_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
-                                                  _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
-                                                  hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
-                                                  ws.numel() * 4 if ws is not None else 0, _st()),
-              'instnorm_bwd_act')
+        if blur and blur_fusable(y):
+            check(L.ganlab_instnorm_style_bwd_act_blur_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
+                                                           _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
+                                                           int(y.shape[2]), int(y.shape[3]), ctx.act, ctx.slope,
+                                                           ctx.bias_scale, _p(ws), ws.numel() * 4 if ws is not None else 0,
+                                                           _st()), 'instnorm_bwd_act_blur')
+        else:
+            check(L.ganlab_instnorm_style_bwd_act_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
+                                                      _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
+                                                      hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
+                                                      ws.numel() * 4 if ws is not None else 0, _st()),
+                  'instnorm_bwd_act')
+            if blur and ctx.want_x_grad:
+                gz = k_blur(gz)
     gstyle = None
     if style is not None and ctx.want_style_grad:
         gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)
@@ -1532,10 +1517,8 @@ class _LayerTailDeferred(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_b, *_):
-        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors, g_b)
-        gx = None
-        if ctx.want_x_grad:
-            gx = k_blur(gz) if ctx.blur else gz
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors, g_b, blur=ctx.blur)
+        gx = gz if ctx.want_x_grad else None
         return gx, gb, None, gnw, gstyle, None, None, None, None, None
 
 

@@ -223,6 +223,13 @@ int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const flo
                                       float* gz, float* gb, float* gnw, int N, int C, long long HW, int act,
                                       float slope, float bias_scale, void* workspace, size_t workspace_bytes,
                                       void* stream);
+/* ... followed by the (self-adjoint) blur of a BLURRED generator layer in the same pass: out = blur(gz), gz is not written
+ * (blur -> noise/bias/LeakyReLU -> InstanceNorm/style backward of stylegan/architectures.py:497-526 behind :331-360) */
+int ganlab_instnorm_style_bwd_act_blur_f32(const float* gy, const float* x, const float* mean, const float* rstd,
+                                           const float* style, const float* s1, const float* s2, const float* noise,
+                                           float* out, float* gb, float* gnw, int N, int C, int H, int W, int act,
+                                           float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                           void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);

@@ -627,7 +627,10 @@ def test_bias_act_with_fused_instnorm_statistics(ops, shape, blur):
                 if name == 'dbias' and std != 1.0:
                     continue     # all-positive planes: a channel shift in front of the IN has an exactly zero gradient
                 assert_close(got, w_.float(), tol, f'{tag} {name} {shape} blur={blur} std={std}')
-                assert_close(got, sep, 1e-5, f'{tag} vs separate {name} {shape} blur={blur} std={std}')
+                # the fused tail evaluates its element formula in fp64 for the bias / noise-weight sums (cancelling sums over
+                # the plane), the separate kernels add float-rounded elements: the two agree to the fp32 noise of the latter
+                assert_close(got, sep, 1e-4 if name in ('dbias', 'dnoise_w') else 1e-5,
+                             f'{tag} vs separate {name} {shape} blur={blur} std={std}')
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 3, 16, 64, 64), (3, 3, 32, 64, 96), (1, 1, 8, 128, 64), (2, 3, 16, 32, 32)])
