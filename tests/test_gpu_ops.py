@@ -798,9 +798,13 @@ def test_full_size_layer_tail_fused_equals_composed(ops, blur):
         o.backward(cot)
         res.append((o.detach(), x.grad, b.grad, nw.grad, st.grad))
         del o, x
+    # dbias / dnoise_w are sums of 2^25 cancelling terms per channel: the fused tail evaluates each term and the partial
+    # sums in fp64, the composed kernels add float-rounded terms, so the two differ by the composed path's rounding
+    # (a few 1e-5 of the largest entry); every other output is elementwise and agrees to fp32 rounding.
     for a, bb, name in zip(res[0], res[1], ('out', 'dx', 'dbias', 'dnoise_w', 'dstyle')):
         den = bb.abs().max().item()
-        assert (a - bb).abs().max().item() <= 2e-5 * den, f'fused vs composed {name}'
+        tol = 1e-4 if name in ('dbias', 'dnoise_w') else 2e-5
+        assert (a - bb).abs().max().item() <= tol * den, f'fused vs composed {name}'
     plain = ops.layer_tail(x0, b0, nz, nw0, None, act='lrelu', blur=blur, eps=1e-8)
     m = plain.double().mean(dim=(2, 3))
     v = plain.double().var(dim=(2, 3), unbiased=False)
