@@ -101,6 +101,8 @@ SIGNATURES = {
     'ganlab_blur3x3_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_p]),
     'ganlab_up2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_pool2_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_resample2d_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                       _c_int, _c_p]),
     'ganlab_bias_act_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_act_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_f, _c_p]),
     'ganlab_act_bwd_bias_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_f, _c_p, _c_sz, _c_p]),

@@ -12,6 +12,7 @@ import types
 from collections import OrderedDict
 
 import torch
+from torch import nn
 
 from ._int import LearnerConfigCopy
 
@@ -36,7 +37,23 @@ class _ConfigShell(LearnerConfigCopy):
         object.__setattr__(self, name, value)
 
 
-_FOREIGN = {('_int', 'LearnerConfigCopy'): _ConfigShell, ('indexed', 'IndexedOrderedDict'): IndexedOrderedDict}
+class _PoolShell(nn.Module):
+    """``utils.custom_layers.NearestPool2d`` / ``BilinearPool2d`` as unpickled from a reference-written file: the
+    metadata entry only names the pooler (``custom_layers.own_resampler`` maps it by class name); the learner rebuilds its
+    resamplers from the config."""
+
+
+class NearestPool2d(_PoolShell):
+    pass
+
+
+class BilinearPool2d(_PoolShell):
+    pass
+
+
+_FOREIGN = {('_int', 'LearnerConfigCopy'): _ConfigShell, ('indexed', 'IndexedOrderedDict'): IndexedOrderedDict,
+            ('utils.custom_layers', 'NearestPool2d'): NearestPool2d,
+            ('utils.custom_layers', 'BilinearPool2d'): BilinearPool2d}
 
 
 class _Unpickler(pickle.Unpickler):
@@ -105,6 +122,20 @@ class _RefIndexedOrderedDict(OrderedDict):
         return (self.__class__, ([[k, v] for k, v in self.items()],))
 
 
+class _RefNearestPool2d(nn.Module):
+    """Pickles as ``utils.custom_layers.NearestPool2d`` (custom_layers.py:59-65)."""
+
+
+class _RefBilinearPool2d(nn.Module):
+    """Pickles as ``utils.custom_layers.BilinearPool2d`` (custom_layers.py:67-75)."""
+
+    def __init__(self, align_corners):
+        super().__init__()
+        self.align_corners = align_corners
+
+
+for _cls, _name in ((_RefNearestPool2d, 'NearestPool2d'), (_RefBilinearPool2d, 'BilinearPool2d')):
+    _cls.__module__, _cls.__qualname__, _cls.__name__ = 'utils.custom_layers', _name, _name
 _RefConfig.__module__, _RefConfig.__qualname__, _RefConfig.__name__ = '_int', 'LearnerConfigCopy', 'LearnerConfigCopy'
 _RefIndexedOrderedDict.__module__ = 'indexed'
 _RefIndexedOrderedDict.__qualname__ = _RefIndexedOrderedDict.__name__ = 'IndexedOrderedDict'
@@ -116,10 +147,13 @@ class _foreign_modules(object):
 
     def __enter__(self):
         import sys
-        self._saved = {k: sys.modules.get(k) for k in ('_int', 'indexed')}
+        self._saved = {k: sys.modules.get(k) for k in ('_int', 'indexed', 'utils', 'utils.custom_layers')}
         m1, m2 = types.ModuleType('_int'), types.ModuleType('indexed')
+        m3, m4 = types.ModuleType('utils'), types.ModuleType('utils.custom_layers')
         m1.LearnerConfigCopy, m2.IndexedOrderedDict = _RefConfig, _RefIndexedOrderedDict
+        m4.NearestPool2d, m4.BilinearPool2d, m3.custom_layers = _RefNearestPool2d, _RefBilinearPool2d, m4
         sys.modules['_int'], sys.modules['indexed'] = m1, m2
+        sys.modules['utils'], sys.modules['utils.custom_layers'] = m3, m4
 
     def __exit__(self, *exc):
         import sys
@@ -129,6 +163,23 @@ class _foreign_modules(object):
             else:
                 sys.modules[k] = v
         return False
+
+
+def _ref_upsampler(m):
+    """This package's upsampler module -> what the reference pickles (resnetgan/learner.py:147-158)."""
+    if type(m).__name__ == 'BilinearUpsample2x':
+        return nn.Upsample(scale_factor=2, mode='bilinear', align_corners=m.align_corners)
+    return nn.Upsample(scale_factor=2, mode='nearest')
+
+
+def _ref_downsampler(m):
+    """This package's pooler module -> what the reference pickles (resnetgan/learner.py:160-173)."""
+    name = type(m).__name__
+    if name == 'NearestPool2x':
+        return _RefNearestPool2d()
+    if name == 'BilinearPool2x':
+        return _RefBilinearPool2d(m.align_corners)
+    return nn.AvgPool2d(kernel_size=2, stride=2)
 
 
 def torch_adam_state_dict(fused_adam, named_params, ordered_names):
@@ -172,11 +223,11 @@ def reference_checkpoint_dict(learner, g_names, d_names, extra=None):
         'config': _RefConfig(cfg_state),
         'curr_res': learner.gen_model.curr_res,
         'alpha': learner.gen_model.alpha,
-        'gen_model_metadata': {'gen_model_upsampler': nn.Upsample(scale_factor=2, mode='nearest'),
+        'gen_model_metadata': {'gen_model_upsampler': _ref_upsampler(learner.gen_model_upsampler),
                                'num_classes_gen': learner.num_classes_gen},
         'gen_model_state_dict': cpu(learner.gen_model.state_dict()),
         'gen_model_lagged_state_dict': cpu(lagged.state_dict()) if lagged is not None else None,
-        'disc_model_metadata': {'disc_model_downsampler': nn.AvgPool2d(kernel_size=2, stride=2),
+        'disc_model_metadata': {'disc_model_downsampler': _ref_downsampler(learner.disc_model_downsampler),
                                 'num_classes_disc': learner.num_classes_disc},
         'disc_model_state_dict': cpu(learner.disc_model.state_dict()),
         'nl': nl,

@@ -15,6 +15,8 @@ All ops require contiguous fp32 CUDA(HIP) tensors and raise otherwise - there is
 """
 import ctypes
 
+import numpy as np
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -347,6 +349,68 @@ def _wants_input_grad(ctx, x):
                                             x.data_ptr() == _NO_GRAD_TOWARDS[0])
 
 
+# ---- parameter gradients written straight into the flat arena ---------------------------------------
+# ``loss.backward()`` hands every parameter gradient to an AccumulateGrad node: one ``grad += g`` launch per parameter and
+# use (~250 per StyleGAN step - a fifth of the launches of the launch-bound configurations).  Inside
+# ``with direct_param_grads():`` (the learners' backward sweeps, single-process runs) the gradient kernels of a parameter
+# that lives in a ``ParamArena`` write their result INTO its (zeroed) arena slot when it is the first contribution of this
+# step, and the Function returns None for it; later contributions of the same step (the critic is applied to two batches)
+# take the ordinary accumulating path.  Never active while a differentiable backward is being recorded.
+_DIRECT = [False]
+_SINK, _TAKEN = {}, {}
+
+
+class direct_param_grads(object):
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self._prev = _DIRECT[0]
+        _DIRECT[0] = self.enabled
+        _SINK.clear()
+        _TAKEN.clear()
+
+    def __exit__(self, *exc):
+        _DIRECT[0] = self._prev
+        _SINK.clear()
+        _TAKEN.clear()
+        return False
+
+
+def _sink(name, p):
+    """Offer parameter ``p``'s arena slot to the next launcher that allocates the output called ``name``."""
+    if not _DIRECT[0] or p is None or torch.is_grad_enabled():
+        return
+    base = p._base if p._base is not None else p
+    arena = getattr(base, '_ganlab_arena', None)
+    if arena is None or not base.is_leaf or base.grad is None or base.numel() != p.numel() or \
+            getattr(base, '_ganlab_written', -1) == arena.serial:
+        return
+    _SINK[name] = base
+
+
+def _take(name, shape, like):
+    """Output buffer ``name`` of a launcher: the offered arena slot (marked written for this step) or a fresh tensor."""
+    if _SINK:
+        base = _SINK.pop(name, None)
+        if base is not None:
+            n = 1
+            for v in shape:
+                n *= int(v)
+            if base.grad.numel() == n and base.grad.device == like.device:
+                base._ganlab_written = base._ganlab_arena.serial
+                _TAKEN[name] = True
+                return base.grad.view(shape)
+    return _new(shape, like)
+
+
+def _sunk(name):
+    """After the launcher: did it write the parameter's arena slot (-> the Function returns None for that gradient)?"""
+    if _SINK:
+        _SINK.pop(name, None)
+    return _TAKEN.pop(name, False) if _TAKEN else False
+
+
 # ---- launch observer (measurement only) -------------------------------------------------------------
 # bench.py / tools/step_layers.py count the convolution FLOPs the step actually EXECUTES (stride-2 fused layers run
 # 16 low-resolution taps instead of 4 x 9, the shared D(real) forward and the skipped weight gradients never launch)
@@ -518,8 +582,8 @@ def k_conv_wgrad_act(gy, y, x, g, scale, slope, bias_scale, want_gb):
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     _note('wgrad', g)
     L = _lib.lib()
-    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
-    gb = _new((g.Cout,), x) if want_gb else None
+    gw = _take('gw', (g.Cout, g.Cin, g.ks, g.ks), x)
+    gb = _take('gb', (g.Cout,), x) if want_gb else None
     ws = torch.empty((max(L.ganlab_conv_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=x.device)
     if _is_bits(y):
         check(L.ganlab_conv_wgrad_act_bits_f32(_p(gy), y.data_ptr(), _p(x), _p(gw), _p(gb), g.ref(), scale, bias_scale, slope,
@@ -550,7 +614,7 @@ def k_conv_wgrad(gy, x, g, scale):
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     _note('wgrad', g)
     L = _lib.lib()
-    gw = _new((g.Cout, g.Cin, g.ks, g.ks), x)
+    gw = _take('gw', (g.Cout, g.Cin, g.ks, g.ks), x)
     if g.bf is not None:
         if g.bf_fused is not None:
             # the rolling-row kernel reads the half-resolution operand (x of conv(up2 x), gy of pool2(conv x)) in place
@@ -724,7 +788,7 @@ def k_blur_act_bwd(g, y, slope, bias_scale, want_gb):
     g = _c(g)
     n, c, h, w = g.shape
     out = torch.empty_like(g)
-    gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
+    gb = _take('gb', (c,), g) if want_gb else None
     ws = _blur_ws(g) if want_gb else None
     if _is_bits(y):
         assert y.numel() * 32 == g.numel()
@@ -743,8 +807,8 @@ def k_act_bwd_blur(g, y, noise, slope, bias_scale, want_gb, want_gnw):
     g = _c(g)
     n, c, h, w = g.shape
     out = torch.empty_like(g)
-    gb = torch.empty(c, dtype=torch.float32, device=g.device) if want_gb else None
-    gnw = torch.empty(c, dtype=torch.float32, device=g.device) if want_gnw else None
+    gb = _take('gb', (c,), g) if want_gb else None
+    gnw = _take('gnw', (c,), g) if want_gnw else None
     ws = _blur_ws(g) if (want_gb or want_gnw) else None
     if _is_bits(y):
         assert y.numel() * 32 == g.numel()
@@ -774,6 +838,80 @@ def k_pool2(x, scale=0.25):
     assert h % 2 == 0 and w % 2 == 0
     y = _new((n, c, h // 2, w // 2), x)
     check(_lib.lib().ganlab_pool2_f32(_p(x), _p(y), n * c, h // 2, w // 2, scale, _st()), 'pool2')
+    return y
+
+
+# ---- table-driven resamplers: nn.Upsample(mode='bilinear'), NearestPool2d, BilinearPool2d (custom_layers.py:59-75) ---
+RESAMPLE_MODES = ('bilinear_up', 'bilinear_down', 'nearest_down')
+_RESAMPLE_TABLES = {}
+
+
+def resample_matrix(mode, align_corners, n_in):
+    """1-D interpolation matrix (n_out x n_in, float64 entries that are float32 numbers) of ``F.interpolate`` at scale
+    2 / 0.5, with ATen's source-index arithmetic in float32: align_corners -> src = dst * (n_in-1)/(n_out-1); else
+    src = (dst + .5) / scale - .5 clamped at 0 (bilinear), floor(dst / scale) (nearest)."""
+    if mode not in RESAMPLE_MODES:
+        raise ValueError(f'resampler mode {mode!r}: one of {RESAMPLE_MODES}')
+    f32 = np.float32
+    n_out = 2 * n_in if mode == 'bilinear_up' else n_in // 2
+    if n_out < 1 or (mode != 'bilinear_up' and n_in % 2):
+        raise ValueError(f'{mode}: size {n_in} has no 0.5x / 2x counterpart')
+    m = np.zeros((n_out, n_in), np.float64)
+    inv = f32(0.5) if mode == 'bilinear_up' else f32(2.0)
+    for o in range(n_out):
+        if mode == 'nearest_down':
+            m[o, min(int(np.floor(f32(o) * inv)), n_in - 1)] = 1.0
+            continue
+        if align_corners:
+            r = f32(n_in - 1) / f32(n_out - 1) if n_out > 1 else f32(0)
+            src = r * f32(o)
+        else:
+            src = max(inv * (f32(o) + f32(0.5)) - f32(0.5), f32(0))
+        i0 = min(int(src), n_in - 1)
+        i1 = i0 + (1 if i0 < n_in - 1 else 0)
+        l1 = f32(src) - f32(i0)
+        m[o, i0] += float(f32(1) - l1)
+        m[o, i1] += float(l1)
+    return m
+
+
+def _taps(m):
+    nz = [np.nonzero(row)[0] for row in m]
+    t = max(1, max(len(v) for v in nz))
+    if t > 6:
+        raise ValueError(f'resampler needs {t} taps per output (the kernel holds 6)')
+    idx, w = np.zeros((m.shape[0], t), np.int32), np.zeros((m.shape[0], t), np.float32)
+    for o, v in enumerate(nz):
+        idx[o, :len(v)] = v
+        w[o, :len(v)] = m[o, v]
+    return idx, w, t
+
+
+def _resample_tables(mode, align, n_in, adjoint, device):
+    key = (mode, bool(align), int(n_in), bool(adjoint), str(device))
+    tab = _RESAMPLE_TABLES.get(key)
+    if tab is None:
+        m = resample_matrix(mode, align, n_in)
+        idx, w, t = _taps(m.T if adjoint else m)
+        tab = (torch.from_numpy(idx).to(device), torch.from_numpy(w).to(device), t, idx.shape[0])
+        _RESAMPLE_TABLES[key] = tab
+    return tab
+
+
+def k_resample(x, mode, align, hin, win, adjoint):
+    """``adjoint=False``: (N, C, hin, win) -> the resampled map; ``True``: a map of the resampled size -> (N, C, hin, win)
+    through the transposed interpolation matrices (the layer's backward; its own backward is the forward again)."""
+    x = _c(x)
+    n, c, h, w = x.shape
+    iy, wy, ty, ho = _resample_tables(mode, align, hin, adjoint, x.device)
+    ix, wx, tx, wo = _resample_tables(mode, align, win, adjoint, x.device)
+    exp_h = hin if not adjoint else (2 * hin if mode == 'bilinear_up' else hin // 2)
+    exp_w = win if not adjoint else (2 * win if mode == 'bilinear_up' else win // 2)
+    if (h, w) != (exp_h, exp_w):
+        raise ValueError(f'resample {mode} (adjoint={adjoint}): input {h}x{w}, expected {exp_h}x{exp_w}')
+    y = _new((n, c, ho, wo), x)
+    check(_lib.lib().ganlab_resample2d_f32(_p(x), _p(y), _p(iy), _p(wy), _p(ix), _p(wx), n * c, h, w, ho, wo, ty, tx,
+                                           _st()), 'resample2d')
     return y
 
 
@@ -815,19 +953,19 @@ def k_act_bwd_bias(gy, y, slope, scale):
     n, c, hw = _nchw(gy)
     L = _lib.lib()
     ws = torch.empty((L.ganlab_channel_sum_workspace(n, c, hw) + 3) // 4, dtype=torch.float32, device=gy.device)
-    gz, gb = torch.empty_like(gy), _new((c,), gy)
+    gz, gb = torch.empty_like(gy), _take('gb', (c,), gy)
     check(L.ganlab_act_bwd_bias_f32(_p(gy), _p(y), _p(gz), _p(gb), n, c, hw, slope, scale, _p(ws), ws.numel() * 4,
                                     _st()), 'act_bwd_bias')
     return gz, gb
 
 
-def k_channel_sum(a, b=None, scale=1.0):
+def k_channel_sum(a, b=None, scale=1.0, sink=None):
     a = _c(a)
     n, c, hw = _nchw(a)
     L = _lib.lib()
     nbytes = L.ganlab_channel_sum_workspace(n, c, hw)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
-    out = _new((c,), a)
+    out = _take(sink, (c,), a) if sink is not None else _new((c,), a)
     b = _c(b) if b is not None else None
     check(L.ganlab_channel_sum_f32(_p(a), _p(b), _p(out), n, c, hw, scale, _p(ws), ws.numel() * 4, _st()),
           'channel_sum')
@@ -900,7 +1038,12 @@ class _ConvFwd(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and _want_param_grads()) else None
+        gw = None
+        if ctx.needs_input_grad[1] and _want_param_grads():
+            _sink('gw', w)
+            gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.s)
+            if _sunk('gw'):
+                gw = None
         return gx, gw, None, None
 
 
@@ -1128,6 +1271,7 @@ class _BlurBiasAct(Function):
         ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
         return y if stats is None else (y,) + stats
 
     @staticmethod
@@ -1137,8 +1281,14 @@ class _BlurBiasAct(Function):
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
         want_nw = ctx.nw_shape is not None and ctx.needs_input_grad[3] and params
         act = ctx.act != ACT_NONE
+        _sink('gb', ctx.bias_ref if want_b else None)
+        _sink('gnw', ctx.nw_ref if want_nw else None)
         gx, gb, gnw = _ActBwdBlur.apply(gy, y if act else gy, noise if want_nw else None,
                                         ctx.slope if act else 1.0, ctx.bias_scale, bool(want_b), bool(want_nw))
+        if _sunk('gb'):
+            want_b = False
+        if _sunk('gnw'):
+            want_nw = False
         return (gx if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if want_b else None), None, \
             (gnw.view(ctx.nw_shape) if want_nw else None), None, None, None, None
 
@@ -1147,10 +1297,10 @@ class _ChanSum(Function):
     """(N,C,...) -> (C,) sum, optionally weighted by a (N,1,...) map (noise-weight gradient)."""
 
     @staticmethod
-    def forward(ctx, a, b, scale):
+    def forward(ctx, a, b, scale, sink=None):
         ctx.shape, ctx.scale = a.shape, scale
         ctx.has_b = b is not None
-        return k_channel_sum(a, b, scale)
+        return k_channel_sum(a, b, scale, sink)
 
     @staticmethod
     def backward(ctx, g):
@@ -1158,7 +1308,7 @@ class _ChanSum(Function):
             raise NotImplementedError('double backward through the noise-weighted channel sum')
         shape = ctx.shape
         view = [1, shape[1]] + [1] * (len(shape) - 2)
-        return _Scale.apply(g.view(view).expand(shape), ctx.scale), None, None
+        return _Scale.apply(g.view(view).expand(shape), ctx.scale), None, None, None
 
 
 class _GroupBroadcast(Function):
@@ -1187,6 +1337,7 @@ class _ConvBiasAct(Function):
         # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
+        ctx.bias_ref = bias
         if act != ACT_NONE and not blur and not defer and in_slope is None and conv_act_bwd_fusable(g) and \
                 (g.Ho * g.Wo) % 32 == 0 and mask_bits_ok_plane():
             # fromRGB: the gradient kernels take (gy, mask of y); the forward writes that mask as bits next to y
@@ -1222,9 +1373,16 @@ class _ConvBiasAct(Function):
             gx = _ConvDgradAct.apply(gy, y, w, ctx.g, ctx.s, ctx.slope) if _wants_input_grad(ctx, x) else None
             gw = None
             if params and (ctx.needs_input_grad[1] or want_b):
+                _sink('gw', w if ctx.needs_input_grad[1] else None)
+                _sink('gb', ctx.bias_ref if want_b else None)
                 gw, gb = _ConvWgradAct.apply(gy, y, x, ctx.g, ctx.s, ctx.slope, ctx.bias_scale, bool(want_b))
+                if _sunk('gw'):
+                    gw = None
+                if _sunk('gb'):
+                    want_b = False
             return gx, (gw if ctx.needs_input_grad[1] else None), (gb.view(ctx.bias_shape) if want_b else None), \
                 None, None, None, None, None, None, None, None
+        _sink('gb', ctx.bias_ref if want_b else None)
         if ctx.blur and act != ACT_NONE:
             gz, gb = _BlurActBwd.apply(gy, y, ctx.slope, ctx.bias_scale, bool(want_b))
         else:
@@ -1235,12 +1393,19 @@ class _ConvBiasAct(Function):
             else:
                 gz = _ActBwd.apply(gy, y, ctx.slope) if act != ACT_NONE else gy
                 if want_b:
-                    gb = _ChanSum.apply(gz, None, ctx.bias_scale)
+                    gb = _ChanSum.apply(gz, None, ctx.bias_scale, 'gb')
+        if _sunk('gb'):
+            gb = None
         gx = None
         if _wants_input_grad(ctx, x):
             gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.in_slope is None else \
                 _ConvDgradMask.apply(gz, w, x, ctx.g, ctx.s, ctx.in_slope)
-        gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s) if (ctx.needs_input_grad[1] and params) else None
+        gw = None
+        if ctx.needs_input_grad[1] and params:
+            _sink('gw', w)
+            gw = _ConvWgrad.apply(gz, x, ctx.g, ctx.s)
+            if _sunk('gw'):
+                gw = None
         return gx, gw, (gb.view(ctx.bias_shape) if want_b and gb is not None else None), None, None, None, None, \
             None, None, None, None
 
@@ -1262,6 +1427,7 @@ class _BiasAct(Function):
         ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
         return y if stats is None else (y,) + stats
 
     @staticmethod
@@ -1270,14 +1436,20 @@ class _BiasAct(Function):
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[1] and params
         gb = gnw = None
+        _sink('gb', ctx.bias_ref if want_b else None)
         if ctx.act != ACT_NONE and want_b:
             gz, gb = _ActBwdBias.apply(gy, y, ctx.slope, ctx.bias_scale)
         else:
             gz = _ActBwd.apply(gy, y, ctx.slope) if ctx.act != ACT_NONE else gy
             if want_b:
-                gb = _ChanSum.apply(gz, None, ctx.bias_scale)
+                gb = _ChanSum.apply(gz, None, ctx.bias_scale, 'gb')
+        if _sunk('gb'):
+            gb = None
         if ctx.nw_shape is not None and ctx.needs_input_grad[3] and params:
-            gnw = _ChanSum.apply(gz, noise, 1.0).view(ctx.nw_shape)
+            _sink('gnw', ctx.nw_ref)
+            gnw = _ChanSum.apply(gz, noise, 1.0, 'gnw').view(ctx.nw_shape)
+            if _sunk('gnw'):
+                gnw = None
         return (gz if ctx.needs_input_grad[0] else None), (gb.view(ctx.bias_shape) if gb is not None else None), \
             None, gnw, None, None, None, None
 
@@ -1312,6 +1484,21 @@ class _Up2(Function):
     @staticmethod
     def backward(ctx, g):
         return _Pool2.apply(g, ctx.scale), None
+
+
+class _Resample(Function):
+    """Linear map x -> M_y x M_x^T; backward is the adjoint gather, whose backward is the forward (R1 reaches the critic's
+    pooler through a double backward)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, align, hin, win, adjoint):
+        ctx.args = (mode, align, hin, win, adjoint)
+        return k_resample(x, mode, align, hin, win, adjoint)
+
+    @staticmethod
+    def backward(ctx, g):
+        mode, align, hin, win, adjoint = ctx.args
+        return _Resample.apply(g, mode, align, hin, win, not adjoint), None, None, None, None, None
 
 
 class _Scale(Function):
@@ -1409,6 +1596,7 @@ class _LayerTail(Function):
         ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, blur
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
         ctx.style_shape = style.shape if style is not None else None
         return out
 
@@ -1465,8 +1653,10 @@ def _layer_tail_backward(ctx, saved_tail, gout, blur=False):
     gz = gb = gnw = None
     if ctx.want_x_grad or want_b or want_nw:
         gz = torch.empty_like(y)
-        gb = _new((c,), y) if want_b else None
-        gnw = _new((c,), y) if want_nw else None
+        _sink('gb', getattr(ctx, 'bias_ref', None) if want_b else None)
+        _sink('gnw', getattr(ctx, 'nw_ref', None) if want_nw else None)
+        gb = _take('gb', (c,), y) if want_b else None
+        gnw = _take('gnw', (c,), y) if want_nw else None
         ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
                          device=y.device) if (want_b or want_nw) else None
         if blur and blur_fusable(y):
@@ -1486,6 +1676,10 @@ def _layer_tail_backward(ctx, saved_tail, gout, blur=False):
     gstyle = None
     if style is not None and ctx.want_style_grad:
         gstyle = torch.stack((s2, s1), dim=1).reshape(ctx.style_shape)
+    if _sunk('gb'):
+        gb = None
+    if _sunk('gnw'):
+        gnw = None
     return gz, (gb.view(ctx.bias_shape) if gb is not None else None), \
         (gnw.view(ctx.nw_shape) if gnw is not None else None), gstyle
 
@@ -1508,6 +1702,7 @@ class _LayerTailDeferred(Function):
         ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, blur
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
         ctx.style_shape = style.shape if style is not None else None
         ctx.want_x_grad, ctx.want_bias_grad = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         ctx.want_nw_grad, ctx.want_style_grad = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
@@ -1624,7 +1819,7 @@ def k_conv_wgrad_aff(gy, a, s_, t_, g, scale):
     assert tuple(gy.shape) == g.out_shape and tuple(a.shape) == g.in_shape
     _note('wgrad', g)
     L = _lib.lib()
-    gw = _new((g.Cout, g.Cin, 3, 3), a)
+    gw = _take('gw', (g.Cout, g.Cin, 3, 3), a)
     if g.up:
         ws = torch.empty((max(L.ganlab_conv_s2_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=a.device)
         check(L.ganlab_conv_s2_wgrad_aff_f32(_p(gy), _p(a), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4,
@@ -1652,7 +1847,12 @@ class _ConvAff(Function):
     def backward(ctx, gy):
         a, s_, t_, w = ctx.saved_tensors
         ga = k_conv_dgrad(gy, w, ctx.g, ctx.scale) if ctx.needs_input_grad[0] else None
-        gw = k_conv_wgrad_aff(gy, a, s_, t_, ctx.g, ctx.scale) if (ctx.needs_input_grad[3] and _want_param_grads()) else None
+        gw = None
+        if ctx.needs_input_grad[3] and _want_param_grads():
+            _sink('gw', w)
+            gw = k_conv_wgrad_aff(gy, a, s_, t_, ctx.g, ctx.scale)
+            if _sunk('gw'):
+                gw = None
         return ga, None, None, gw, None, None
 
 
@@ -1694,6 +1894,7 @@ class _ConvModTail(Function):
         ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = bias_scale, act, slope, False
         ctx.bias_shape = bias.shape if bias is not None else None
         ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
         ctx.style_shape = style.shape if style is not None else None
         ctx.want_x_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
         ctx.want_bias_grad, ctx.want_nw_grad = ctx.needs_input_grad[4], ctx.needs_input_grad[6]
@@ -1711,7 +1912,10 @@ class _ConvModTail(Function):
         if ctx.needs_input_grad[0]:
             ga = k_conv_dgrad(gz, w, g, ctx.scale)              # d/d(a_in*s + t): shared weights, plain kernel
         if ctx.needs_input_grad[3] and _want_param_grads():
+            _sink('gw', w)
             gw = k_conv_wgrad_aff(gz, a_in, s_in, t_in, g, ctx.scale)
+            if _sunk('gw'):
+                gw = None
         return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None
 
 
@@ -1733,6 +1937,7 @@ class _ToRGBMod(Function):
         ctx.save_for_backward(a, s_, t_, w)
         ctx.scale, ctx.bias_scale = scale, bias_scale
         ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -1753,10 +1958,16 @@ class _ToRGBMod(Function):
             ws = torch.empty((L.ganlab_mod_torgb_cross_workspace(n) + 3) // 4, dtype=torch.float32, device=a.device)
             check(L.ganlab_mod_torgb_cross_f32(_p(a), _p(gy), _p(out), n, cin, cout, h * wd, _p(ws), ws.numel() * 4,
                                                _st()), 'mod_torgb_cross')
-            gw = _new((cout, cin, 1, 1), a) if want_w else None
-            gb = _new(tuple(ctx.bias_shape), a) if want_b else None
+            _sink('gw', w if want_w else None)
+            _sink('gb', ctx.bias_ref if want_b else None)
+            gw = _take('gw', (cout, cin, 1, 1), a) if want_w else None
+            gb = _take('gb', tuple(ctx.bias_shape), a) if want_b else None
             check(L.ganlab_mod_torgb_wgrad_f32(_p(out), _p(s_), _p(t_), _p(gw), _p(gb), n, cin, cout, ctx.scale,
                                                ctx.bias_scale, _st()), 'mod_torgb_wgrad')
+            if _sunk('gw'):
+                gw = None
+            if _sunk('gb'):
+                gb = None
         return ga, None, None, gw, gb, None, None
 
 
@@ -2295,6 +2506,14 @@ def avg_pool2(x):
 
 def upsample2(x):
     return _Up2.apply(x, 1.0)
+
+
+def resample(x, mode, align_corners=False):
+    """``F.interpolate`` at scale 2 (``'bilinear_up'``) / 0.5 (``'bilinear_down'``, ``'nearest_down'``) of an NCHW map:
+    nn.Upsample(mode='bilinear') / BilinearPool2d / NearestPool2d of the reference (custom_layers.py:59-75)."""
+    if x.dim() == 3:
+        x = x.view(-1, *x.shape)
+    return _Resample.apply(x, mode, bool(align_corners), int(x.shape[2]), int(x.shape[3]), False)
 
 
 def lerp(a, b, alpha):

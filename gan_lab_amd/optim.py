@@ -41,6 +41,7 @@ class ParamArena(object):
             self.sizes.append(p.numel())
             off += _round_up(p.numel(), _ALIGN)
         self.total = off
+        self.serial = 0          # bumped by zero_grad(): ops.direct_param_grads writes each slot once per step
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.gflat = torch.zeros(off, dtype=torch.float32, device=device)
         with torch.no_grad():
@@ -53,6 +54,7 @@ class ParamArena(object):
         for p, o, n in zip(self.params, self.offsets, self.sizes):
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.gflat[o:o + n].view(p.shape)
+            p._ganlab_arena = self
 
     def is_attached(self):
         base, gbase = self.flat.data_ptr(), self.gflat.data_ptr()
@@ -72,6 +74,7 @@ class ParamArena(object):
 
     def zero_grad(self):
         self.gflat.zero_()
+        self.serial += 1
         if not self.is_attached():
             self.reabsorb()
 

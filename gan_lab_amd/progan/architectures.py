@@ -16,7 +16,7 @@ from .. import ops
 from .._int import FMAP_SAMPLES, RES_INIT
 from ..progressive import ProgressiveBase, StyleGAN
 from ..utils.custom_layers import (AvgPool2x, Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer,
-                                   Upsample2x, concat_mbstd_layer, fused_sequential, get_blur_op)
+                                   Upsample2x, concat_mbstd_layer, fused_sequential, get_blur_op, own_resampler)
 from .base import ProGAN
 
 FMAP_G_INIT_FCTR = 1
@@ -30,9 +30,7 @@ class ProGenerator(ProGAN):
                  equalized_lr=True, normalize_z=True, use_pixelnorm=True):
         super().__init__(final_res)
         self.gen_blocks = nn.ModuleList()
-        self.upsampler = upsampler if upsampler is not None else Upsample2x()
-        if not isinstance(self.upsampler, Upsample2x):
-            raise NotImplementedError("model_upsample_type must be 'nearest' on the HIP path")
+        self.upsampler = own_resampler(upsampler) if upsampler is not None else Upsample2x()
         self.gen_blur_type = blur_type
         self.nl = nl if nl is not None else LeakyReLU(.2)
         self.len_latent, self.num_classes = len_latent, num_classes
@@ -105,9 +103,7 @@ class _DiscriminatorBody(object):
         self.init_type = 'StyleGAN' if isinstance(self, StyleGAN) else 'ProGAN'
         self.disc_blocks = nn.ModuleList()
         self.num_classes = num_classes
-        self.pooler = pooler if pooler is not None else AvgPool2x()
-        if not isinstance(self.pooler, AvgPool2x):
-            raise NotImplementedError("model_downsample_type must be 'average'/'box' on the HIP path")
+        self.pooler = own_resampler(pooler) if pooler is not None else AvgPool2x()
         self.disc_blur_type = blur_type
         self.nl = nl if nl is not None else LeakyReLU(.2)
         self.equalized_lr = equalized_lr

@@ -16,12 +16,12 @@ import warnings
 
 import torch
 
-from .. import _lib, parallel
+from .. import _lib, ops, parallel
 from .._int import FMAP_SAMPLES, LearnerConfigCopy, get_current_configuration  # noqa: F401
 from ..optim import ParamArena
 from ..utils import backprop_utils as bp
 from ..utils.backprop_utils import configure_adam_for_gan
-from ..utils.custom_layers import AvgPool2x, LeakyReLU, Upsample2x
+from ..utils.custom_layers import LeakyReLU, make_downsampler, make_upsampler
 from ..utils.latent_utils import gen_rand_latent_vars
 
 NONREDEFINABLE_ATTRS = ('model', 'res_samples', 'res_dataset', 'len_latent', 'num_classes', 'class_condition',
@@ -63,15 +63,9 @@ class GANLearner(object):
                              f'less than\nor equal to resolution of dataset (config.res_dataset = '
                              f'{config.res_dataset}) at all times.\nPlease set config.res_samples <= '
                              f'config.res_dataset.')
-        # resamplers (:147-176): only the hot-path choices have kernels
-        if config.model_upsample_type.casefold() != 'nearest':
-            raise ValueError("config does not support this model_upsample_type on the HIP path.\n"
-                             "Supported Upsampling Types are: [ 'nearest' ]")
-        self.gen_model_upsampler = Upsample2x()
-        if config.model_downsample_type.casefold() not in ('average', 'box',):
-            raise ValueError("config does not support this model_downsample_type on the HIP path.\n"
-                             "Supported Downsampling Types are: [ 'average', 'box' ]")
-        self.disc_model_downsampler = AvgPool2x()
+        # resamplers (:147-176)
+        self.gen_model_upsampler = make_upsampler(config.model_upsample_type, config.align_corners)
+        self.disc_model_downsampler = make_downsampler(config.model_downsample_type, config.align_corners)
         # nonlinearity (:178-184)
         nl = config.nonlinearity.casefold()
         if nl == 'leaky relu':
@@ -196,7 +190,8 @@ class GANLearner(object):
         # :573-578 - the minimax generator loss here is -BCE(D(G(z)), 0), like backprop_utils
         loss = self.loss_func_gen(out)
         self.reducer.arm(self.arena_g)
-        loss.backward()
+        with ops.direct_param_grads(parallel.world_size() == 1):      # first-use gradients land in the arena directly
+            loss.backward()
         self.reducer.allreduce(self.arena_g.gflat)
         self.opt_gen.step()
         return loss.detach()
@@ -215,7 +210,8 @@ class GANLearner(object):
         if self.gradient_penalty is not None:
             loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
         self.reducer.arm(self.arena_d)
-        loss.backward()
+        with ops.direct_param_grads(parallel.world_size() == 1):
+            loss.backward()
         self.reducer.allreduce(self.arena_d.gflat)
         self.opt_disc.step()
         return loss.detach()

@@ -8,7 +8,7 @@ containers; ``forward`` hands their children to the peephole executor so that
 from torch import nn
 
 from .. import ops
-from ..utils.custom_layers import (AvgPool2x, Conv2dEx, Lambda, LeakyReLU, NormalizeLayer, Upsample2x,
+from ..utils.custom_layers import (AvgPool2x, Conv2dEx, Lambda, LeakyReLU, NormalizeLayer, Upsample2x, own_resampler,
                                    fused_sequential, get_blur_op)
 
 
@@ -23,14 +23,7 @@ def _own_nl(nl):
     raise NotImplementedError(f'nonlinearity {nl!r} has no HIP kernel (ReLU / LeakyReLU only)')
 
 
-def _own_resampler(m):
-    if m is None or isinstance(m, (Upsample2x, AvgPool2x)):
-        return m
-    if isinstance(m, nn.Upsample) and m.mode == 'nearest' and float(m.scale_factor) == 2.:
-        return Upsample2x()
-    if isinstance(m, nn.AvgPool2d) and m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2)):
-        return AvgPool2x()
-    raise NotImplementedError(f'resampler {m!r} has no HIP kernel (nearest x2 / 2x2 average only)')
+_own_resampler = own_resampler
 
 
 class ResBlock2d(nn.Module):

@@ -19,7 +19,7 @@ from torch import nn
 from .. import ops, rng
 from .._int import FMAP_SAMPLES, RES_INIT
 from ..utils.custom_layers import (Blur2d, Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer, Upsample2x,
-                                   fused_sequential, get_blur_op)
+                                   fused_sequential, get_blur_op, own_resampler)
 from ..utils.latent_utils import gen_rand_latent_vars
 from .base import StyleGAN
 
@@ -84,9 +84,7 @@ class StyleGenerator(StyleGAN):
         if num_classes:
             raise NotImplementedError('class-conditioned mapping network: SURVEY.md §8f item 4 (next)')
         self.gen_layers = nn.ModuleList()
-        self.upsampler = upsampler if upsampler is not None else Upsample2x()
-        if not isinstance(self.upsampler, Upsample2x):
-            raise NotImplementedError("model_upsample_type must be 'nearest' on the HIP path")
+        self.upsampler = own_resampler(upsampler) if upsampler is not None else Upsample2x()
         self.gen_blur_type = blur_type
         self.nl = nl if nl is not None else LeakyReLU(.2)
         self.equalized_lr = equalized_lr

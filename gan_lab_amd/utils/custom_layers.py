@@ -55,6 +55,94 @@ class AvgPool2x(nn.Module):
         return ops.avg_pool2(x)
 
 
+class BilinearUpsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=...) stand-in (resnetgan/learner.py:147-158): a
+    table-driven streaming kernel in front of a plain 3x3 conv (no fold into the stride-2 kernels)."""
+
+    def __init__(self, align_corners=False):
+        super().__init__()
+        self.align_corners = bool(align_corners)
+
+    def forward(self, x):
+        return ops.resample(x, 'bilinear_up', self.align_corners)
+
+    def extra_repr(self):
+        return f'scale_factor=2.0, mode=bilinear, align_corners={self.align_corners}'
+
+
+class NearestPool2x(nn.Module):
+    """NearestPool2d stand-in (custom_layers.py:59-65): F.interpolate(scale_factor=.5, mode='nearest') = x[..., ::2, ::2]."""
+
+    def forward(self, x):
+        return ops.resample(x, 'nearest_down')
+
+
+class BilinearPool2x(nn.Module):
+    """BilinearPool2d stand-in (custom_layers.py:67-75).  Without align_corners the 0.5x bilinear samples fall on the
+    centres of the 2x2 cells - the 2x2 average - and the layer takes the average pool's kernels and folds
+    (``is_avg_pool``); with align_corners it is a two-tap gather of its own."""
+
+    def __init__(self, align_corners=False):
+        super().__init__()
+        self.align_corners = bool(align_corners)
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.view(-1, *x.shape)
+        return ops.resample(x, 'bilinear_down', True) if self.align_corners else ops.avg_pool2(x)
+
+    def extra_repr(self):
+        return f'align_corners={self.align_corners}'
+
+
+def is_avg_pool(m):
+    """Is ``m`` a 2x2 average (the stride-2 conv kernels fold it)?"""
+    return isinstance(m, AvgPool2x) or (isinstance(m, BilinearPool2x) and not m.align_corners)
+
+
+def make_upsampler(kind, align_corners=False):
+    """config.model_upsample_type -> module (resnetgan/learner.py:147-158)."""
+    kind = kind.casefold()
+    if kind == 'nearest':
+        return Upsample2x()
+    if kind == 'bilinear':
+        return BilinearUpsample2x(align_corners)
+    raise ValueError("config does not support this model_upsample_type.\n"
+                     "Supported Upsampling Types are: [ 'nearest', 'bilinear' ]")
+
+
+def make_downsampler(kind, align_corners=False):
+    """config.model_downsample_type -> module (resnetgan/learner.py:160-173)."""
+    kind = kind.casefold()
+    if kind in ('average', 'box',):
+        return AvgPool2x()
+    if kind == 'nearest':
+        return NearestPool2x()
+    if kind == 'bilinear':
+        return BilinearPool2x(align_corners)
+    raise ValueError("config does not support this model_downsample_type.\n"
+                     "Supported Downsampling Types are: [ 'nearest', 'average', 'box', 'bilinear' ]")
+
+
+def own_resampler(m):
+    """A torch / reference resampler module -> this package's (None and own modules pass through)."""
+    if m is None or isinstance(m, (Upsample2x, BilinearUpsample2x, AvgPool2x, NearestPool2x, BilinearPool2x)):
+        return m
+    if isinstance(m, nn.Upsample) and float(m.scale_factor) == 2.:
+        if m.mode == 'nearest':
+            return Upsample2x()
+        if m.mode == 'bilinear':
+            return BilinearUpsample2x(bool(m.align_corners))
+    if isinstance(m, nn.AvgPool2d) and m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2)):
+        return AvgPool2x()
+    name = type(m).__name__
+    if name == 'NearestPool2d':
+        return NearestPool2x()
+    if name == 'BilinearPool2d':
+        return BilinearPool2x(bool(getattr(m, 'align_corners', False)))
+    raise NotImplementedError(f'resampler {m!r} has no HIP kernel (nearest / bilinear x2, 2x2 average, nearest / bilinear x0.5)')
+
+
 class Blur2d(nn.Module):
     """Depthwise 3x3 binomial blur, zero padding (custom_layers.py:41-51)."""
 
@@ -288,7 +376,7 @@ class LinearBias(nn.Module):
 def _folds_act_grad(conv, after, width):
     """``conv`` (fed a ``width``-wide map, followed by ``after``) applies the previous layer's LeakyReLU derivative in
     its dgrad epilogue: a plain 3x3 'same' conv (no pooling behind it) on the fp32 kernels, rows of >= 16 pixels."""
-    return isinstance(conv, Conv2dEx) and not isinstance(after, AvgPool2x) and conv.conv2d.kernel_size == (3, 3) and \
+    return isinstance(conv, Conv2dEx) and not is_avg_pool(after) and conv.conv2d.kernel_size == (3, 3) and \
         conv.padding == 1 and width >= 16 and width % 4 == 0 and ops.get_compute_dtype() == 'f32'
 
 
@@ -337,7 +425,7 @@ def fused_sequential(mods, x):
             x = m(x, **kw)
         elif isinstance(m, (Conv2dEx, LinearEx, Conv2dBias, LinearBias)):
             kw = {}
-            if isinstance(m, Conv2dEx) and not up and isinstance(nxt, AvgPool2x):
+            if isinstance(m, Conv2dEx) and not up and is_avg_pool(nxt):
                 # conv -> AvgPool2d(2) [-> Conv2dBias] [-> LeakyReLU]: one stride-2 kernel (a bias of
                 # the conv itself commutes with the pooling: pool(conv + b) = pool(conv) + b)
                 kw['pool'] = True

@@ -172,6 +172,12 @@ int ganlab_up2_f32(const float* x, float* y, long long planes, int H, int W, flo
 /* y[h,w] = scale * sum_{i,j<2} x[2h+i,2w+j]  (avg-pool with scale .25; backward of up2) */
 int ganlab_pool2_f32(const float* x, float* y, long long planes, int Hout, int Wout, float scale,
                      void* stream);
+/* The other resamplers of custom_layers.py:59-75 (NearestPool2d, BilinearPool2d) and of nn.Upsample(mode='bilinear')
+ * (resnetgan/learner.py:147-170), forward and adjoint: a separable table-driven gather
+ *   y[p,oy,ox] = sum_{a<Ty} sum_{b<Tx} wy[oy*Ty+a] * wx[ox*Tx+b] * x[p, iy[oy*Ty+a], ix[ox*Tx+b]]
+ * with int32 source indices / float weights per output row and column (1 <= Ty, Tx <= 6; pad with weight 0). */
+int ganlab_resample2d_f32(const float* x, float* y, const int* iy, const float* wy, const int* ix, const float* wx,
+                          long long planes, int Hi, int Wi, int Ho, int Wo, int Ty, int Tx, void* stream);
 
 /* ---- bias / activation / noise (custom_layers.py:213-226, stylegan/architectures.py:105-119) ---- */
 /* y = act(x + noise_w[c]*noise[n,hw] + bias[c]*bias_scale); noise/noise_w and bias may be NULL. */

@@ -21,6 +21,9 @@ DEFAULT_CFG = dict(
     leak=0.2,
     equalized_lr=True,
     mbstd_group_size=4,
+    upsample='nearest',     # config.model_upsample_type: 'nearest' | 'bilinear'
+    downsample='average',   # config.model_downsample_type: 'average' | 'box' | 'nearest' | 'bilinear'
+    align_corners=False,    # config.align_corners (bilinear only)
 )
 
 
@@ -74,7 +77,7 @@ def _style_layer(sd, n, out, w, noise_n, cfg, first_conv_upsamples):
         cb = sd.get(ck[:-len('weight')] + 'bias')
         up = first_conv_upsamples
         if up:
-            out = ops.upsample2(out)
+            out = ops.upsample2(out, cfg['upsample'], cfg['align_corners'])
         out = ops.conv2d_ex(out, cw, cb, _ws(cw, 2.0, cfg), padding=1)
         if up and cfg['blur']:
             out = ops.blur_binomial(out)
@@ -169,7 +172,7 @@ def progen_forward(sd, z, cfg, alpha=1.0, fade_in=False):
         p0, p1 = f'gen_blocks.{i}.0.', f'gen_blocks.{i}.1.'
         ck = _idx_keys(sd, p0, 'conv2d.weight')[0]
         cw, cb = sd[ck], sd.get(ck[:-len('weight')] + 'bias')
-        x = ops.upsample2(x)
+        x = ops.upsample2(x, cfg['upsample'], cfg['align_corners'])
         x = ops.conv2d_ex(x, cw, cb, _ws(cw, 2.0, cfg), padding=1)
         if cfg['blur']:
             x = ops.blur_binomial(x)
@@ -214,7 +217,7 @@ def _disc_block(sd, i, x, cfg):
     ck = _idx_keys(sd, p1, 'conv2d.weight')[0]
     cw = sd[ck]
     x = ops.conv2d_ex(x, cw, None, _ws(cw, 2.0, cfg), padding=1)
-    x = ops.avgpool2(x)
+    x = ops.pool2(x, cfg['downsample'], cfg['align_corners'])
     bk = [k for k in _idx_keys(sd, p1, '.bias') if 'conv2d' not in k]
     x = x + sd[bk[0]]
     return ops.lrelu(x, cfg['leak'])

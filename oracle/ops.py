@@ -110,12 +110,26 @@ def lrelu(x, slope=0.2):
     return F.leaky_relu(x, slope)
 
 
-def upsample2(x):
-    return F.interpolate(x, scale_factor=2, mode='nearest')
+def upsample2(x, mode='nearest', align_corners=False):
+    """nn.Upsample(scale_factor=2, mode=...) as resnetgan/learner.py:147-158 builds it (align_corners only reaches
+    the bilinear mode); the fade-in skip connections always call it with the default (progan/architectures.py:52-53)."""
+    if mode == 'nearest':
+        return F.interpolate(x, scale_factor=2, mode='nearest')
+    return F.interpolate(x, scale_factor=2, mode=mode, align_corners=bool(align_corners))
 
 
 def avgpool2(x):
     return F.avg_pool2d(x, kernel_size=2, stride=2)
+
+
+def pool2(x, mode='average', align_corners=False):
+    """The critic's pooler (resnetgan/learner.py:160-173): nn.AvgPool2d(2, 2) | NearestPool2d | BilinearPool2d
+    (utils/custom_layers.py:59-75)."""
+    if mode in ('average', 'box'):
+        return avgpool2(x)
+    if mode == 'nearest':
+        return F.interpolate(x, scale_factor=.5, mode='nearest')
+    return F.interpolate(x, scale_factor=.5, mode='bilinear', align_corners=bool(align_corners))
 
 
 # -- utils/backprop_utils.py:19-49, progan/learner.py:791-812,883-896 ---------------------------- #

@@ -60,9 +60,25 @@ def randomize_zero_params(module, gen):
 
 
 # ---------------------------------------------------------------------------------------------- #
-def make_nets(kind, res, blur='binomial', mbstd=4, **gkw):
+def ref_resamplers(up, down, align):
+    """The generator's upsampler and the critic's pooler as resnetgan/learner.py:147-173 builds them from
+    config.model_upsample_type / model_downsample_type / align_corners."""
+    upsampler = nn.Upsample(scale_factor=2, mode=up, align_corners=(align if up == 'bilinear' else None))
+    if down in ('average', 'box'):
+        pooler = nn.AvgPool2d(kernel_size=2, stride=2)
+    elif down == 'nearest':
+        pooler = ns.cl.NearestPool2d()
+    else:
+        pooler = ns.cl.BilinearPool2d(align_corners=align)
+    return upsampler, pooler
+
+
+def make_nets(kind, res, blur='binomial', mbstd=4, resample=None, **gkw):
     """Build reference G and D the way the learners do (stylegan/learner.py:114-163,
     progan/learner.py:120-160) and grow them to `res` (fade_in_phase left True)."""
+    dkw = {}
+    if resample is not None:
+        gkw['upsampler'], dkw['pooler'] = ref_resamplers(*resample)
     if kind == 'stylegan':
         ns.sb.FMAP_BASE, ns.sb.FMAP_MAX = FMAP_BASE, FMAP_MAX
         Base = type('StyleGAN', (nn.Module, ABC,), dict(ns.sb.StyleGAN.__dict__))
@@ -82,7 +98,7 @@ def make_nets(kind, res, blur='binomial', mbstd=4, **gkw):
         kw = dict(final_res=64, len_latent=LEN_LATENT, blur_type=blur)
         kw.update(gkw)
         g = G(**kw)
-    d = D(final_res=64, blur_type=blur, mbstd_group_size=mbstd)
+    d = D(final_res=64, blur_type=blur, mbstd_group_size=mbstd, **dkw)
     for _ in range(int(np.log2(res)) - 2):
         g.increase_scale()
         d.increase_scale()
@@ -286,6 +302,9 @@ def golden_nets(kind, res, fade_in, alpha, tag, b=4, loss='nonsaturating', gp='r
         if p.grad is not None:
             out['ggp.' + k] = T(p.grad)
     out['meta'] = np.array([kind, loss, gp], dtype='U16')
+    if gkw.get('resample') is not None:
+        up, down, align = gkw['resample']
+        out['resample'] = np.array([up, down, str(int(bool(align)))], dtype='U16')
     save(f'{tag}.npz', **out)
 
 
@@ -785,6 +804,13 @@ if __name__ == '__main__':
         'pg_fade8': lambda: golden_nets('progan', 8, True, 0.6, 'progan_fade8', loss='wgan', gp='wgan-gp',
                                         seed=5),
         'sg_r2_8': lambda: golden_nets('stylegan', 8, False, 1.0, 'stylegan_r2_8', gp='r2', seed=6),
+        # the other resamplers (custom_layers.py:59-75, resnetgan/learner.py:147-173): (upsample, downsample, align_corners)
+        'sg_bilinear16': lambda: golden_nets('stylegan', 16, False, 1.0, 'stylegan_bilinear16', seed=7,
+                                             resample=('bilinear', 'bilinear', True)),
+        'pg_nearest16': lambda: golden_nets('progan', 16, True, 0.4, 'progan_nearest16', loss='wgan', gp='wgan-gp',
+                                            seed=8, resample=('bilinear', 'nearest', False)),
+        'sg_bilinear8': lambda: golden_nets('stylegan', 8, False, 1.0, 'stylegan_bilinear8', seed=9,
+                                            resample=('bilinear', 'bilinear', False)),
         'mixing': golden_mixing,
         'step_sg': lambda: golden_step('stylegan', 16, 'step_stylegan16', 'nonsaturating', 'r1'),
         'step_sg_fade': lambda: golden_step('stylegan', 8, 'step_stylegan8_fade', 'nonsaturating', 'r1',

@@ -252,6 +252,69 @@ def test_training_is_bitwise_reproducible():
     assert la == lb
 
 
+def test_direct_parameter_gradients_equal_the_accumulated_ones():
+    """``ops.direct_param_grads`` (the learners' backward sweeps in a single-process run): the first gradient of a parameter
+    in a step is written into its zeroed arena slot by the kernel that computes it, later ones go through AccumulateGrad.
+    0 + g is exact and the order of the contributions is unchanged, so both arenas must match the plain path BIT FOR BIT
+    - and most of the per-parameter ``grad += g`` launches must be gone."""
+    from gan_lab_amd import ops, progressive as P, rng
+    from gan_lab_amd.utils.data_utils import SyntheticImageLoader
+    P.FMAP_BASE, P.FMAP_MAX = 2048, 64
+    real = next(iter(SyntheticImageLoader(64, 4, 64, seed=3)))
+    real = (real[0] if isinstance(real, (tuple, list)) else real).cuda()
+
+    class Off(object):                                   # stands in for ops.direct_param_grads: never enables
+        def __init__(self, *_):
+            pass
+
+        def __enter__(self):
+            pass
+
+        def __exit__(self, *exc):
+            return False
+
+    def run(direct):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        L = make_learner('stylegan', 64, batch=4, loss='nonsaturating', gradient_penalty='r1', random_seed=11)
+        L.gen_model.train()
+        L.disc_model.train()
+        rng.manual_seed(5)
+        orig = ops.direct_param_grads
+        taken = [0]
+        if direct:
+            take = ops._take
+
+            def counting(name, shape, like):
+                out = take(name, shape, like)
+                taken[0] += int(bool(ops._TAKEN.get(name)))
+                return out
+            ops._take = counting
+        else:
+            ops.direct_param_grads = Off
+        try:
+            L.d_step(real, defer_update=True)
+            gd = L.arena_d.gflat.clone()
+            L.g_step(d_update_pending=True)
+            gg = L.arena_g.gflat.clone()
+        finally:
+            ops.direct_param_grads = orig
+            if direct:
+                ops._take = take
+        torch.cuda.synchronize()
+        n_params = len(L.arena_d.params) + len(L.arena_g.params)
+        return gd, gg, L.arena_d.flat.clone(), L.arena_g.flat.clone(), taken[0], n_params
+    try:
+        a, b = run(True), run(False)
+    finally:
+        P.FMAP_BASE, P.FMAP_MAX = 8192, 512
+    for i, what in enumerate(('critic gradients', 'generator gradients', 'critic parameters', 'generator parameters')):
+        assert a[i].abs().max() > 0
+        assert torch.equal(a[i], b[i]), what
+    assert a[4] >= 0.6 * a[5], f'only {a[4]} of {a[5]} parameters took the direct path'
+    assert b[4] == 0
+
+
 def test_load_reference_written_stylegan_checkpoint(tmp_path):
     """tests/golden/ref_stylegan_ckpt.tar was written by the reference's own StyleGANLearner.save_model
     (stylegan/learner.py:432-501: 9 main iterations, 4x4 -> 8x8 mid fade-in, truncation trick on).  The expectations

@@ -12,19 +12,24 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def build_pair(kind, res, sd_g, sd_d):
+def build_pair(kind, res, sd_g, sd_d, resample=None):
     from gan_lab_amd import progressive as P
     from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator, StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
+    from gan_lab_amd.utils.custom_layers import make_downsampler, make_upsampler
     P.FMAP_BASE, P.FMAP_MAX = 64, 16       # the fixtures' shrunken widths (tests/golden/make_golden.py)
+    gkw, dkw = {}, {}
+    if resample is not None:               # (model_upsample_type, model_downsample_type, align_corners)
+        gkw['upsampler'] = make_upsampler(resample[0], resample[2])
+        dkw['pooler'] = make_downsampler(resample[1], resample[2])
     if kind == 'stylegan':
         P.StyleGAN.reset_state()
-        g = StyleGenerator(final_res=64, len_latent=16, len_dlatent=16, mapping_num_fcs=2, blur_type='binomial')
-        d = StyleDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4)
+        g = StyleGenerator(final_res=64, len_latent=16, len_dlatent=16, mapping_num_fcs=2, blur_type='binomial', **gkw)
+        d = StyleDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4, **dkw)
     else:
         P.ProGAN.reset_state()
-        g = ProGenerator(final_res=64, len_latent=16, blur_type='binomial')
-        d = ProDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4)
+        g = ProGenerator(final_res=64, len_latent=16, blur_type='binomial', **gkw)
+        d = ProDiscriminator(final_res=64, blur_type='binomial', mbstd_group_size=4, **dkw)
     for _ in range(int(np.log2(res)) - 2):
         g.increase_scale()
         d.increase_scale()
@@ -41,7 +46,8 @@ def _restore_widths():
     P.FMAP_BASE, P.FMAP_MAX = 8192, 512
 
 
-NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16', 'progan_fade8']
+NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16', 'progan_fade8',
+        'stylegan_bilinear16', 'progan_nearest16', 'stylegan_bilinear8']    # last three: the other resamplers
 
 
 @pytest.mark.parametrize('name', NETS)
@@ -51,7 +57,11 @@ def test_nets_match_reference_golden(name):
     G = load_golden(name + '.npz')
     kind, loss, gp = [str(s) for s in G['meta']]
     res, alpha, fade = int(G['res']), float(G['alpha']), bool(G['fade_in'])
-    g, d = build_pair(kind, res, sub(G, 'g.'), sub(G, 'd.'))
+    resample = None
+    if 'resample' in G:
+        up, down, align = [str(s) for s in G['resample']]
+        resample = (up, down, bool(int(align)))
+    g, d = build_pair(kind, res, sub(G, 'g.'), sub(G, 'd.'), resample)
     g.fade_in_phase = fade
     g.alpha = alpha if fade else 1
     g.eval()

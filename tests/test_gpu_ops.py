@@ -1125,3 +1125,30 @@ def test_fromrgb_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     a, b_ = run(True), run(False)
     for name, u, v in zip(['y', 'gx', 'gw', 'gb', 'gw (second order)'], a, b_):
         assert torch.equal(u, v), name
+
+
+@pytest.mark.parametrize('mode,scale,tmode,align', [('bilinear_up', 2, 'bilinear', False), ('bilinear_up', 2, 'bilinear', True),
+                                                    ('bilinear_down', .5, 'bilinear', True),
+                                                    ('bilinear_down', .5, 'bilinear', False),
+                                                    ('nearest_down', .5, 'nearest', False)])
+def test_resampler_variants_match_interpolate(ops, mode, scale, tmode, align):
+    """nn.Upsample(mode='bilinear') / BilinearPool2d / NearestPool2d (custom_layers.py:59-75): the table-driven kernel
+    against F.interpolate on the CPU - output, input gradient (adjoint gather) and the R1-shaped second order (the
+    gradient of |d out / d x|^2-like functionals reaches the pooler's forward again)."""
+    gen = torch.Generator().manual_seed(5)
+    for shape in ((2, 3, 4, 4), (3, 5, 16, 16), (1, 2, 6, 10), (2, 16, 64, 64)):
+        x0 = torch.randn(*shape, generator=gen)
+        kw = {} if tmode == 'nearest' else {'align_corners': align}
+        xr = x0.clone().requires_grad_(True)
+        yr = F.interpolate(xr, scale_factor=scale, mode=tmode, **kw)
+        cot = torch.randn(yr.shape, generator=gen)
+        xg = gpu(x0).requires_grad_(True)
+        yg = ops.resample(xg, mode, align)
+        assert_close(yg, yr, 1e-5, f'{mode} forward {shape}')
+        # second order: L = sum (d<y, cot * y>/dx)^2
+        gr, = torch.autograd.grad((yr * yr * cot).sum(), xr, create_graph=True)
+        gg, = torch.autograd.grad((yg * yg * gpu(cot)).sum(), xg, create_graph=True)
+        assert_close(gg, gr, 1e-5, f'{mode} input gradient {shape}')
+        (gr ** 2).sum().backward()
+        (gg ** 2).sum().backward()
+        assert_close(xg.grad, xr.grad, 1e-4, f'{mode} second order {shape}')

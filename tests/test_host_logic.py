@@ -381,3 +381,31 @@ def test_conditional_variants_row_is_closed_by_the_probe(monkeypatch):
         cfg = make_config('progan', dev='cpu', pin_memory=False, res_samples=8, res_dataset=8, num_classes=3, **kw)
         with pytest.raises(NotImplementedError, match='conditional_probe'):
             ProGANLearner(cfg)
+
+
+@pytest.mark.parametrize('mode,scale,tmode', [('bilinear_up', 2, 'bilinear'), ('bilinear_down', .5, 'bilinear'),
+                                              ('nearest_down', .5, 'nearest')])
+def test_resampler_tables_reproduce_interpolate(mode, scale, tmode):
+    """The host-built interpolation matrices of the table-driven resampler kernel (ops.resample_matrix: ATen's
+    source-index arithmetic restated) against F.interpolate itself - what the reference's nn.Upsample(mode='bilinear'),
+    NearestPool2d and BilinearPool2d call (utils/custom_layers.py:59-75) - and the tap tables handed to the kernel
+    (forward: <= 2 taps, adjoint: <= 6) against the matrices."""
+    import torch
+    import torch.nn.functional as F
+    from gan_lab_amd import ops
+    for align in ((False, True) if tmode == 'bilinear' else (False,)):
+        for n in (4, 6, 8, 16, 64, 256):
+            m = ops.resample_matrix(mode, align, n)
+            x = torch.randn(2, 3, n, n, dtype=torch.float64)
+            kw = {} if tmode == 'nearest' else {'align_corners': align}
+            y = F.interpolate(x.float(), scale_factor=scale, mode=tmode, **kw).double()
+            mm = torch.from_numpy(m)
+            assert (y - mm @ x @ mm.T).abs().max().item() < 1e-6, (mode, align, n)
+            for mat, tmax in ((m, 2), (m.T, 6)):
+                idx, w, t = ops._taps(mat)
+                assert t <= tmax
+                dense = np.zeros_like(mat)
+                for o in range(mat.shape[0]):
+                    for a in range(t):
+                        dense[o, idx[o, a]] += w[o, a]
+                assert np.abs(dense - mat).max() < 1e-7

@@ -102,7 +102,15 @@ def test_noise_and_losses(G):
 
 # ---------------------------------------------------------------------------------------------- #
 NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16',
-        'progan_fade8']
+        'progan_fade8', 'stylegan_bilinear16', 'progan_nearest16', 'stylegan_bilinear8']
+
+
+def _resample_cfg(g):
+    """The fixture's (model_upsample_type, model_downsample_type, align_corners), absent = the defaults."""
+    if 'resample' not in g:
+        return {}
+    up, down, align = [str(s) for s in g['resample']]
+    return dict(upsample=up, downsample=down, align_corners=bool(int(align)))
 
 
 def _run_gen(kind, sd, z, noise, cfg, alpha, fade):
@@ -115,7 +123,7 @@ def _run_gen(kind, sd, z, noise, cfg, alpha, fade):
 def test_whole_nets_forward_backward_gp(name):
     g = load_golden(name + '.npz')
     kind, loss, gp = [str(s) for s in g['meta']]
-    cfg = nets.make_cfg(use_pixelnorm=(kind == 'progan'))
+    cfg = nets.make_cfg(use_pixelnorm=(kind == 'progan'), **_resample_cfg(g))
     alpha, fade = float(g['alpha']), bool(g['fade_in'])
     sd_g = {k: v.requires_grad_(True) for k, v in sub(g, 'g.').items()}
     sd_d = {k: v.requires_grad_(True) for k, v in sub(g, 'd.').items()}
