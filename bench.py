@@ -62,6 +62,9 @@ def parse():
     p.add_argument('--cpu-baseline-batch', type=int, default=1)
     p.add_argument('--cpu-baseline-steps', type=int, default=3)
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--step-graph', choices=('auto', '0', '1'), default='auto',
+                   help='replay the stabilised iteration as HIP graphs (gan_lab_amd/graphs.py GraphedStep): auto = the '
+                        "learner's own rule (single process, resolutions up to 256 - the launch-bound configurations)")
     p.add_argument('--dry-run-dist', action='store_true',
                    help='rehearse the multi-rank path on CPU: gloo ranks build a small learner (host logic only), '
                         'broadcast its arenas and run the bucketed gradient exchange; no GPU is touched')
@@ -109,6 +112,8 @@ def build_learner(res, batch, device, dtype='f32', model='stylegan', seed=1234, 
 
 
 def one_step(learner, real):
+    if learner.use_step_graph and learner.step_graph.eligible():
+        return learner.step_graph(real)       # eager for its first calls, then HIP-graph replays (graphs.GraphedStep)
     learner.set_requires_grad_disc(True)
     ld = learner.d_step(real, defer_update=True)
     learner.set_requires_grad_disc(False)
@@ -550,6 +555,8 @@ def dry_run_dist(a, json_fd):
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
+    if a.step_graph != 'auto':
+        os.environ['GANLAB_STEP_GRAPH'] = a.step_graph
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and a.gpus > 1:
         sys.exit(launch_ranks(a))                   # parent: no torch.cuda call before or after
@@ -610,7 +617,15 @@ def main():
     # executed conv FLOPs of a step: counted on ONE more step outside the timed region (every stabilised step launches
     # the same kernels; the Python observer would cost a launch-bound configuration ~1 us per launch inside it)
     with flops:
-        wl.step()
+        prev = os.environ.get('GANLAB_STEP_GRAPH')
+        os.environ['GANLAB_STEP_GRAPH'] = '0'          # the observer sits in the Python launchers: count an eager step
+        try:
+            wl.step()
+        finally:
+            if prev is None:
+                del os.environ['GANLAB_STEP_GRAPH']
+            else:
+                os.environ['GANLAB_STEP_GRAPH'] = prev
     torch.cuda.synchronize()
     exchange = None
     if use_dist:
@@ -660,6 +675,9 @@ def main():
         }
         if exchange is not None:
             out['gradient_exchange'] = exchange
+        sg = getattr(wl.learner, '_step_graph', None)
+        out['step_graph'] = {'replayed': bool(sg is not None and sg.graphs),
+                             'graphs': len(sg.graphs) if sg is not None else 0}
         out.update(wl.extra)
     del wl
     torch.cuda.empty_cache()

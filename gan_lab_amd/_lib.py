@@ -166,6 +166,10 @@ SIGNATURES = {
     'ganlab_adam_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
     'ganlab_ewma_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_f, _c_p]),
     'ganlab_randn_f32': (_c_int, [_c_p, _c_ll, _c_u64, _c_u64, _c_p]),
+    'ganlab_randn_dev_f32': (_c_int, [_c_p, _c_ll, _c_u64, _c_p, _c_u64, _c_p]),
+    'ganlab_adam_dev_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_ll, _c_p, _c_f, _c_f, _c_f, _c_f, _c_p]),
+    'ganlab_step_scalars_size': (_c_int, []),
+    'ganlab_set_step_scalars': (_c_int, [_c_p, _c_u64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
 }
 
 _LIB = None

@@ -1287,8 +1287,8 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ gy, const float* __res
 // ---------------------------------------------------------------------------------------------- //
 // elementwise axpby, reductions, losses
 // ---------------------------------------------------------------------------------------------- //
-__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
-                             long long n, float a, float b) {
+// (out may be y itself: every element is read before it is written, by the same thread)
+__global__ void axpby_kernel(const float* __restrict__ x, const float* y, float* out, long long n, float a, float b) {
   const long long n4 = n >> 2;
   GRID_STRIDE(i, n4) {
     float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -1410,9 +1410,17 @@ __global__ void chnorm_pen_bwd_kernel(const float* __restrict__ g, const float* 
 // ---------------------------------------------------------------------------------------------- //
 // optimiser + EWMA + RNG
 // ---------------------------------------------------------------------------------------------- //
+// ``dev``: (lr, bc1, bc2) of THIS step read from device memory - the step-graph form (graphs.py GraphedStep): a captured
+// launch replays with its arguments frozen, so what changes from step to step lives in a small device block that one
+// ordinary launch (set_scalars_kernel) rewrites before each replay
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2) {
+                            float bc1, float bc2, const float* __restrict__ dev) {
+  if (dev != nullptr) {
+    lr = dev[0];
+    bc1 = dev[1];
+    bc2 = dev[2];
+  }
   const float step = lr / bc1, isq = rsqrtf(bc2);
   GRID_STRIDE(i, n) {
     float gi = g[i];
@@ -1442,7 +1450,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
-__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
+// ``base``: device-resident stream position added to ``offset`` (step graphs, see adam_kernel)
+__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset,
+                             const uint64_t* __restrict__ base) {
+  if (base != nullptr) offset += *base;
   const long long n4 = (n + 3) >> 2;
   GRID_STRIDE(i, n4) {
     const uint64_t ctr = offset + (uint64_t)i;
@@ -1461,6 +1472,15 @@ __global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed
     }
     for (int k = 0; k < 4; ++k)
       if (i * 4 + k < n) out[i * 4 + k] = r[k];
+  }
+}
+
+__global__ void set_scalars_kernel(uint32_t* __restrict__ block, uint64_t rng_base, float f0, float f1, float f2,
+                                   float f3, float f4, float f5) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *reinterpret_cast<uint64_t*>(block) = rng_base;
+    float* f = reinterpret_cast<float*>(block) + 4;
+    f[0] = f0; f[1] = f1; f[2] = f2; f[3] = f3; f[4] = f4; f[5] = f5;
   }
 }
 
@@ -1992,7 +2012,25 @@ int ganlab_adam_f32(float* p, const float* g, float* m, float* v, long long n, f
                     float eps, float wd, float bc1, float bc2, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) return GANLAB_EINVAL;
   GL_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, wd,
-                     bc1, bc2);
+                     bc1, bc2, (const float*)nullptr);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_adam_dev_f32(float* p, const float* g, float* m, float* v, long long n, const float* lr_bc1_bc2, float beta1,
+                        float beta2, float eps, float wd, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || !lr_bc1_bc2) return GANLAB_EINVAL;
+  GL_LAUNCH(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST, p, g, m, v, n, 0.f, beta1, beta2, eps, wd, 1.f, 1.f,
+            lr_bc1_bc2);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_step_scalars_size(void) { return GANLAB_STEP_SCALARS_BYTES; }
+
+int ganlab_set_step_scalars(void* block, uint64_t rng_base, float f0, float f1, float f2, float f3, float f4, float f5,
+                            void* stream) {
+  if (!block) return GANLAB_EINVAL;
+  GL_LAUNCH(set_scalars_kernel, dim3(1), dim3(64), 0, ST, reinterpret_cast<uint32_t*>(block), rng_base, f0, f1, f2, f3,
+            f4, f5);
   return GL_CHECK_LAUNCH();
 }
 
@@ -2004,7 +2042,15 @@ int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void
 
 int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream) {
   if (!out || n <= 0) return GANLAB_EINVAL;
-  GL_LAUNCH(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, offset);
+  GL_LAUNCH(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, offset,
+            (const uint64_t*)nullptr);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_randn_dev_f32(float* out, long long n, uint64_t seed, const void* base, uint64_t delta, void* stream) {
+  if (!out || n <= 0 || !base) return GANLAB_EINVAL;
+  GL_LAUNCH(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, ST, out, n, seed, delta,
+            reinterpret_cast<const uint64_t*>(base));
   return GL_CHECK_LAUNCH();
 }
 

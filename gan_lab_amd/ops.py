@@ -202,6 +202,31 @@ def bump_weight_epoch(ranges=None):
         _PACK_RANGES[(int(r[0]), int(r[1]))] = _PACK_SERIAL[0]
 
 
+def mark_packs_stale():
+    """Every cached packed weight is re-packed at its next use, but the cache entries, their buffers and the descriptor
+    tables of the batched re-pack stay (``bump_weight_epoch()`` without arguments drops them).  graphs.GraphedStep: a step
+    graph must pack what it uses itself - with the ONE launch per parameter range of the steady state, whose table is
+    already on the device - and a replay rewrites the parameters behind the host's back."""
+    if _PACK_RANGES:
+        bump_weight_epoch(list(_PACK_RANGES.keys()))
+    else:
+        bump_weight_epoch()
+
+
+def _pack_one(e):
+    """Re-pack one cache entry with its own kernel (the batched launch's table cannot be uploaded while a capture runs)."""
+    L = _lib.lib()
+    kind, cout, cin, ks, mode, up, scale, total = e.desc
+    if kind == _KIND_S2:
+        rc = L.ganlab_conv_s2_pack_f32(_p(e.w), _p(e.out), cout, cin, up, mode, scale, _st())
+    elif kind == _KIND_BF16:
+        rc = L.ganlab_conv_pack_bf16(_p(e.w), e.out.data_ptr(), cout, cin, mode, scale, _st())
+    else:
+        rc = L.ganlab_conv_pack_f32(_p(e.w), _p(e.out), cout, cin, ks, mode, scale, _st())
+    if rc != total:
+        raise _lib.GanlabLibraryError(f're-pack failed ({rc} != {total})')
+
+
 def _stale_range(e):
     for r, ser in _PACK_RANGES.items():
         if ser > e.serial and r[0] <= e.ptr < r[1]:
@@ -216,6 +241,11 @@ def _repack_range(r):
     items = [(k, e) for k, e in _PACK_CACHE.items() if r[0] <= e.ptr < r[1] and e.serial < ser]
     keys = tuple(k for k, _ in items)
     tab = _PACK_TABLES.get(r)
+    if (tab is None or tab[0] != keys) and torch.cuda.is_current_stream_capturing():
+        for _, e in items:          # no host-to-device copy inside a capture: one kernel per entry
+            _pack_one(e)
+            e.serial = _PACK_SERIAL[0]
+        return
     if tab is None or tab[0] != keys:
         arr = (_lib.PackDesc * len(items))()
         blocks = 0
@@ -972,12 +1002,16 @@ def k_channel_sum(a, b=None, scale=1.0, sink=None):
     return out
 
 
-def k_axpby(x, y, a, b):
+def k_axpby(x, y, a, b, out=None):
+    """a*x + b*y; ``out`` may be ``y`` itself (running averages updated in place: a captured step must write the buffer
+    the next replay reads)."""
     x = _c(x)
     y = _c(y) if y is not None else None
     if y is not None:
         assert x.shape == y.shape
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.shape == x.shape
     check(_lib.lib().ganlab_axpby_f32(_p(x), _p(y), _p(out), x.numel(), a, b, _st()), 'axpby')
     return out
 
@@ -1007,6 +1041,14 @@ def randn(shape, seed, offset, device):
     return out
 
 
+def randn_dev(shape, seed, base, delta, device):
+    """``randn`` at stream position ``*base + delta`` (``base``: the step-scalar block of graphs.GraphedStep)."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().ganlab_randn_dev_f32(_p(out), out.numel(), int(seed) & (2 ** 64 - 1), _p(base), int(delta), _st()),
+          'randn_dev')
+    return out
+
+
 def lerp_rows(a, b, t):
     a, b, t = _c(a), _c(b), _c(t)
     out = torch.empty_like(a)
@@ -1018,6 +1060,18 @@ def lerp_rows(a, b, t):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, bc1, bc2):
     check(_lib.lib().ganlab_adam_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
                                      _st()), 'adam')
+
+
+def adam_step_dev(p, g, m, v, scalars, beta1, beta2, eps, wd):
+    """``adam_step`` with (lr, 1 - beta1^t, 1 - beta2^t) read from the three floats at ``scalars`` (a device pointer)."""
+    check(_lib.lib().ganlab_adam_dev_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), ctypes.c_void_p(scalars), beta1, beta2, eps,
+                                         wd, _st()), 'adam_dev')
+
+
+def set_step_scalars(block, rng_base, floats):
+    f = [float(v) for v in floats] + [0.0] * (6 - len(floats))
+    check(_lib.lib().ganlab_set_step_scalars(ctypes.c_void_p(block.data_ptr()), int(rng_base) & (2 ** 64 - 1), *f[:6],
+                                             _st()), 'set_step_scalars')
 
 
 def ewma_step(lagged, p, beta):

@@ -97,6 +97,22 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._runs = None
         self._sig = None
+        # step-graph capture (graphs.GraphedStep): device address of this optimiser's (lr, 1-beta1^t, 1-beta2^t); while
+        # set, step() launches the kernel that reads them there and leaves the step count to host_scalars()
+        self.dev_scalars = None
+
+    def host_scalars(self, advance=True):
+        """(lr, 1 - beta1^t, 1 - beta2^t) of the NEXT step of the (single) parameter group, advancing its step count:
+        what ``step()`` computes on the host, for a replayed step."""
+        group = self.param_groups[0]
+        cached = self.state.get('_fused', {}).get(id(group))
+        if cached is None:
+            raise RuntimeError('host_scalars() before the first eager step()')
+        if advance:
+            cached['step'] += 1
+        t = cached['step']
+        b1, b2 = group['betas']
+        return float(group['lr']), 1 - b1 ** t, 1 - b2 ** t
 
     def _build_runs(self, params):
         items = sorted(((p.data_ptr(), p) for p in params), key=lambda t: t[0])
@@ -141,17 +157,21 @@ class FusedAdam(torch.optim.Optimizer):
                     if old is not None:  # carry moments across a re-layout
                         self._carry(old, r)
                 st[key] = cached
-            cached['step'] += 1
-            t = cached['step']
             b1, b2 = group['betas']
-            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            if self.dev_scalars is None:
+                cached['step'] += 1
+                t = cached['step']
+                bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
             for r in cached['runs']:
                 p0 = r['params'][0]
                 # raw views over the whole run (padding floats have zero grad -> stay zero)
                 pv = torch.as_strided(p0.data.reshape(-1), (r['n'],), (1,))
                 gv = torch.as_strided(p0.grad.reshape(-1), (r['n'],), (1,))
-                ops.adam_step(pv, gv, r['m'], r['v'], group['lr'], b1, b2, group['eps'], group['weight_decay'],
-                              bc1, bc2)
+                if self.dev_scalars is not None:
+                    ops.adam_step_dev(pv, gv, r['m'], r['v'], self.dev_scalars, b1, b2, group['eps'], group['weight_decay'])
+                else:
+                    ops.adam_step(pv, gv, r['m'], r['v'], group['lr'], b1, b2, group['eps'], group['weight_decay'],
+                                  bc1, bc2)
                 touched.append((r['start'], r['end']))
         # packed conv weights inside the rewritten memory are stale: they are re-packed (all of them, one launch) at
         # their next use; the other network's stay valid

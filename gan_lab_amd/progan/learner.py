@@ -201,6 +201,23 @@ class ProGANLearner(GANLearner):
     def _gen_forward(self, zb, **kw):
         return self.gen_model(zb, **kw)
 
+    @property
+    def step_graph(self):
+        """The iteration's HIP-graph executor (graphs.GraphedStep), built on first use."""
+        if getattr(self, '_step_graph', None) is None:
+            from ..graphs import GraphedStep
+            self._step_graph = GraphedStep(self)
+        return self._step_graph
+
+    @property
+    def use_step_graph(self):
+        """config.use_step_graph / GANLAB_STEP_GRAPH: 1 = replay eligible iterations as HIP graphs, 0 = never, unset =
+        where the step is launch-bound (resolutions up to 256)."""
+        v = os.environ.get('GANLAB_STEP_GRAPH', getattr(self.config, 'use_step_graph', None))
+        if v in (None, '', 'auto'):
+            return self.gen_model.curr_res <= 256
+        return str(v).lower() not in ('0', 'false', 'no')
+
     def fade_in_real(self, xb):
         """Real images follow the generator's fade-in: up(down(x))*(1-alpha) + x*alpha
         (progan/learner.py:771-779, the non-bit-exact branch), on the device."""
@@ -393,40 +410,57 @@ class ProGANLearner(GANLearner):
                 self.set_requires_grad_disc(True)
                 self._apply_phase_events(sched, train_dl, valid_dl, z_valid_dl)
 
-                # ------------------------- TRAIN DISCRIMINATOR -------------------------
-                for disc_iter in range(num_disc_iters):
+                valid_due = (itr + 1) % c.num_iters_valid == 0 or itr == 0
+                metrics_due = valid_due and z_valid_dl is not None and (bool(c.gen_metrics) or
+                                                                        (valid_dl is not None and bool(c.disc_metrics)))
+                if self.use_step_graph and num_disc_iters == 1 and num_gen_iters == 1 and not metrics_due and \
+                        self.step_graph.eligible():
+                    # stabilised phase, single process: the whole iteration replayed as HIP graphs (graphs.GraphedStep)
                     batch = next(self.train_dataiter, None)
                     if batch is None:
                         self.curr_epoch_num += 1
                         self.train_dataiter = iter(train_dl)
                         batch = next(self.train_dataiter)
                     xb = batch[0].to(c.dev, non_blocking=True).float()
-                    last = disc_iter == num_disc_iters - 1
-                    valid_now = last and ((itr + 1) % c.num_iters_valid == 0 or itr == 0)
-                    d_metrics = valid_now and z_valid_dl is not None and valid_dl is not None and bool(c.disc_metrics)
-                    loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0 and not d_metrics)
-                    if d_metrics:       # validation metrics of the just-updated discriminator (:822-832)
-                        vals = self.compute_metrics(metrics=c.disc_metrics, metrics_type='Discriminator',
-                                                    z_valid_dl=z_valid_dl, valid_dl=valid_dl)
-                        if parallel.rank() == 0:
-                            print('|\n', 'Discriminator Validation Metrics:\n', *vals)
+                    loss_d, loss_g = self.step_graph(xb)
                     self.curr_dataset_batch_num += 1
                     sched.after_d_iter()
                     self.curr_img_num = sched.curr_img_num
+                else:
+                    # ------------------------- TRAIN DISCRIMINATOR -------------------------
+                    for disc_iter in range(num_disc_iters):
+                        batch = next(self.train_dataiter, None)
+                        if batch is None:
+                            self.curr_epoch_num += 1
+                            self.train_dataiter = iter(train_dl)
+                            batch = next(self.train_dataiter)
+                        xb = batch[0].to(c.dev, non_blocking=True).float()
+                        last = disc_iter == num_disc_iters - 1
+                        valid_now = last and ((itr + 1) % c.num_iters_valid == 0 or itr == 0)
+                        d_metrics = valid_now and z_valid_dl is not None and valid_dl is not None and bool(c.disc_metrics)
+                        loss_d = self.d_step(xb, defer_update=last and num_gen_iters > 0 and not d_metrics)
+                        if d_metrics:       # validation metrics of the just-updated discriminator (:822-832)
+                            vals = self.compute_metrics(metrics=c.disc_metrics, metrics_type='Discriminator',
+                                                        z_valid_dl=z_valid_dl, valid_dl=valid_dl)
+                            if parallel.rank() == 0:
+                                print('|\n', 'Discriminator Validation Metrics:\n', *vals)
+                        self.curr_dataset_batch_num += 1
+                        sched.after_d_iter()
+                        self.curr_img_num = sched.curr_img_num
 
-                # --------------------------- TRAIN GENERATOR ---------------------------
-                self.set_requires_grad_disc(False)
-                loss_g = None
-                for gen_iter in range(num_gen_iters):
-                    loss_g = self.g_step(d_update_pending=(gen_iter == 0))
-                    if gen_iter == num_gen_iters - 1 and z_valid_dl is not None and c.gen_metrics and \
-                            ((itr + 1) % c.num_iters_valid == 0 or itr == 0):     # (:921-928)
-                        vals = self.compute_metrics(metrics=c.gen_metrics, metrics_type='Generator',
-                                                    z_valid_dl=z_valid_dl, valid_dl=None)
-                        if parallel.rank() == 0:
-                            print('|\n', 'Generator Validation Metrics:\n', *vals)
-                if num_gen_iters == 0:
-                    self._finish_d_update()
+                    # --------------------------- TRAIN GENERATOR ---------------------------
+                    self.set_requires_grad_disc(False)
+                    loss_g = None
+                    for gen_iter in range(num_gen_iters):
+                        loss_g = self.g_step(d_update_pending=(gen_iter == 0))
+                        if gen_iter == num_gen_iters - 1 and z_valid_dl is not None and c.gen_metrics and \
+                                ((itr + 1) % c.num_iters_valid == 0 or itr == 0):     # (:921-928)
+                            vals = self.compute_metrics(metrics=c.gen_metrics, metrics_type='Generator',
+                                                        z_valid_dl=z_valid_dl, valid_dl=None)
+                            if parallel.rank() == 0:
+                                print('|\n', 'Generator Validation Metrics:\n', *vals)
+                    if num_gen_iters == 0:
+                        self._finish_d_update()
 
                 # alpha, LR schedule (progan/learner.py:951-956)
                 sched.end_iter()

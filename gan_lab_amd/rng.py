@@ -4,6 +4,21 @@ import torch
 from . import ops
 
 _STATE = {'seed': 0x5EED, 'offset': 0}
+# While a step graph is being captured (graphs.GraphedStep) the stream position cannot be a launch argument - it would be
+# frozen into the graph: draws then read a device-resident base (rewritten before every replay) and pass only their
+# distance from the position the capture started at.
+_DEVICE_BASE = {'block': None, 'start': 0}
+
+
+def begin_device_offsets(block):
+    _DEVICE_BASE['block'], _DEVICE_BASE['start'] = block, _STATE['offset']
+
+
+def end_device_offsets():
+    """Back to by-value offsets; returns how far the stream advanced since ``begin_device_offsets``."""
+    n = _STATE['offset'] - _DEVICE_BASE['start']
+    _DEVICE_BASE['block'] = None
+    return n
 
 
 def manual_seed(seed, rank=0):
@@ -35,6 +50,10 @@ def randn(shape, device='cuda'):
     n = 1
     for s in shape:
         n *= int(s)
-    out = ops.randn(tuple(shape), _STATE['seed'], _STATE['offset'], device)
+    if _DEVICE_BASE['block'] is not None:
+        out = ops.randn_dev(tuple(shape), _STATE['seed'], _DEVICE_BASE['block'], _STATE['offset'] - _DEVICE_BASE['start'],
+                            device)
+    else:
+        out = ops.randn(tuple(shape), _STATE['seed'], _STATE['offset'], device)
     _STATE['offset'] += (n + 3) // 4
     return out

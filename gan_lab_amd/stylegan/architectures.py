@@ -325,24 +325,31 @@ class StyleGenerator(StyleGAN):
                                   device=dev)
         return self.z_to_w(z2)
 
+    def draw_mixing_cutoff(self):
+        """The host coin + layer index of the mixing regularisation (:415-422): None = this forward is not mixed."""
+        if self._use_mixing_reg and np.random.rand() < self.pct_mixing_reg:
+            hi = 2 * self.scale_stage if self.alpha != 0 else 2 * self.scale_stage - 2
+            return torch.randint(1, hi, (1,)).item()
+        return None
+
     def forward(self, x, x_mixing=None, style_mixing_stage: int = None, noise=None, _mix=None):
         """``_mix=(cutoff_idx, z_mix)`` pins the mixing-regularisation draw (tests); otherwise it is
         drawn like the reference does (:415-422)."""
         cutoff_idx, z_mix = None, None
         if _mix is not None:
             cutoff_idx, z_mix = _mix
-        elif self._use_mixing_reg:
-            if np.random.rand() < self.pct_mixing_reg:
-                hi = 2 * self.scale_stage if self.alpha != 0 else 2 * self.scale_stage - 2
-                cutoff_idx = torch.randint(1, hi, (1,)).item()
+        else:
+            cutoff_idx = self.draw_mixing_cutoff()
         w = self.z_to_w(x)
         bs = w.shape[0]
         if self.use_truncation_trick:
             if self.training:
                 with torch.no_grad():  # running average of w for the eval-time truncation trick (:427-437)
                     wm = ops.k_channel_sum(w.detach(), None, 1.0 / bs)          # mean over the batch (HIP kernel)
-                    self.w_ewma = wm if self.w_ewma is None else \
-                        ops.k_axpby(wm, self.w_ewma, 1. - self.w_ewma_beta, self.w_ewma_beta)
+                    if self.w_ewma is None:
+                        self.w_ewma = wm
+                    else:     # in place: the same buffer every step (a replayed step graph reads what the last one wrote)
+                        ops.k_axpby(wm, self.w_ewma, 1. - self.w_ewma_beta, self.w_ewma_beta, out=self.w_ewma)
             elif self.trunc_cutoff_stage is not None:
                 w = self.w_ewma.expand_as(w) + self.w_eval_psi * (w - self.w_ewma.expand_as(w))
         out = self.const_input.expand(bs, -1, -1, -1)

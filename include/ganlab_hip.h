@@ -360,6 +360,21 @@ int ganlab_ewma_f32(float* lagged, const float* p, long long n, float beta, void
 /* counter-based N(0,1) generator (Philox4x32-10 + Box-Muller) for latents / per-layer noise */
 int ganlab_randn_f32(float* out, long long n, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- step-graph forms (gan_lab_amd/graphs.py GraphedStep; progan/learner.py:734-943 replayed as HIP graphs) ----
+ * A captured launch replays with frozen arguments, so the per-step scalars live in a GANLAB_STEP_SCALARS_BYTES device
+ * block: [0,8) the Philox stream position at the start of the replay, floats at byte 16: (lr, 1-beta1^t, 1-beta2^t) of
+ * the critic's optimiser, then of the generator's.  One ordinary launch rewrites it before each replay. */
+#define GANLAB_STEP_SCALARS_BYTES 64
+int ganlab_step_scalars_size(void);
+int ganlab_set_step_scalars(void* block, uint64_t rng_base, float f0, float f1, float f2, float f3, float f4, float f5,
+                            void* stream);
+/* ganlab_randn_f32 at stream position *base + delta (base: device uint64) */
+int ganlab_randn_dev_f32(float* out, long long n, uint64_t seed, const void* base, uint64_t delta, void* stream);
+/* ganlab_adam_f32 with (lr, bc1, bc2) read from device memory */
+int ganlab_adam_dev_f32(float* p, const float* g, float* m, float* v, long long n, const float* lr_bc1_bc2, float beta1,
+                        float beta2, float eps, float wd, void* stream);
+
+
 /* ---- real-image input path -----------------------------------------------------------
  * uint8 NHWC dataset images -> 2^k box downsample -> fp32 NCHW ((v/255 - mean[c]) / std[c]); replaces the host
  * chain PIL Image.resize(BOX) -> ToTensor -> Normalize (data_config.py:307-341, progan/learner.py:1099-1112).

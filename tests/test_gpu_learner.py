@@ -254,9 +254,10 @@ def test_training_is_bitwise_reproducible():
 
 def test_direct_parameter_gradients_equal_the_accumulated_ones():
     """``ops.direct_param_grads`` (the learners' backward sweeps in a single-process run): the first gradient of a parameter
-    in a step is written into its zeroed arena slot by the kernel that computes it, later ones go through AccumulateGrad.
-    0 + g is exact and the order of the contributions is unchanged, so both arenas must match the plain path BIT FOR BIT
-    - and most of the per-parameter ``grad += g`` launches must be gone."""
+    in a step is written into its zeroed arena slot by the kernel that computes it; the others are summed by the engine
+    and added by the parameter's AccumulateGrad node, which runs after every contributing Function - so nothing can be
+    overwritten.  Only the order of the additions differs from the plain path (g1 + (g2 + g3) against ((g1 + g2) + g3)):
+    both arenas and the updated parameters must agree to fp32 rounding - and most of the per-parameter ``grad += g`` launches must be gone."""
     from gan_lab_amd import ops, progressive as P, rng
     from gan_lab_amd.utils.data_utils import SyntheticImageLoader
     P.FMAP_BASE, P.FMAP_MAX = 2048, 64
@@ -279,6 +280,7 @@ def test_direct_parameter_gradients_equal_the_accumulated_ones():
         L = make_learner('stylegan', 64, batch=4, loss='nonsaturating', gradient_penalty='r1', random_seed=11)
         L.gen_model.train()
         L.disc_model.train()
+        L.beta = 0.999
         rng.manual_seed(5)
         orig = ops.direct_param_grads
         taken = [0]
@@ -310,9 +312,72 @@ def test_direct_parameter_gradients_equal_the_accumulated_ones():
         P.FMAP_BASE, P.FMAP_MAX = 8192, 512
     for i, what in enumerate(('critic gradients', 'generator gradients', 'critic parameters', 'generator parameters')):
         assert a[i].abs().max() > 0
-        assert torch.equal(a[i], b[i]), what
+        if what == 'generator gradients':   # taken through the critic AFTER its update, which already differs by rounding
+            assert (a[i] - b[i]).abs().max().item() <= 1e-3 * b[i].abs().max().item(), what
+        elif 'gradients' in what:
+            assert (a[i] - b[i]).abs().max().item() <= 4e-6 * b[i].abs().max().item(), what
+        else:       # one Adam step of lr 1e-3: a sign-sized move where a gradient is rounding noise around zero
+            assert (a[i] - b[i]).abs().max().item() <= 2.1e-3, what
     assert a[4] >= 0.6 * a[5], f'only {a[4]} of {a[5]} parameters took the direct path'
     assert b[4] == 0
+
+
+@pytest.mark.parametrize('kind', ['stylegan', 'progan'])
+def test_graphed_step_equals_eager(kind):
+    """graphs.GraphedStep: the stabilised iteration replayed as HIP graphs (device-resident Philox position and Adam
+    scalars, one graph per style-mixing cut and half) against the same learner stepping eagerly - parameters, Adam moments,
+    EWMA generator, the running w average and both losses BIT FOR BIT after 6 iterations, 4 of them replayed."""
+    from gan_lab_amd import progressive as P, rng
+    from gan_lab_amd.graphs import GraphedStep
+    gen = torch.Generator().manual_seed(17)
+    reals = [(torch.rand(4, 3, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(6)]
+
+    def run(graphed):
+        P.FMAP_BASE, P.FMAP_MAX = 1024, 64
+        torch.manual_seed(9)
+        np.random.seed(9)
+        kw = dict(loss='nonsaturating', gradient_penalty='r1') if kind == 'stylegan' else \
+            dict(loss='wgan', gradient_penalty='wgan-gp')
+        L = make_learner(kind, 32, batch=4, random_seed=21, **kw)
+        L.gen_model.train()
+        L.disc_model.train()
+        L.beta = 0.99
+        torch.manual_seed(10)               # the WGAN-GP interpolation weights come from torch's device generator
+        stepper = GraphedStep(L, warmup=2)
+        losses = []
+        for x in reals:
+            if graphed:
+                ld, lg = stepper(x)
+            else:
+                cut, kw_d = stepper._mix_kwargs()
+                ld = stepper._d_half(x, kw_d)
+                cut, kw_g = stepper._mix_kwargs()
+                lg = stepper._g_half(kw_g)
+            losses.append((float(ld), float(lg)))
+        torch.cuda.synchronize()
+        state = {'g': L.arena_g.flat.clone(), 'd': L.arena_d.flat.clone(), 'lag': L.ewma.flat.clone()}
+        for name, opt in (('og', L.opt_gen), ('od', L.opt_disc)):
+            ex = opt.export_moments(list(L.gen_model.named_parameters()) if name == 'og' else
+                                    list(L.disc_model.named_parameters()))
+            state[name + '.step'] = torch.tensor(ex['step'])
+            for k2, v in ex['exp_avg'].items():
+                state[f'{name}.m.{k2}'] = v
+            for k2, v in ex['exp_avg_sq'].items():
+                state[f'{name}.v.{k2}'] = v
+        if getattr(L.gen_model, 'w_ewma', None) is not None:
+            state['w_ewma'] = L.gen_model.w_ewma.clone()
+        return state, losses, (len(stepper.graphs) if graphed else 0), rng._STATE['offset']
+    try:
+        a, la, n_graphs, off_a = run(True)
+        b, lb, _, off_b = run(False)
+    finally:
+        P.FMAP_BASE, P.FMAP_MAX = 8192, 512
+    assert n_graphs >= 2, 'nothing was captured'
+    assert off_a == off_b, 'the device random stream advanced differently'
+    assert la == lb, (la, lb)
+    assert a.keys() == b.keys()
+    diff = [k for k in a if not torch.equal(a[k].cpu(), b[k].cpu())]
+    assert not diff, f'{len(diff)} of {len(a)} tensors differ between replayed and eager steps, e.g. {diff[:4]}'
 
 
 def test_load_reference_written_stylegan_checkpoint(tmp_path):
