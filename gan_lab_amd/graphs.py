@@ -84,24 +84,99 @@ class GraphedGenerator(object):
         return self.out
 
 
-class GraphedStep(object):
+class _StepGraphs(object):
+    """Capture / replay machinery shared by the learners' step graphs: a 64-byte device block of per-replay scalars, one
+    memory pool, graphs keyed by (half, variant)."""
+
+    def __init__(self, learner, warmup=2):
+        self.L = learner
+        self.warmup = int(warmup)
+        self._reset()
+
+    def _reset(self):
+        self.graphs, self.pool, self.sig, self.calls = {}, None, None, 0
+        self.block = self.real = None
+        self.losses = {}
+
+    def eligible(self):
+        from . import parallel
+        return parallel.world_size() == 1 and torch.cuda.is_available()
+
+    def _common_signature(self, real):
+        L = self.L
+        return (id(L.opt_disc), id(L.opt_gen), id(L.arena_d), id(L.arena_g), L.batch_size, tuple(real.shape), real.device,
+                ops.get_compute_dtype(), bool(L.gen_model.training), bool(L.disc_model.training))
+
+    def _check(self, sig):
+        if sig != self.sig:
+            self._reset()
+            self.sig = sig
+
+    def _capture(self, key, fn):
+        """Record ``fn()`` (a learner half returning its loss) as the graph ``key``."""
+        L = self.L
+        dev = self.real.device
+        if self.block is None:
+            self.block = torch.zeros(16, dtype=torch.int32, device=dev)
+            self.pool = torch.cuda.graph_pool_handle()
+        if key[0] not in self.losses:
+            self.losses[key[0]] = torch.zeros((), device=dev)
+        base = self.block.data_ptr()
+        # the graph packs the weights it uses itself: every cached pack is stale, and the steady state's batched re-pack
+        # (one launch per parameter range, descriptor table already on the device) is what gets captured
+        ops.mark_packs_stale()
+        known = set(ops._PACK_CACHE.keys())
+        start = rng._STATE['offset']
+        rng.begin_device_offsets(self.block)
+        L.opt_disc.dev_scalars, L.opt_gen.dev_scalars = base + 16, base + 28
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, pool=self.pool):
+                self.losses[key[0]].copy_(fn())
+        finally:
+            L.opt_disc.dev_scalars = L.opt_gen.dev_scalars = None
+            draws = rng.end_device_offsets()
+            rng._STATE['offset'] = start              # a capture records, it does not run: nothing was drawn yet
+            # packed weights first made during the capture live in the graph's pool: not for eager use
+            for k in [k for k in ops._PACK_CACHE if k not in known]:
+                del ops._PACK_CACHE[k]
+            ops.mark_packs_stale()
+        self.graphs[key] = (graph, draws)
+
+    def _replay(self, key, opts):
+        """``opts``: which optimisers step inside this graph (their step counts advance on the host here)."""
+        L = self.L
+        graph, draws = self.graphs[key]
+        scal = [0.0] * 6
+        if 'd' in opts:
+            scal[0:3] = L.opt_disc.host_scalars()
+        if 'g' in opts:
+            scal[3:6] = L.opt_gen.host_scalars()
+        ops.set_step_scalars(self.block, rng._STATE['offset'], scal)
+        graph.replay()
+        rng._STATE['offset'] += draws
+        ops.mark_packs_stale()          # the replay rewrote parameters (and the cached packs' buffers) on its own
+        return self.losses[key[0]]
+
+
+class GraphedStep(_StepGraphs):
     """One main iteration of a stabilised phase - ``d_step(real, defer_update=True)`` then
     ``g_step(d_update_pending=True)`` (progan/learner.py:734-943: critic loss + gradient penalty + backward, generator
     loss + backward, both Adam updates, the EWMA generator) - replayed as HIP graphs.
 
     The launch-bound configurations (StyleGAN-128 at batch 8: ~1300 launches of a few microseconds each per step; the
-    low-resolution phases of a growth schedule; the ResNet GAN) spend their step on the HOST: ctypes + autograd issue a
-    launch every ~12 us while the kernels need less.  A replay submits the same launches from the runtime's graph
-    executor.  What a captured launch cannot carry as an argument lives in a 64-byte device block that ONE ordinary
-    launch rewrites before each replay (``ganlab_set_step_scalars``):
+    4^2 / 8^2 phases of a growth schedule) spend their step on the HOST: ctypes + autograd issue a launch
+    every ~12 us while the kernels need less.  A replay submits the same launches from the runtime's graph executor.
+    What a captured launch cannot carry as an argument lives in a 64-byte device block that ONE ordinary launch rewrites
+    before each replay (``ganlab_set_step_scalars``):
       * the Philox stream position - the latent / per-layer noise draws pass their distance from it
         (``rng.begin_device_offsets``), so replay k draws exactly what eager step k would have drawn;
       * (lr, 1 - beta1^t, 1 - beta2^t) of both optimisers (``FusedAdam.dev_scalars``) - the LR schedule keeps working.
     The style-mixing cut (a host coin and a host integer per generator forward, stylegan/architectures.py:415-422) selects
     among captured VARIANTS of each half: ('d', cut) and ('g', cut), at most 2 * (layers + 1) graphs sharing one memory
-    pool, captured the first time a cut comes up.  Each graph re-packs the conv weights it uses (the packed-weight
-    cache misses during capture), so it depends on nothing but the parameter / optimiser / EWMA buffers, the static real
-    batch and the scalar block.  Results are bit-identical to the eager steps
+    pool, all captured at the first replayed iteration (``precapture``).  Each graph re-packs the conv weights it uses
+    (every cached pack is stale when the capture starts), so it depends on nothing but the parameter / optimiser / EWMA
+    buffers, the static real batch and the scalar block.  Results are bit-identical to the eager steps
     (tests/test_gpu_learner.py::test_graphed_step_equals_eager).
 
     Single process only (the bucketed all-reduce of ``parallel.GradReducer`` is host-driven), stabilised phases only (alpha
@@ -110,27 +185,11 @@ class GraphedStep(object):
     optimiser, batch size or phase drops the graphs."""
 
     def __init__(self, learner, warmup=2, precapture=True):
-        self.L = learner
-        self.warmup = int(warmup)
         self.precapture = bool(precapture)      # capture every mixing variant at the first replayed iteration
-        self._reset()
-
-    def _reset(self):
-        self.graphs, self.pool, self.sig, self.calls = {}, None, None, 0
-        self.block = self.real = self.loss_d = self.loss_g = None
-
-    # -- eligibility -------------------------------------------------------------------------------------------------
-    def _signature(self, real):
-        L = self.L
-        g = L.gen_model
-        return (id(L.opt_disc), id(L.opt_gen), id(L.arena_d), id(L.arena_g), L.batch_size, g.curr_res,
-                bool(g.fade_in_phase), tuple(real.shape), real.device, ops.get_compute_dtype(), bool(g.training),
-                bool(L.disc_model.training))
+        super().__init__(learner, warmup)
 
     def eligible(self):
-        from . import parallel
-        L = self.L
-        return parallel.world_size() == 1 and not L.gen_model.fade_in_phase and torch.cuda.is_available()
+        return super().eligible() and not self.L.gen_model.fade_in_phase
 
     def _mix_kwargs(self):
         """The generator's own host draw of the mixing cut, made here so that it can select the graph."""
@@ -156,56 +215,14 @@ class GraphedStep(object):
         self.L.set_requires_grad_disc(False)
         return self.L.g_step(d_update_pending=True, gen_kwargs=kw)
 
-    def _capture(self, kind, cut, kw):
-        L = self.L
-        dev = self.real.device
-        if self.block is None:
-            self.block = torch.zeros(16, dtype=torch.int32, device=dev)
-            self.loss_d, self.loss_g = torch.zeros((), device=dev), torch.zeros((), device=dev)
-            self.pool = torch.cuda.graph_pool_handle()
-        base = self.block.data_ptr()
-        # the graph packs the weights it uses itself: every cached pack is stale, and the steady state's batched re-pack
-        # (one launch per parameter range, descriptor table already on the device) is what gets captured
-        ops.mark_packs_stale()
-        known = set(ops._PACK_CACHE.keys())
-        start = rng._STATE['offset']
-        rng.begin_device_offsets(self.block)
-        L.opt_disc.dev_scalars, L.opt_gen.dev_scalars = base + 16, base + 28
-        graph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(graph, pool=self.pool):
-                if kind == 'd':
-                    self.loss_d.copy_(self._d_half(self.real, kw))
-                else:
-                    self.loss_g.copy_(self._g_half(kw))
-        finally:
-            L.opt_disc.dev_scalars = L.opt_gen.dev_scalars = None
-            draws = rng.end_device_offsets()
-            rng._STATE['offset'] = start              # a capture records, it does not run: nothing was drawn yet
-            # packed weights first made during the capture live in the graph's pool: not for eager use
-            for k in [k for k in ops._PACK_CACHE if k not in known]:
-                del ops._PACK_CACHE[k]
-            ops.mark_packs_stale()
-        self.graphs[(kind, cut)] = (graph, draws)
-
-    def _replay(self, kind, cut):
-        L = self.L
-        graph, draws = self.graphs[(kind, cut)]
-        scal = [0.0] * 6
-        if kind == 'g':         # the deferred critic update and the generator update both sit in this half
-            scal = list(L.opt_disc.host_scalars()) + list(L.opt_gen.host_scalars())
-        ops.set_step_scalars(self.block, rng._STATE['offset'], scal)
-        graph.replay()
-        rng._STATE['offset'] += draws
-        ops.mark_packs_stale()          # the replay rewrote parameters (and the cached packs' buffers) on its own
+    def _capture_half(self, kind, cut, kw):
+        self._capture((kind, cut), (lambda: self._d_half(self.real, kw)) if kind == 'd' else (lambda: self._g_half(kw)))
 
     def __call__(self, real):
         """-> (loss_d, loss_g) device scalars (valid until the next call)."""
         L = self.L
-        sig = self._signature(real)
-        if sig != self.sig:
-            self._reset()
-            self.sig = sig
+        g = L.gen_model
+        self._check(self._common_signature(real) + (g.curr_res, bool(g.fade_in_phase)))
         self.calls += 1
         if not self.eligible() or self.calls <= self.warmup:
             cut_d, kw_d = self._mix_kwargs()
@@ -217,13 +234,15 @@ class GraphedStep(object):
             self.real.copy_(real)
             if self.precapture:
                 for cut in self._all_cuts():
-                    kw = {'_mix': (cut, None)} if hasattr(L.gen_model, 'draw_mixing_cutoff') else None
+                    kw = {'_mix': (cut, None)} if hasattr(g, 'draw_mixing_cutoff') else None
                     for kind in ('d', 'g'):
-                        self._capture(kind, cut, kw)
+                        self._capture_half(kind, cut, kw)
         self.real.copy_(real)
+        out = []
         for kind in ('d', 'g'):
             cut, kw = self._mix_kwargs()
             if (kind, cut) not in self.graphs:
-                self._capture(kind, cut, kw)
-            self._replay(kind, cut)
-        return self.loss_d, self.loss_g
+                self._capture_half(kind, cut, kw)
+            # the deferred critic update and the generator update both sit in the 'g' half
+            out.append(self._replay((kind, cut), ('d', 'g') if kind == 'g' else ()))
+        return tuple(out)

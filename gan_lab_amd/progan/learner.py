@@ -209,15 +209,6 @@ class ProGANLearner(GANLearner):
             self._step_graph = GraphedStep(self)
         return self._step_graph
 
-    @property
-    def use_step_graph(self):
-        """config.use_step_graph / GANLAB_STEP_GRAPH: 1 = replay eligible iterations as HIP graphs, 0 = never, unset =
-        where the step is launch-bound (resolutions up to 256)."""
-        v = os.environ.get('GANLAB_STEP_GRAPH', getattr(self.config, 'use_step_graph', None))
-        if v in (None, '', 'auto'):
-            return self.gen_model.curr_res <= 256
-        return str(v).lower() not in ('0', 'false', 'no')
-
     def fade_in_real(self, xb):
         """Real images follow the generator's fade-in: up(down(x))*(1-alpha) + x*alpha
         (progan/learner.py:771-779, the non-bit-exact branch), on the device."""

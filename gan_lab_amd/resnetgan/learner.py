@@ -178,6 +178,18 @@ class GANLearner(object):
         for p in self.disc_model.parameters():
             p.requires_grad_(flag)
 
+    @property
+    def use_step_graph(self):
+        """config.use_step_graph / GANLAB_STEP_GRAPH: 1 = replay eligible iterations as HIP graphs (graphs.GraphedStep: the
+        progressive learners), 0 = never, unset = where the step is launch-bound (resolutions up to 256).  The ResNet GAN's
+        iteration is bound by its kernels (measured: 158.9 ms eager, 159.0 ms replayed) and always steps eagerly."""
+        import os
+        v = os.environ.get('GANLAB_STEP_GRAPH', getattr(self.config, 'use_step_graph', None))
+        if v in (None, '', 'auto'):
+            res = getattr(self.gen_model, 'curr_res', None) or self.config.res_samples
+            return res <= 256
+        return str(v).lower() not in ('0', 'false', 'no')
+
     # -- the hot path: one generator iteration, one critic iteration ------------------------------------
     def g_step(self, zb=None):
         """resnetgan/learner.py:545-597 (critic parameters frozen by the caller)."""
