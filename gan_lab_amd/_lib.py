@@ -76,6 +76,8 @@ SIGNATURES = {
                                               _c_p, _c_sz, _c_p]),
     'ganlab_act_bwd_blur_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int,
                                               _c_f, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_fwd_blur_supported': (_c_int, [_GP, _c_p, _c_p]),
+    'ganlab_conv_fwd_blur_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_f, _c_p]),
     'ganlab_conv_fwd_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
     'ganlab_conv_fwd_mask_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),

@@ -1,0 +1,324 @@
+// conv 3x3 -> +bias -> LeakyReLU -> binomial blur in ONE kernel, for the thinnest layer of the critic
+// (conv -> LeakyReLU -> blur -> pooled conv, gan_lab/progan/architectures.py:254-284 at the top resolution: 16 -> 16
+// channels at 1024^2): the blur pass of the composed form (csrc/pointwise.hip blur3x3_vec_kernel: 1R + 1W of the
+// widest tensor of the network) is folded into the rolling-window convolution, which also emits the sign bits of the
+// activation (the only thing the backward needs of it: ops._ConvBiasAct).
+//
+// Same skeleton as conv.hip's conv_fwd_roll_kernel - a workgroup owns a 64-pixel column strip and walks DOWN it four
+// rows per step over a six-slot LDS ring of input rows, weights in registers - with the wave-to-output map turned by
+// 90 degrees: wave w owns the 16-pixel column BLOCK w for all four rows of the step (not one row across four blocks):
+//   * the vertical half of the blur stays in registers: a lane holds the same four pixels of its channel in rows
+//     4s .. 4s+3, plus the two (horizontally blurred) rows carried over from the previous step; the output lags the
+//     convolution by one row, and a row strip computes ONE extra step for the rows its neighbours own (v rows Y0-1 and
+//     Y0+4n: +1/32 of the MFMA work at the benchmark size);
+//   * the horizontal half needs one pixel from the left / right neighbour: the next lane group (ds_bpermute), the next
+//     wave (2 KB exchange through LDS at the step's first barrier), or - at the strip's own edges - the conv output of
+//     the two columns just outside the strip.  Those 8 pixels per step are a fifth MFMA block whose 36 K-steps are split
+//     among the four waves by channel group (9 MFMAs each, +6 %); the partial sums meet in the same LDS exchange;
+//   * an input row feeds up to three (output row, ky) pairs of the SAME wave: 72 LDS operand reads per step and wave
+//     instead of 144.
+// Zero padding of the blur: activation rows / columns outside the image are zero (not "conv of the padding").
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RB_TW = 64, RB_SLOTS = 6, RB_RP = 80, RB_SLOT = 16 * RB_RP, RB_Q = 18;
+constexpr int RB_ITEMS = 4 * 16 * RB_Q;             // float4 items of one 4-row prefetch: 1152
+constexpr int RB_PT = (RB_ITEMS + 255) / 256;       // 5
+constexpr int RB_OOB = (int)0x80000000;
+
+struct RBArgs {
+  const float* x;
+  const float* wp;          // PACK_FWD: [9 taps][Cin_p][Cout_p]
+  const float* bias;
+  float* y;
+  unsigned short* bits;     // sign bits of the activation, 16 pixels per halfword (bit e of the NCHW-linear index); or null
+  int N, Cin, Cout, H, W;
+  int Cin_p, Cout_p;
+  int cols, strips, spu;    // 64-pixel columns per row, row strips per column, steps (4 rows) per strip
+  float bias_scale, slope;
+};
+
+__device__ __forceinline__ float rb_act(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
+  __shared__ __attribute__((aligned(16))) float ring[RB_SLOTS * RB_SLOT];       // 30720 B
+  __shared__ __attribute__((aligned(16))) float xn[2 * 4 * 16 * 4];             // [side][wave][co][row]: own edge pixels
+  __shared__ __attribute__((aligned(16))) float xe[2 * 4 * 16 * 4];             // [side][wave][co][row]: outside columns, partial
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int co = lane & 15, kk = lane >> 4;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = bid % p.cols;
+  bid /= p.cols;
+  const int syi = bid % p.strips;
+  const int n0 = bid / p.strips;
+  const int ns = min(p.spu, p.H / 4 - syi * p.spu);       // steps that OWN output rows; the kernel runs ns + 1
+  const int ox0 = txi * RB_TW, Y0 = syi * p.spu * 4;
+  const int plane = p.H * p.W;
+  const float* xb = p.x + (long long)n0 * p.Cin * plane;
+
+  // staging items of a 4-row group: (k = row in group, ci, q = float4 column)
+  int gbase[RB_PT], lo_k[RB_PT], lo_off[RB_PT];
+#pragma unroll
+  for (int i = 0; i < RB_PT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % RB_Q, t = e / RB_Q;
+    const int ci = t & 15, k = t >> 4;
+    const int vx = ox0 - 4 + 4 * q;
+    gbase[i] = (e < RB_ITEMS && ci < p.Cin && (unsigned)vx < (unsigned)p.W) ? (ci * plane + vx) * 4 : RB_OOB;
+    lo_k[i] = k;
+    lo_off[i] = ci * RB_RP + 4 * q;
+  }
+  // weights -> registers (k-step st = tap * 4 + c4)
+  float wreg[36];
+#pragma unroll
+  for (int st = 0; st < 36; ++st)
+    wreg[st] = p.wp[(long long)((st >> 2) * p.Cin_p + (st & 3) * 4 + kk) * p.Cout_p + co];
+  // the outside columns' K-steps of this wave: all nine taps of channel group w
+  float wedge[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) wedge[tap] = p.wp[(long long)(tap * p.Cin_p + w * 4 + kk) * p.Cout_p + co];
+  const bool co_ok = co < p.Cout;
+  const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] * p.bias_scale : 0.f;
+
+  const long long oplane = (long long)p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (long long)n0 * p.Cout * oplane, 0, (unsigned)(p.Cout * oplane * 4), 0x00020000);
+  const int vo_lane = co_ok ? (int)(((long long)co * oplane + ox0 + w * 16 + kk * 4) * 4) : RB_OOB;
+
+  float4 xr[RB_PT];
+  // rel row r of the strip = input row Y0 - 2 + r; rows outside the image and k >= nrows read as zeros
+  auto load_rows = [&](int rel0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < RB_PT; ++i) {
+      const int vy = Y0 - 2 + rel0 + lo_k[i];
+      const bool ok = gbase[i] != RB_OOB && lo_k[i] < nrows && (unsigned)vy < (unsigned)p.H;
+      const int off = ok ? gbase[i] + (int)((unsigned)vy * (unsigned)(p.W * 4)) : RB_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+  };
+  auto store_rows = [&](int rel0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < RB_PT; ++i)
+      if (tid + i * 256 < RB_ITEMS && lo_k[i] < nrows)
+        *reinterpret_cast<float4*>(ring + ((rel0 + lo_k[i]) % RB_SLOTS) * RB_SLOT + lo_off[i]) = xr[i];
+  };
+
+  f32x4 acc[4], acce;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acce = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;       // horizontally blurred rows carried from the previous step
+
+  // A-operand addressing.  Main blocks: pixel = lane & 15 of column block w, channel 4*c4 + kk.
+  const int a_lane = kk * RB_RP + w * 16 + co + 3;     // + LP(4) - pad(1); `co` doubles as the pixel index here
+  // Outside columns (fifth block): pixel e = lane & 7: row e & 3 of the step, column -1 (e < 4) or 64; this wave
+  // contracts channel group c4 = w of it
+  const int e_row = lane & 3, e_side = (lane >> 2) & 1;
+  const int e_lane = (w * 4 + kk) * RB_RP + (e_side ? 64 : -1) + 3;
+
+  load_rows(0, 4);
+  store_rows(0, 4);
+  load_rows(4, 2);
+  store_rows(4, 2);
+  __syncthreads();
+
+  for (int s = 0; s <= ns; ++s) {
+    // ---- MFMA phase: v rows Y0 - 1 + 4s + r4 (r4 < 4) of column block w from rel input rows 4s .. 4s+5 ----
+    int sb[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sb[j] = ((4 * s + j) % RB_SLOTS) * RB_SLOT;
+    int eb[3];
+    {
+      const int s6 = (4 * s) % RB_SLOTS;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        int e = s6 + e_row + ky;
+        e = e >= RB_SLOTS ? e - RB_SLOTS : e;
+        e = e >= RB_SLOTS ? e - RB_SLOTS : e;
+        eb[ky] = e * RB_SLOT + e_lane;
+      }
+    }
+    // fetch order: input rows (0, 5) interleaved (one accumulator each), then 1, 4, 2, 3; 12 (kx, c4) pairs per row
+    constexpr int JORD[6] = {0, 5, 1, 4, 2, 3};
+    constexpr int PD = 3;
+    float rb[PD + 1], ae = 0.f;
+    auto fetch = [&](int f, int slot) {
+      // f < 24: rows 0 / 5 alternate; else rows in JORD order, 12 fetches each
+      const int j = f < 24 ? JORD[f & 1] : JORD[2 + (f - 24) / 12];
+      const int i12 = f < 24 ? (f >> 1) : (f - 24) % 12;
+      const int kx = i12 >> 2, c4 = i12 & 3;
+      rb[slot] = ring[sb[j] + c4 * 4 * RB_RP + kx + a_lane];
+    };
+#pragma unroll
+    for (int f = 0; f < PD; ++f) fetch(f, f % (PD + 1));
+#pragma unroll
+    for (int f = 0; f < 72; ++f) {
+      if (f + PD < 72) fetch(f + PD, (f + PD) % (PD + 1));
+      const int slot = f % (PD + 1);
+      const int j = f < 24 ? JORD[f & 1] : JORD[2 + (f - 24) / 12];
+      const int i12 = f < 24 ? (f >> 1) : (f - 24) % 12;
+      const int kx = i12 >> 2, c4 = i12 & 3;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int ky = j - r4;
+        if (ky >= 0 && ky < 3)
+          acc[r4] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot], wreg[(ky * 3 + kx) * 4 + c4], acc[r4], 0, 0, 0);
+      }
+      if ((f & 7) == 3) ae = ring[eb[(f >> 3) / 3] + (f >> 3) % 3];     // operand of the outside columns' K-step f / 8
+      if ((f & 7) == 7)          // this wave's share of the fifth block: tap f / 8 of channel group w
+        acce = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, wedge[f >> 3], acce, 0, 0, 0);
+      if (f == 8) load_rows(4 * s + 6, s < ns ? 4 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- activation; publish what the neighbours need ----
+    f32x4 v[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int row = Y0 - 1 + 4 * s + r4;
+      const bool in = (unsigned)row < (unsigned)p.H;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r4][r] = in ? rb_act(acc[r4][r] + bv, p.slope) : 0.f;
+      acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (kk == 0) *reinterpret_cast<float4*>(xn + ((0 * 4 + w) * 16 + co) * 4) = float4{v[0][0], v[1][0], v[2][0], v[3][0]};
+    if (kk == 3) *reinterpret_cast<float4*>(xn + ((1 * 4 + w) * 16 + co) * 4) = float4{v[0][3], v[1][3], v[2][3], v[3][3]};
+    if (kk < 2)   // lanes kk = 0: column -1, rows r; kk = 1: column 64
+      *reinterpret_cast<float4*>(xe + ((kk * 4 + w) * 16 + co) * 4) = float4{acce[0], acce[1], acce[2], acce[3]};
+    acce = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the exchange buffers are complete
+    store_rows(4 * s + 6, s < ns ? 4 : 0);       // into the slots of rows 4s .. 4s+3
+    // ---- horizontal blur (unnormalised [1 2 1]) ----
+    float4 nl = float4{0.f, 0.f, 0.f, 0.f}, nr = nl;      // left neighbour of pixel 0 / right neighbour of pixel 15 (by row)
+    if (kk == 0) {
+      if (w > 0) {
+        nl = *reinterpret_cast<const float4*>(xn + ((1 * 4 + (w - 1)) * 16 + co) * 4);
+      } else if (txi > 0) {
+        float4 t = *reinterpret_cast<const float4*>(xe + ((0 * 4 + 0) * 16 + co) * 4);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float4 u = *reinterpret_cast<const float4*>(xe + ((0 * 4 + ww) * 16 + co) * 4);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        nl = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope),
+                    rb_act(t.w + bv, p.slope)};
+      }
+    }
+    if (kk == 3) {
+      if (w < 3) {
+        nr = *reinterpret_cast<const float4*>(xn + ((0 * 4 + (w + 1)) * 16 + co) * 4);
+      } else if (txi + 1 < p.cols) {
+        float4 t = *reinterpret_cast<const float4*>(xe + ((1 * 4 + 0) * 16 + co) * 4);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float4 u = *reinterpret_cast<const float4*>(xe + ((1 * 4 + ww) * 16 + co) * 4);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        nr = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope),
+                    rb_act(t.w + bv, p.slope)};
+      }
+    }
+    f32x4 hb[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int row = Y0 - 1 + 4 * s + r4;
+      const bool in = (unsigned)row < (unsigned)p.H;
+      float l = __shfl_up(v[r4][3], 16, 64);      // lane - 16: pixel 4kk - 1
+      float r = __shfl_down(v[r4][0], 16, 64);    // lane + 16: pixel 4kk + 4
+      const float nlv = r4 == 0 ? nl.x : r4 == 1 ? nl.y : r4 == 2 ? nl.z : nl.w;
+      const float nrv = r4 == 0 ? nr.x : r4 == 1 ? nr.y : r4 == 2 ? nr.z : nr.w;
+      if (kk == 0) l = in ? nlv : 0.f;
+      if (kk == 3) r = in ? nrv : 0.f;
+      hb[r4][0] = l + 2.f * v[r4][0] + v[r4][1];
+      hb[r4][1] = v[r4][0] + 2.f * v[r4][1] + v[r4][2];
+      hb[r4][2] = v[r4][1] + 2.f * v[r4][2] + v[r4][3];
+      hb[r4][3] = v[r4][2] + 2.f * v[r4][3] + r;
+    }
+    // ---- vertical blur, one row behind: output rows Y0 - 2 + 4s + i from (c0, c1, hb[0..3]) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = Y0 - 2 + 4 * s + i;
+      const f32x4 a = i == 0 ? c0 : i == 1 ? c1 : hb[i - 2];
+      const f32x4 b = i == 0 ? c1 : hb[i - 1];
+      const f32x4 c = hb[i];
+      if (row >= Y0 && row < Y0 + 4 * ns) {
+        u32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __float_as_uint((a[r] + 2.f * b[r] + c[r]) * 0.0625f);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, 0);
+      }
+    }
+    c0 = hb[2];
+    c1 = hb[3];
+    // ---- sign bits of the activation rows this strip owns ----
+    if (p.bits != nullptr) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = Y0 - 1 + 4 * s + r4;
+        unsigned nib = (v[r4][0] > 0.f ? 1u : 0u) | (v[r4][1] > 0.f ? 2u : 0u) | (v[r4][2] > 0.f ? 4u : 0u) |
+                       (v[r4][3] > 0.f ? 8u : 0u);
+        nib <<= 4 * kk;
+        nib |= __shfl_xor(nib, 16, 64);
+        nib |= __shfl_xor(nib, 32, 64);
+        if (kk == 0 && co_ok && row >= Y0 && row < Y0 + 4 * ns)
+          p.bits[(((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0 + w * 16) >> 4] = (unsigned short)nib;
+      }
+    }
+    __syncthreads();   // the ring holds rows 4s+4 .. 4s+9; the exchange buffers may be rewritten
+  }
+}
+
+}  // namespace
+
+// ---- host side (called from conv.hip's entry points) ----
+bool gl_roll_blur_supported(int N, int Cin, int Cout, int H, int W, const void* x, const void* y) {
+  const char* e = getenv("GANLAB_ROLL_BLUR");
+  if (e != nullptr && e[0] == '0') return false;                 // A/B knob: conv kernel + blur pass
+  return N > 0 && Cin >= 1 && Cin <= 16 && Cout >= 1 && Cout <= 16 && W % RB_TW == 0 && H % 4 == 0 &&
+         (long long)Cin * H * W * 4 < 0x7fffffffLL && (long long)Cout * H * W * 4 < 0x7fffffffLL &&
+         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
+int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, float* y, void* bits, int N, int Cin, int Cout,
+                        int H, int W, int Cin_p, int Cout_p, float bias_scale, float slope, hipStream_t st) {
+  RBArgs a{};
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.bits = reinterpret_cast<unsigned short*>(bits);
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Cin_p = Cin_p; a.Cout_p = Cout_p;
+  a.bias_scale = bias_scale; a.slope = slope;
+  a.cols = W / RB_TW;
+  const int steps = H / 4;
+  const long long cols = (long long)a.cols * N;
+  int k = 1;                   // row strips per column: >= ~4096 workgroups, >= 16 steps each (every strip pays one extra)
+  while (k < steps && cols * k < 4096 && (steps + k) / (k + 1) >= 16) ++k;
+  a.spu = (steps + k - 1) / k;
+  a.strips = (steps + a.spu - 1) / a.spu;
+  const long long grid = cols * a.strips;
+  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  GL_LAUNCH(conv_fwd_roll_blur_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return GL_CHECK_LAUNCH();
+}
+
+extern "C" {
+
+int ganlab_conv_fwd_blur_supported(const ganlab_conv_geom* g, const void* x, const void* y) {
+  if (!g || g->ks != 3 || g->pad != 1 || g->up || g->pool) return 0;
+  return gl_roll_blur_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, x, y) ? 1 : 0;
+}
+
+int ganlab_conv_fwd_blur_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
+                                  const ganlab_conv_geom* g, float bias_scale, float slope, void* stream) {
+  if (!x || !wp || !y || !g) return GANLAB_EINVAL;
+  if (!ganlab_conv_fwd_blur_supported(g, x, y)) return GANLAB_EUNSUPPORTED;
+  const int cin_p = (g->Cin + 15) / 16 * 16, cout_p = (g->Cout + 63) / 64 * 64;
+  return gl_roll_blur_launch(x, wp, bias, y, ybits, g->N, g->Cin, g->Cout, g->Hin, g->Win, cin_p, cout_p, bias_scale,
+                             slope, gl_stream(stream));
+}
+
+}  // extern "C"

@@ -639,6 +639,25 @@ def k_conv_fwd_bits(x, w, bias, g, scale, bias_scale, act, slope):
     return y, bits
 
 
+def k_conv_fwd_blur_bits(x, w, bias, g, scale, bias_scale, slope):
+    """blur(lrelu(conv3x3(x, w) * scale + bias)) and the sign bits of the un-blurred activation in ONE rolling-window kernel
+    (csrc/conv_roll_blur.hip) - or None where the geometry is not the thin one it takes."""
+    if g.ks != 3 or g.up or g.pool or g.bf is not None or get_compute_dtype() != 'f32' or not mask_bits_ok_plane():
+        return None
+    x, w = _c(x, 'conv input'), _c(w, 'conv weight')
+    L = _lib.lib()
+    y = _new(g.out_shape, x)
+    if not L.ganlab_conv_fwd_blur_supported(g.ref(), _p(x), _p(y)):
+        return None
+    assert tuple(x.shape) == g.in_shape
+    _note('fwd', g)
+    bits = torch.empty((y.numel() // 32,), dtype=torch.int32, device=x.device)
+    check(L.ganlab_conv_fwd_blur_bits_f32(_p(x), _p(_packed(w, PACK_FWD, scale)), _p(_c(bias, 'bias')) if bias is not None
+                                          else None, _p(y), bits.data_ptr(), g.ref(), bias_scale, slope, _st()),
+          'conv_fwd_blur_bits')
+    return y, bits
+
+
 def k_conv_wgrad(gy, x, g, scale):
     gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
@@ -1400,10 +1419,16 @@ class _ConvBiasAct(Function):
             ctx.bias_shape = bias.shape if bias is not None else None
             ctx.save_for_backward(x, w, bits)
             return y
-        y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         ctx.defer, ctx.in_slope = bool(defer), in_slope
         assert not (defer and blur)
         ctx.bias_shape = bias.shape if bias is not None else None
+        if blur and act == ACT_LRELU:
+            # thin layer: conv + bias + LeakyReLU + blur + the sign bits in one rolling-window kernel
+            fused = k_conv_fwd_blur_bits(x, w, bias, g, s, bias_scale, slope)
+            if fused is not None:
+                ctx.save_for_backward(x, w, fused[1])
+                return fused[0]
+        y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         # blur=True: the D block's  conv -> bias -> LeakyReLU -> blur  (progan/architectures.py:280-293);
         # forward is conv kernel + blur kernel, backward is ONE pass (blur^T, LeakyReLU', bias gradient)
         if blur and act != ACT_NONE and mask_bits_ok(y):

@@ -400,6 +400,12 @@ int ganlab_act_bwd_blur_bits_f32(const float* g, const unsigned* ybits, const fl
  * the sign bits of y, the gradient kernels of ganlab_conv_{dgrad_act,fwd_mask,wgrad_act}_f32 read the bits instead of y */
 int ganlab_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
                              const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+/* The critic's  conv3x3 -> +bias -> LeakyReLU -> binomial blur  (progan/architectures.py:254-284) of a thin layer (<= 16 -> 16
+ * channels, W % 64 == 0, H % 4 == 0) in ONE rolling-window kernel (csrc/conv_roll_blur.hip): y = blur(lrelu(conv + b)) and
+ * the sign bits of the un-blurred activation (ybits may be NULL).  wp: GANLAB_PACK_FWD-packed weights. */
+int ganlab_conv_fwd_blur_supported(const ganlab_conv_geom* g, const void* x, const void* y);
+int ganlab_conv_fwd_blur_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
+                                  const ganlab_conv_geom* g, float bias_scale, float slope, void* stream);
 int ganlab_conv_dgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* wp, float* gx,
                                    const ganlab_conv_geom* g, float slope, void* stream);
 int ganlab_conv_fwd_mask_bits_f32(const float* x, const float* wp, const unsigned* ybits, float* out,

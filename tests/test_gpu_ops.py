@@ -1084,6 +1084,7 @@ def test_leaky_relu_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     x0 = rnd(gen, n, c, h, w)
     wt0, b0 = rnd(gen, c, c, 3, 3), rnd(gen, c)
     cot = rnd(gen, n, c, h, w).cuda()
+    monkeypatch.setenv('GANLAB_ROLL_BLUR', '0')        # the composed form (the fused kernel has its own test below)
 
     def run(bits_on):
         monkeypatch.setattr(ops, '_MASK_BITS', [bits_on])
@@ -1099,6 +1100,51 @@ def test_leaky_relu_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     assert ops.mask_bits_ok(x0.cuda()) or not ops._MASK_BITS[0]
     for name, u, v in zip(['y', 'gx', 'gw', 'gb', 'gw (second order)'], a, b_):
         assert torch.equal(u, v), name
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 64), (1, 16, 16, 8, 64), (3, 5, 7, 24, 128), (2, 16, 16, 256, 192),
+                                   (1, 3, 16, 132, 64), (2, 16, 9, 4, 64)],
+                         ids=['16ch 64x64', 'two steps', 'odd channels 24x128', 'row strips 256x192', 'ragged strips 132x64',
+                              'single step'])
+def test_conv_lrelu_blur_fused_kernel_equals_composed(ops, shape, monkeypatch):
+    """csrc/conv_roll_blur.hip: conv3x3 -> +bias -> LeakyReLU -> blur of a thin layer in ONE rolling-window kernel (the blur
+    pass folded into the convolution, sign bits written beside it) against the composed form - conv kernel, then the blur
+    pass that emits the bits (progan/architectures.py:254-284).  The two sum the 144 products of an output in different
+    orders: outputs and gradients agree to fp32 rounding, the sign bits wherever the pre-activation is not rounding noise,
+    and the float64 CPU evaluation is as close to one as to the other."""
+    n, cin, cout, h, w = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()))
+    x0, wt0, b0 = rnd(gen, n, cin, h, w), rnd(gen, cout, cin, 3, 3), rnd(gen, cout)
+    cot = rnd(gen, n, cout, h, w).cuda()
+    g = ops.Geom(n, cin, h, w, cout, 3, 1, 0)
+
+    def run(fused):
+        monkeypatch.setenv('GANLAB_ROLL_BLUR', '1' if fused else '0')
+        x = x0.cuda().requires_grad_(True)
+        wt, b = wt0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        if fused:
+            direct = ops.k_conv_fwd_blur_bits(x.detach(), wt.detach(), b.detach(), g, 0.1, 1.0, 0.2)
+            assert direct is not None, 'the fused kernel refused a geometry it documents'
+        y = ops.conv2d(x, wt, b, scale=0.1, padding=1, act='lrelu', blur=True)
+        gx, gw, gb = torch.autograd.grad((y * cot).sum(), (x, wt, b))
+        return [t_.detach() for t_ in (y, gx, gw, gb)] + ([direct[1]] if fused else [])
+    a, b_ = run(True), run(False)
+    # float64 reference of the forward
+    pre = F.conv2d(x0.double(), wt0.double() * 0.1, b0.double(), padding=1)
+    act = F.leaky_relu(pre, 0.2)
+    k = torch.tensor([1., 2., 1.], dtype=torch.float64)
+    k2 = (k[:, None] * k[None, :] / 16).expand(cout, 1, 3, 3)
+    ref = F.conv2d(act, k2, padding=1, groups=cout)
+    e_f, e_c = (a[0].cpu().double() - ref).abs().max().item(), (b_[0].cpu().double() - ref).abs().max().item()
+    assert e_f <= max(2 * e_c, 1e-6 * ref.abs().max().item()), (e_f, e_c)
+    for name, u, v in zip(['y', 'gx', 'gw', 'gb'], a, b_):
+        assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item(), name
+    # the sign bits: bit e of the NCHW-linear index, wrong only where the pre-activation is rounding noise
+    bits = a[4].cpu().numpy().view(np.uint32)
+    got = ((bits[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1).astype(bool)
+    want = (pre > 0).reshape(-1).numpy()
+    bad = got != want
+    assert (pre.reshape(-1).numpy()[bad].__abs__() < 1e-5).all() and bad.mean() < 1e-4, int(bad.sum())
 
 
 @pytest.mark.parametrize('shape', [(2, 3, 64, 64, 16), (3, 3, 64, 96, 24)], ids=['3->16 64x64', '3->24 64x96'])
