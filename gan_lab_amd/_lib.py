@@ -78,6 +78,11 @@ SIGNATURES = {
                                               _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_fwd_blur_supported': (_c_int, [_GP, _c_p, _c_p]),
     'ganlab_conv_fwd_blur_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_f, _c_p]),
+    'ganlab_conv_s2_blur_supported': (_c_int, [_GP]),
+    'ganlab_conv_s2_blur_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_s2_fwd_blur_tail_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int,
+                                                  _c_f, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_s2_dgrad_blur_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_fwd_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
     'ganlab_conv_fwd_mask_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),

@@ -658,6 +658,59 @@ def k_conv_fwd_blur_bits(x, w, bias, g, scale, bias_scale, slope):
     return y, bits
 
 
+def conv_s2_blur_ok(g):
+    """Does the thin transposed stride-2 kernel with the blur folded in (csrc/conv_s2_roll_blur.hip) take geometry ``g`` - an
+    up layer for the generator's forward tail, a pooled layer for the critic's backward?"""
+    import os
+    if get_compute_dtype() != 'f32' or g.bf is not None or not g.s2 or os.environ.get('GANLAB_S2_ROLL_BLUR') == '0':
+        return False
+    key = ('s2blur', g.N, g.Cin, g.Hin, g.Win, g.Cout, g.up, g.pool)
+    hit = _AFF_OK.get(key)
+    if hit is None:
+        hit = bool(_lib.lib().ganlab_conv_s2_blur_supported(g.ref()))
+        _AFF_OK[key] = hit
+    return hit
+
+
+def k_conv_s2_fwd_blur_tail(a, s_, t_, w, bias, noise, noise_w, g, scale, bias_scale, act, slope, eps):
+    """(y, mean, rstd): y = act(blur(conv(up2(a * s + t), w) * scale) + noise_w * noise + bias * bias_scale) and the
+    InstanceNorm statistics of y, one kernel + the statistics' finish (``s_`` / ``t_`` None: plain input)."""
+    a, w = _c(a, 'conv input'), _c(w, 'conv weight')
+    assert g.up and tuple(a.shape) == g.in_shape
+    _note('fwd', g)
+    L = _lib.lib()
+    y = _new(g.out_shape, a)
+    mean, rstd = _new((g.N, g.Cout), a), _new((g.N, g.Cout), a)
+    ws = torch.empty((L.ganlab_conv_s2_blur_workspace(g.ref()) + 7) // 8, dtype=torch.float64, device=a.device)
+    wp = _packed(w, PACK_FWD, scale, s2_up=1)
+    noise = _c(noise) if noise is not None else None
+    if noise is not None:
+        assert noise.numel() == g.N * g.Ho * g.Wo, (tuple(noise.shape), g.out_shape)
+    check(L.ganlab_conv_s2_fwd_blur_tail_f32(_p(a), _p(wp), _p(s_), _p(t_), _p(bias), _p(noise), _p(noise_w), _p(y), _p(mean),
+                                             _p(rstd), g.ref(), bias_scale, act, slope, eps, ctypes.c_void_p(ws.data_ptr()),
+                                             ws.numel() * 8, _st()), 'conv_s2_fwd_blur_tail')
+    return y, mean, rstd
+
+
+def k_conv_s2_dgrad_blur_act(gy, w, bits, g, scale, slope, bias_scale, want_gb):
+    """(gz, gb) = (lrelu'(bits) * blur(dgrad(gy, w) * scale), bias_scale * sum gz): the pooled conv g's input gradient fused
+    with the backward of the LeakyReLU -> blur in front of it."""
+    gy, w = _c(gy, 'conv grad_out'), _c(w, 'conv weight')
+    assert g.pool and tuple(gy.shape) == g.out_shape and bits.numel() * 32 == g.N * g.Cin * g.Hin * g.Win
+    _note('dgrad', g)
+    L = _lib.lib()
+    gz = _new(g.in_shape, gy)
+    gb = _new((g.Cin,), gy) if want_gb else None
+    ws = torch.empty((L.ganlab_conv_s2_blur_workspace(g.ref()) + 7) // 8, dtype=torch.float64, device=gy.device) \
+        if want_gb else None
+    wp = _packed(w, PACK_DGRAD, scale, s2_up=0)
+    check(L.ganlab_conv_s2_dgrad_blur_act_bits_f32(_p(gy), _p(wp), bits.data_ptr(), _p(gz), _p(gb), g.ref(), slope, bias_scale,
+                                                   ctypes.c_void_p(ws.data_ptr()) if ws is not None else None,
+                                                   ws.numel() * 8 if ws is not None else 0, _st()),
+          'conv_s2_dgrad_blur_act_bits')
+    return gz, gb
+
+
 def k_conv_wgrad(gy, x, g, scale):
     gy, x = _c(gy, 'conv grad_out'), _c(x, 'conv input')
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
@@ -1245,6 +1298,49 @@ class _ConvWgradAct(Function):
         return d_gy, None, d_x, None, None, None, None, None
 
 
+BLUR_HANDOFF = '_ganlab_blur_handoff'
+
+
+class BlurHandoff(object):
+    """Link between the critic's  conv -> LeakyReLU -> blur  layer (A) and the pooled conv (B) that is its only reader
+    (progan/architectures.py:254-284): B's input-gradient kernel can apply A's blur^T and LeakyReLU derivative and sum A's bias
+    gradient on the way (csrc/conv_s2_roll_blur.hip).  A fills in what that takes at forward time; B's backward sets ``done``
+    and ``gb``, A's backward - which always runs after it - then takes the incoming gradient as that of its pre-activation."""
+    __slots__ = ('bits', 'slope', 'bias_scale', 'want_gb', 'gb', 'done')
+
+    def __init__(self):
+        self.bits, self.slope, self.bias_scale, self.want_gb, self.gb, self.done = None, 0.2, 1.0, False, None, False
+
+
+class _ConvDgradBlurAct(Function):
+    """(gzA, gbA) = (lrelu'(bits) * blur(dgrad_B(gy, w)), bias_scale * sum gzA) in one kernel; linear in gy and in w.  Its
+    derivative is the composition the separate passes have: the adjoint of blur^T o mask (``_ActBwdBlur``), then the pooled
+    conv's forward / weight gradient."""
+
+    @staticmethod
+    def forward(ctx, gy, w, bits, g, s, slope, bias_scale, want_gb):
+        ctx.save_for_backward(gy, w, bits)
+        ctx.set_materialize_grads(False)
+        ctx.g, ctx.s, ctx.slope = g, s, slope
+        gz, gb = k_conv_s2_dgrad_blur_act(gy, w, bits, g, s, slope, bias_scale, want_gb)
+        if gb is None:
+            gb = gz.new_zeros(())
+            ctx.mark_non_differentiable(gb)
+        return gz, gb
+
+    @staticmethod
+    def backward(ctx, gg, ggb):
+        if ggb is not None:
+            raise NotImplementedError('second derivative through the fused bias gradient of the blurred layer')
+        gy, w, bits = ctx.saved_tensors
+        if gg is None:
+            return (None,) * 8
+        t = _ActBwdBlur.apply(gg, bits, None, ctx.slope, 1.0, False, False)[0]
+        d_gy = _ConvFwd.apply(t, w, ctx.g, ctx.s) if ctx.needs_input_grad[0] else None
+        d_w = _ConvWgrad.apply(gy, t, ctx.g, ctx.s) if ctx.needs_input_grad[1] else None
+        return d_gy, d_w, None, None, None, None, None, None
+
+
 class _ActBwd(Function):
     """gz = gy * lrelu'(y) from the saved OUTPUT y (sign(y) == sign(pre-activation))."""
 
@@ -1406,11 +1502,14 @@ class _ConvBiasAct(Function):
     epilogue).  Reference: Conv2dEx.forward (+ nn.LeakyReLU) custom_layers.py:202-211."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False, defer=False, in_slope=None):
+    def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False, defer=False, in_slope=None, handoff_out=None,
+                handoff_in=None):
         # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
         ctx.bias_ref = bias
+        # handoff_out: this is layer A of a BlurHandoff pair (filled in below when the sign bits exist); handoff_in: layer B
+        ctx.handoff_out, ctx.handoff_in = None, handoff_in
         if act != ACT_NONE and not blur and not defer and in_slope is None and conv_act_bwd_fusable(g) and \
                 (g.Ho * g.Wo) % 32 == 0 and mask_bits_ok_plane():
             # fromRGB: the gradient kernels take (gy, mask of y); the forward writes that mask as bits next to y
@@ -1427,6 +1526,7 @@ class _ConvBiasAct(Function):
             fused = k_conv_fwd_blur_bits(x, w, bias, g, s, bias_scale, slope)
             if fused is not None:
                 ctx.save_for_backward(x, w, fused[1])
+                ctx.handoff_out = _fill_handoff(handoff_out, fused[1], slope, bias_scale, bias)
                 return fused[0]
         y = k_conv_fwd(x, w, bias, g, s, bias_scale, act, slope)
         # blur=True: the D block's  conv -> bias -> LeakyReLU -> blur  (progan/architectures.py:280-293);
@@ -1436,6 +1536,7 @@ class _ConvBiasAct(Function):
             # tensor per pass at the top of the critic; the backward passes read 1/32 of its bytes)
             out, bits = k_blur_bits(y)
             ctx.save_for_backward(x, w, bits)
+            ctx.handoff_out = _fill_handoff(handoff_out, bits, slope, bias_scale, bias)
             return out
         ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer) else None)
         return k_blur(y) if blur else y
@@ -1460,11 +1561,18 @@ class _ConvBiasAct(Function):
                 if _sunk('gb'):
                     want_b = False
             return gx, (gw if ctx.needs_input_grad[1] else None), (gb.view(ctx.bias_shape) if want_b else None), \
-                None, None, None, None, None, None, None, None
-        _sink('gb', ctx.bias_ref if want_b else None)
-        if ctx.blur and act != ACT_NONE:
+                None, None, None, None, None, None, None, None, None, None
+        h = ctx.handoff_out
+        if h is not None and h.done:
+            # the pooled conv behind the blur already applied blur^T and this layer's LeakyReLU derivative in its input-
+            # gradient kernel (and summed the bias gradient): gy IS the pre-activation gradient
+            gz, gb = gy, (h.gb if want_b else None)
+            h.done, h.gb = False, None
+        elif ctx.blur and act != ACT_NONE:
+            _sink('gb', ctx.bias_ref if want_b else None)
             gz, gb = _BlurActBwd.apply(gy, y, ctx.slope, ctx.bias_scale, bool(want_b))
         else:
+            _sink('gb', ctx.bias_ref if want_b else None)
             if ctx.blur:
                 gy = _Blur.apply(gy)
             if act != ACT_NONE and want_b:
@@ -1477,8 +1585,14 @@ class _ConvBiasAct(Function):
             gb = None
         gx = None
         if _wants_input_grad(ctx, x):
-            gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.in_slope is None else \
-                _ConvDgradMask.apply(gz, w, x, ctx.g, ctx.s, ctx.in_slope)
+            hin = ctx.handoff_in
+            if hin is not None:      # layer B of the pair: input gradient + layer A's blur^T, LeakyReLU', bias gradient
+                gx, gba = _ConvDgradBlurAct.apply(gz, w, hin.bits, ctx.g, ctx.s, hin.slope, hin.bias_scale,
+                                                  bool(hin.want_gb and params))
+                hin.gb, hin.done = (gba if (hin.want_gb and params) else None), True
+            else:
+                gx = _ConvDgrad.apply(gz, w, ctx.g, ctx.s) if ctx.in_slope is None else \
+                    _ConvDgradMask.apply(gz, w, x, ctx.g, ctx.s, ctx.in_slope)
         gw = None
         if ctx.needs_input_grad[1] and params:
             _sink('gw', w)
@@ -1486,7 +1600,15 @@ class _ConvBiasAct(Function):
             if _sunk('gw'):
                 gw = None
         return gx, gw, (gb.view(ctx.bias_shape) if want_b and gb is not None else None), None, None, None, None, \
-            None, None, None, None
+            None, None, None, None, None, None
+
+
+def _fill_handoff(h, bits, slope, bias_scale, bias):
+    if h is not None:
+        h.bits, h.slope, h.bias_scale = bits, slope, bias_scale
+        h.want_gb = bias is not None and bias.requires_grad
+        h.gb, h.done = None, False
+    return h
 
 
 class _BiasAct(Function):
@@ -1998,6 +2120,78 @@ class _ConvModTail(Function):
         return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None
 
 
+class _UpConvBlurTail(Function):
+    """A generator layer that opens a resolution,  Upsample -> conv3x3 -> blur -> +noise -> +bias -> LeakyReLU  with the
+    InstanceNorm statistics of the result (stylegan/architectures.py:292-334, 497-526), in ONE pass over the activations
+    (csrc/conv_s2_roll_blur.hip) - from a plain input or a deferred one (``s_in`` / ``t_in``: affine on load) to a deferred
+    output (see ``Deferred``).  Backward: the layer tail's (InstanceNorm backward + LeakyReLU' + blur^T in one pass), then
+    the up-conv's input gradient on the shared weights and its weight gradient with the same on-the-fly input."""
+
+    @staticmethod
+    def forward(ctx, a_in, s_in, t_in, w, bias, noise, noise_w, style, g, scale, bias_scale, act, slope, eps):
+        noise = _c(noise) if noise is not None else None
+        y, mean, rstd = k_conv_s2_fwd_blur_tail(a_in, s_in, t_in, w, bias, noise, noise_w, g, scale, bias_scale, act, slope,
+                                                eps)
+        style_c = _c(style) if style is not None else None
+        s_, t_ = _affine_from_stats(mean, rstd, style_c, g.N, g.Cout)
+        ctx.save_for_backward(a_in, s_in, t_in, w, y, mean, rstd, style_c, noise)
+        ctx.g, ctx.scale = g, scale
+        ctx.bias_scale, ctx.act, ctx.slope = bias_scale, act, slope
+        ctx.bias_shape = bias.shape if bias is not None else None
+        ctx.nw_shape = noise_w.shape if noise_w is not None else None
+        ctx.style_shape = style.shape if style is not None else None
+        ctx.bias_ref, ctx.nw_ref = bias, noise_w
+        ctx.want_x_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
+        ctx.want_bias_grad, ctx.want_nw_grad = ctx.needs_input_grad[4], ctx.needs_input_grad[6]
+        ctx.want_style_grad = ctx.needs_input_grad[7]
+        ctx.mark_non_differentiable(s_, t_, mean, rstd)
+        return y, s_, t_, mean, rstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_b, *_):
+        a_in, s_in, t_in, w = ctx.saved_tensors[:4]
+        gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors[4:], g_b, blur=True)   # d / d (conv output)
+        g = ctx.g
+        ga = gw = None
+        if ctx.needs_input_grad[0]:
+            ga = k_conv_dgrad(gz, w, g, ctx.scale)              # d/d(a_in*s + t) resp. d/d a_in: shared weights, plain kernel
+        if ctx.needs_input_grad[3] and _want_param_grads():
+            _sink('gw', w)
+            gw = k_conv_wgrad_aff(gz, a_in, s_in, t_in, g, ctx.scale) if s_in is not None else \
+                k_conv_wgrad(gz, a_in, g, ctx.scale)
+            if _sunk('gw'):
+                gw = None
+        return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None, None
+
+
+def upconv_blur_tail_ok(shape, weight, deferred, padding=1):
+    """Can the layer  Upsample -> conv3x3(weight) -> blur -> tail  on an input of ``shape`` run as the one-pass kernel (and,
+    for a deferred input, its weight gradient with the affine on load)?"""
+    if padding != 1 or tuple(weight.shape[2:]) != (3, 3) or int(weight.shape[1]) != int(shape[1]):
+        return False
+    n, cin, h, w = (int(v) for v in shape)
+    try:
+        g = Geom(n, cin, h, w, int(weight.shape[0]), 3, 1, 1, 0)
+    except ValueError:
+        return False
+    if not conv_s2_blur_ok(g) or not _lib.lib().ganlab_blur_fused_supported(2 * h, 2 * w):
+        return False
+    return conv_aff_ok(shape, weight, True, padding) if deferred else True
+
+
+def upconv_blur_tail(x, weight, scale, bias=None, noise=None, noise_w=None, style=None, bias_scale=1.0, act=None, slope=0.2,
+                     eps=1e-8):
+    """``x``: a tensor or a ``Deferred``; returns the layer's output as a ``Deferred`` (see ``upconv_blur_tail_ok``)."""
+    a_in, s_in, t_in = (x.a, x.s, x.t) if isinstance(x, Deferred) else (x, None, None)
+    n, cin, h, w = a_in.shape
+    g = Geom(n, cin, h, w, weight.shape[0], 3, 1, 1, 0)
+    a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    y, s_, t_, mean, rstd = _UpConvBlurTail.apply(a_in, s_in, t_in, weight, bias, noise, noise_w, style, g, float(scale),
+                                                  float(bias_scale), a, float(slope), float(eps))
+    return Deferred(y, s_, t_, mean, rstd, style)
+
+
 class _ToRGBMod(Function):
     """toRGB (1x1, stylegan/architectures.py torgb) of a deferred tensor: per-sample weights w*s and bias b + w.t, built
     and folded back by two small kernels (csrc/mod.hip)."""
@@ -2493,7 +2687,7 @@ ACT_DEFERRED = '_ganlab_act_deferred'    # attribute on a conv2d(defer_act_grad=
 
 
 def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False,
-           blur=False, defer_act_grad=False, in_act_slope=None):
+           blur=False, defer_act_grad=False, in_act_slope=None, in_blur_handoff=None):
     """blur?(act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale)) on the matrix cores.
     ``pool``: the D down layer conv -> AvgPool2d(2) -> +bias -> LeakyReLU (progan/architectures.py:261-284)
     as one stride-2 kernel when the shape qualifies, else composed from the plain kernels.
@@ -2516,8 +2710,11 @@ def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0,
         if not pool and not up and ks in (1, 3) and act == 'lrelu':
             g = Geom(n, cin, h, w, cout, ks, padding, 0, 0)
             if _lib.lib().ganlab_blur_fused_supported(g.Ho, g.Wo):
+                h = BlurHandoff()
                 y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), ACT_LRELU, float(slope),
-                                       True, False, in_act_slope)
+                                       True, False, in_act_slope, h, None)
+                if h.bits is not None:      # its only reader may take over this layer's blur^T / LeakyReLU' (fused_sequential)
+                    setattr(y, BLUR_HANDOFF, h)
         return y if y is not None else _Blur.apply(conv2d(x, weight, bias, scale, padding, up, bias_scale, act, slope,
                                                           pool, in_act_slope=in_act_slope))
     if pool and not (not up and pool_fusable(n, cin, h, w, cout, ks, padding)):
@@ -2533,8 +2730,12 @@ def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0,
         assert in_act_slope is None
         return _ConvFwd.apply(x, weight, g, float(scale))
     defer = bool(defer_act_grad) and a == ACT_LRELU and not conv_act_bwd_fusable(g)
+    hin = None
+    if in_blur_handoff is not None and pool and in_act_slope is None and in_blur_handoff.bits is not None and \
+            conv_s2_blur_ok(g):
+        hin = in_blur_handoff
     y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), a, float(slope), False, defer,
-                           in_act_slope)
+                           in_act_slope, None, hin)
     if defer:
         setattr(y, ACT_DEFERRED, True)
     return y

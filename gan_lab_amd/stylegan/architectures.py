@@ -11,6 +11,7 @@ Module tree, constructor arguments and ``state_dict`` keys are those of the refe
       -> InstanceNorm statistics + ONE pass: normalise and apply (ys+1, yb)       (K6+K7)
 """
 import copy
+import types
 
 import numpy as np
 import torch
@@ -251,6 +252,17 @@ class StyleGenerator(StyleGAN):
             body = head[:-1] if blur else head
             up = len(body) == 2 and isinstance(body[0], Upsample2x)
             conv = body[-1] if (body and isinstance(body[-1], Conv2dEx) and len(body) == (2 if up else 1)) else None
+            src = out.a if isinstance(out, ops.Deferred) else out
+            if up and blur and conv is not None and conv.conv2d.bias is None and plain_in and \
+                    ops.upconv_blur_tail_ok(src.shape, conv.conv2d.weight, isinstance(out, ops.Deferred), conv.padding):
+                # the layer that opens a resolution in ONE pass: upsample + conv + blur + noise + bias + LeakyReLU + the
+                # InstanceNorm statistics (thin transposed stride-2 kernel with the blur folded in), deferred in and out
+                like = types.SimpleNamespace(shape=(src.shape[0], 1, 2 * src.shape[2], 2 * src.shape[3]), device=src.device)
+                nz = layer[1].draw(like, noise[n] if noise is not None else None) if self.use_noise else None
+                nw = layer[1].noise_weight if nz is not None else None
+                d = ops.upconv_blur_tail(out, conv.conv2d.weight, conv.scale, bias_t, nz, nw, y, bias_scale=bias_scale,
+                                         act=name, slope=slope, eps=IN_EPS)
+                return d if self._defer_ok(d.a.shape, consumer) else ops.materialize(d)
             if isinstance(out, ops.Deferred) and conv is not None and conv.conv2d.bias is None:
                 if not up and not blur and bias is not None and plain_in and \
                         ops.mod_conv_ok(out, conv.conv2d.weight, conv.padding):

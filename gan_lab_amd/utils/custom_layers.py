@@ -297,7 +297,7 @@ class Conv2dEx(nn.Module):
         return s * (self.lrmul if self.use_lrmul else 1.0)
 
     def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None, blur=False, defer_act_grad=False,
-                in_act_slope=None):
+                in_act_slope=None, in_blur_handoff=None):
         # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
         # pool / bias_mod: the D down layer  conv -> AvgPool2d -> Conv2dBias -> LeakyReLU  as one kernel
         bias, bias_scale = self.conv2d.bias, (self.lrmul if self.use_lrmul else 1.0)
@@ -306,7 +306,7 @@ class Conv2dEx(nn.Module):
             bias, bias_scale = bias_mod.bias, (bias_mod.lrmul if bias_mod.use_lrmul else 1.0)
         return ops.conv2d(x, self.conv2d.weight, bias, scale=self.scale, padding=self.padding, up=up,
                           bias_scale=bias_scale, act=act, slope=slope, pool=pool, blur=blur,
-                          defer_act_grad=defer_act_grad, in_act_slope=in_act_slope)
+                          defer_act_grad=defer_act_grad, in_act_slope=in_act_slope, in_blur_handoff=in_blur_handoff)
 
 
 class Conv2dBias(nn.Module):
@@ -405,8 +405,10 @@ def fused_sequential(mods, x):
         add(m)
     i, n = 0, len(flat)
     pending_slope = None     # the previous conv left its LeakyReLU derivative to the conv that comes next
+    blur_handoff = None      # the previous conv -> LeakyReLU -> blur offers its blur^T / LeakyReLU' to the pooled conv behind it
     while i < n:
         m = flat[i]
+        handoff, blur_handoff = blur_handoff, None
         up = False
         if isinstance(m, Upsample2x) and i + 1 < n and isinstance(flat[i + 1], Conv2dEx):
             up = True
@@ -445,6 +447,8 @@ def fused_sequential(mods, x):
             if up:
                 kw['up'] = True
             if isinstance(m, Conv2dEx):
+                if handoff is not None and 'pool' in kw:
+                    kw['in_blur_handoff'] = handoff       # x has this one reader: ops.BlurHandoff
                 if pending_slope is not None:
                     kw['in_act_slope'] = pending_slope
                 # conv + LeakyReLU feeding the next conv directly (D block k -> block k+1): that conv's dgrad epilogue
@@ -457,6 +461,7 @@ def fused_sequential(mods, x):
                 assert pending_slope is None
             x = m(x, **kw)
             pending_slope = kw['slope'] if getattr(x, ops.ACT_DEFERRED, False) else None
+            blur_handoff = getattr(x, ops.BLUR_HANDOFF, None) if kw.get('blur') else None
         else:
             assert pending_slope is None
             x = m(x)

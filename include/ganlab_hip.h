@@ -406,6 +406,23 @@ int ganlab_conv_fwd_bits_f32(const float* x, const float* wp, const float* bias,
 int ganlab_conv_fwd_blur_supported(const ganlab_conv_geom* g, const void* x, const void* y);
 int ganlab_conv_fwd_blur_bits_f32(const float* x, const float* wp, const float* bias, float* y, unsigned* ybits,
                                   const ganlab_conv_geom* g, float bias_scale, float slope, void* stream);
+/* The thin transposed stride-2 conv (32 low-resolution channels -> <= 16 high-resolution ones, Wl % 32 == 0) together with
+ * the blur that follows it and what follows the blur (csrc/conv_s2_roll_blur.hip).  `g` is the UP layer (g->up) for the
+ * generator's forward tail (stylegan/architectures.py:292-334, 497-526):
+ *   y = act(blur(conv(up2(x * aff_s + aff_t), w)) + noise_w[c] * noise[n,hw] + bias[c] * bias_scale), mean / rstd = the
+ *   InstanceNorm statistics of y (aff_s / aff_t NULL: plain input; wp: ganlab_conv_s2_pack_f32(up 1, transposed 0));
+ * and the POOLED layer (g->pool) for the critic's backward (progan/architectures.py:254-284):
+ *   gz = lrelu'(ybits) * blur(dgrad(gy, w)), gb[c] = bias_scale * sum gz (gb may be NULL) - the pooled conv's input gradient
+ *   fused with the backward of the LeakyReLU -> blur in front of it (wp: what ganlab_conv_s2_dgrad_f32 takes). */
+int ganlab_conv_s2_blur_supported(const ganlab_conv_geom* g);
+size_t ganlab_conv_s2_blur_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_s2_fwd_blur_tail_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t,
+                                     const float* bias, const float* noise, const float* noise_w, float* y, float* mean,
+                                     float* rstd, const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_conv_s2_dgrad_blur_act_bits_f32(const float* gy, const float* wp, const unsigned* ybits, float* gz, float* gb,
+                                           const ganlab_conv_geom* g, float slope, float bias_scale, void* workspace,
+                                           size_t workspace_bytes, void* stream);
 int ganlab_conv_dgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* wp, float* gx,
                                    const ganlab_conv_geom* g, float slope, void* stream);
 int ganlab_conv_fwd_mask_bits_f32(const float* x, const float* wp, const unsigned* ybits, float* out,

@@ -1147,6 +1147,78 @@ def test_conv_lrelu_blur_fused_kernel_equals_composed(ops, shape, monkeypatch):
     assert (pre.reshape(-1).numpy()[bad].__abs__() < 1e-5).all() and bad.mean() < 1e-4, int(bad.sum())
 
 
+S2_BLUR_CASES = [(2, 32, 16, 16, 32), (1, 24, 9, 6, 64), (2, 32, 16, 128, 32), (1, 17, 16, 4, 96)]
+S2_BLUR_IDS = ['32->16 16x32', '24->9 6x64', 'row strips 128x32', '17->16 two steps 4x96']
+
+
+@pytest.mark.parametrize('deferred', [False, True], ids=['plain input', 'deferred input'])
+@pytest.mark.parametrize('shape', S2_BLUR_CASES, ids=S2_BLUR_IDS)
+def test_upconv_blur_tail_fused_kernel_equals_composed(ops, shape, deferred, monkeypatch):
+    """csrc/conv_s2_roll_blur.hip, TB_TAIL: the generator layer that opens a resolution - Upsample -> conv3x3 -> blur ->
+    +noise -> +bias -> LeakyReLU with the InstanceNorm statistics (stylegan/architectures.py:292-334, 497-526) - in one pass,
+    against the composed form (stride-2 transposed kernel, then the fused blur + tail pass): activation, the (s, t) of the
+    deferred InstanceNorm + style, and every gradient (input, weight, bias, noise weight, style) of a loss on the NORMALISED
+    output."""
+    n, cl, ch, hl, wl = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((shape, deferred)).encode()))
+    x0, w0 = rnd(gen, n, cl, hl, wl), rnd(gen, ch, cl, 3, 3)
+    b0, nw0, st0 = rnd(gen, 1, ch, 1, 1), rnd(gen, 1, ch, 1, 1), rnd(gen, n, 2 * ch)
+    nz = rnd(gen, n, 1, 2 * hl, 2 * wl).cuda()
+    s_in, t_in = (rnd(gen, n, cl) * 0.5 + 1).cuda(), rnd(gen, n, cl).cuda()
+    cot = rnd(gen, n, ch, 2 * hl, 2 * wl).cuda()
+    assert ops.upconv_blur_tail_ok((n, cl, hl, wl), w0, deferred), 'the fused kernel refused a geometry it documents'
+
+    def run(fused):
+        x, w = x0.cuda().requires_grad_(True), w0.cuda().requires_grad_(True)
+        b, nw, st = (t_.cuda().requires_grad_(True) for t_ in (b0, nw0, st0))
+        src = ops.Deferred(x, s_in, t_in, None, None, None) if deferred else x
+        if fused:
+            d = ops.upconv_blur_tail(src, w, 0.07, b, nz, nw, st, bias_scale=1.0, act='lrelu', slope=0.2, eps=1e-8)
+        else:
+            monkeypatch.setenv('GANLAB_S2_ROLL_BLUR', '0')
+            c = ops.conv_aff(src, w, 0.07, up=True) if deferred else ops.conv2d(x, w, None, scale=0.07, padding=1, up=True)
+            d = ops.layer_tail_deferred(c, b, nz, nw, st, bias_scale=1.0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
+            monkeypatch.delenv('GANLAB_S2_ROLL_BLUR')
+        out = ops.materialize(d)
+        (out * cot).sum().backward()
+        return [t_.detach() for t_ in (d.a, d.s, d.t, out, x.grad, w.grad, b.grad, nw.grad, st.grad)]
+    a, b_ = run(True), run(False)
+    for name, u, v in zip(['a', 's', 't', 'normalised output', 'gx', 'gw', 'gbias', 'gnoise_w', 'gstyle'], a, b_):
+        assert (u - v).abs().max().item() <= 5e-5 * v.abs().max().item(), name
+
+
+@pytest.mark.parametrize('shape', S2_BLUR_CASES, ids=S2_BLUR_IDS)
+def test_pooled_conv_dgrad_blur_act_fused_kernel_equals_composed(ops, shape, monkeypatch):
+    """csrc/conv_s2_roll_blur.hip, TB_MASK: the critic's  conv -> LeakyReLU -> blur -> conv -> AvgPool -> bias -> LeakyReLU
+    (progan/architectures.py:254-284) with the blur^T + LeakyReLU' + bias-gradient pass of the first layer folded into the
+    pooled conv's input-gradient kernel (ops.BlurHandoff) against the separate passes: outputs, first-order gradients of
+    both layers and the R1-shaped second order."""
+    n, cl, ch, hl, wl = shape           # the pooled conv maps ch (high) -> cl (low) channels
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()) + 1)
+    x0 = rnd(gen, n, ch, 2 * hl, 2 * wl)
+    wa0, ba0 = rnd(gen, ch, ch, 3, 3), rnd(gen, ch)
+    wb0, bb0 = rnd(gen, cl, ch, 3, 3), rnd(gen, 1, cl, 1, 1)
+    cot = rnd(gen, n, cl, hl, wl).cuda()
+
+    def run(fused):
+        monkeypatch.setenv('GANLAB_S2_ROLL_BLUR', '1' if fused else '0')
+        x = x0.cuda().requires_grad_(True)
+        wa, ba, wb, bb = (t_.cuda().requires_grad_(True) for t_ in (wa0, ba0, wb0, bb0))
+        y = ops.conv2d(x, wa, ba, scale=0.08, padding=1, act='lrelu', blur=True)
+        h = getattr(y, ops.BLUR_HANDOFF, None)
+        assert h is not None and h.bits is not None
+        z = ops.conv2d(y, wb, bb, scale=0.06, padding=1, act='lrelu', pool=True, in_blur_handoff=h)
+        gx, = torch.autograd.grad((z * cot).sum(), x, create_graph=True)
+        pen = (gx ** 2).sum()
+        second = torch.autograd.grad(pen, (wa, wb), retain_graph=True)
+        first = torch.autograd.grad((z * cot).sum(), (wa, ba, wb, bb))
+        return [t_.detach() for t_ in (z, gx) + tuple(first) + tuple(second)]
+    a, b_ = run(True), run(False)
+    names = ['z', 'gx', 'gwA', 'gbA', 'gwB', 'gbB', 'gwA (second order)', 'gwB (second order)']
+    for name, u, v in zip(names, a, b_):
+        assert (u - v).abs().max().item() <= 5e-5 * v.abs().max().item(), name
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 64, 64, 16), (3, 3, 64, 96, 24)], ids=['3->16 64x64', '3->24 64x96'])
 def test_fromrgb_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     """fromRGB (1x1 conv + LeakyReLU, progan/architectures.py:286-292) with its mask as bits: the forward writes y and
