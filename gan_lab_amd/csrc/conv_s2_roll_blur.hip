@@ -29,6 +29,7 @@
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TB_OOB = (int)0x80000000;
 constexpr int TB_TW = 32, TB_CP = 48, TB_SLOT = 32 * TB_CP, TB_SLOTS = 4, TB_Q = 10;
 constexpr int TB_ITEMS = 2 * 32 * TB_Q, TB_PT = (TB_ITEMS + 255) / 256;      // 640 float4 per 2-row prefetch, 3 per thread
@@ -155,6 +156,27 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_blur_kernel(TBArgs p) 
   const bool edge_l = X0 > 0, edge_r = X0 + TB_TW < p.Wl;
 
   for (int s = 0; s <= ns; ++s) {
+    // this step's output row (one behind the convolution) and what its tail reads from memory - the noise map resp. the
+    // sign bits of its 2 x 8 pixels - requested NOW: the round trip hides behind the MFMA phase
+    const int orow_g = HY0 - 3 + 4 * s + wv;
+    const bool own = orow_g >= HY0 && orow_g < HY0 + 4 * ns;
+    [[maybe_unused]] float4 nzp[4];
+    [[maybe_unused]] unsigned mbits[2] = {0xffu, 0xffu};
+    if constexpr (MODE == TB_TAIL) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nzp[i] = float4{0.f, 0.f, 0.f, 0.f};
+      if (own && p.noise != nullptr) {
+        const float* nrow = p.noise + ((long long)n * Hh + orow_g) * Wh + 2 * X0 + 8 * kk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nzp[i] = *reinterpret_cast<const float4*>(nrow + 32 * (i >> 1) + 4 * (i & 1));
+      }
+    } else {
+      if (own && co_ok) {
+        const unsigned char* brow = p.bits + (((((long long)n * p.Cout + co) * Hh + orow_g) * Wh + 2 * X0 + 8 * kk) >> 3);
+        mbits[0] = brow[0];
+        mbits[1] = brow[4];
+      }
+    }
     // ---- MFMA phase: conv row HY0 - 2 + 4s + wv from rel low rows 2s .. 2s+3 ----
     int sb[2], se[2];
 #pragma unroll
@@ -246,13 +268,13 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_blur_kernel(TBArgs p) 
     __syncthreads();          // rel rows 2s, 2s+1 of the input ring are dead; the blurred rows 4s .. 4s+3 are complete
     store_rows(2 * s + 4, s < ns);
     // ---- vertical blur, one row behind: wave q finishes conv row 4s - 1 + q (high row HY0 - 3 + 4s + q) ----
-    const int orow_g = HY0 - 3 + 4 * s + wv;
-    if (orow_g >= HY0 && orow_g < HY0 + 4 * ns) {
+    if (own) {
       const int r1 = 4 * s - 1 + wv;                 // >= 2 here
       const float* ra = oring + ((r1 - 1) % TB_OSLOTS) * TB_OROW + co * TB_OP + 8 * kk;
       const float* rbm = oring + (r1 % TB_OSLOTS) * TB_OROW + co * TB_OP + 8 * kk;
       const float* rc = oring + ((r1 + 1) % TB_OSLOTS) * TB_OROW + co * TB_OP + 8 * kk;
       const int obase = vo == TB_OOB ? TB_OOB : vo + orow_g * Wh * 4;
+      float rs1 = 0.f, rs2 = 0.f;        // this row's 16 pixels: fp32 partial sums, then one fp64 addition each
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -260,36 +282,35 @@ __global__ __launch_bounds__(256, 3) void conv_s2_up_roll_blur_kernel(TBArgs p) 
           const float4 a = *reinterpret_cast<const float4*>(ra + 32 * blk + 4 * hf);
           const float4 b = *reinterpret_cast<const float4*>(rbm + 32 * blk + 4 * hf);
           const float4 c = *reinterpret_cast<const float4*>(rc + 32 * blk + 4 * hf);
-          float o[4] = {(a.x + 2.f * b.x + c.x) * 0.0625f, (a.y + 2.f * b.y + c.y) * 0.0625f,
-                        (a.z + 2.f * b.z + c.z) * 0.0625f, (a.w + 2.f * b.w + c.w) * 0.0625f};
-          const int xh = 2 * X0 + 32 * blk + 8 * kk + 4 * hf;        // first high column of these four pixels
+          // two pixels per instruction (v_pk_fma_f32 / v_pk_mul_f32): VALU issue is what these kernels pay for the fold
+          const f32x2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w}, clo = {c.x, c.y}, chi = {c.z, c.w};
+          const f32x2 two = {2.f, 2.f}, sc = {0.0625f, 0.0625f};
+          const f32x2 olo = (__builtin_elementwise_fma(blo, two, alo) + clo) * sc;
+          const f32x2 ohi = (__builtin_elementwise_fma(bhi, two, ahi) + chi) * sc;
+          float o[4] = {olo[0], olo[1], ohi[0], ohi[1]};
           if constexpr (MODE == TB_TAIL) {
-            float4 nz = float4{0.f, 0.f, 0.f, 0.f};
-            if (p.noise != nullptr)
-              nz = *reinterpret_cast<const float4*>(p.noise + ((long long)n * Hh + orow_g) * Wh + xh);
+            const float4 nz = nzp[2 * blk + hf];
             const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              float v = o[j] + nzv[j] * nwv + bv;
+              float v = fmaf(nzv[j], nwv, o[j] + bv);
               if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
               o[j] = v;
-              sum1 += (double)v;
-              sum2 += (double)v * (double)v;
             }
+            // four terms in fp32 (a relative 1e-7 of a 4-term sum), everything beyond in fp64
+            rs1 += (o[0] + o[1]) + (o[2] + o[3]);
+            rs2 += fmaf(o[0], o[0], o[1] * o[1]) + fmaf(o[2], o[2], o[3] * o[3]);
           } else {
-            unsigned m = 0xffu;
-            if (co_ok) m = p.bits[((((long long)n * p.Cout + co) * Hh + orow_g) * Wh + xh) >> 3];
-            m >>= 4 * hf;
+            const unsigned m = mbits[blk] >> (4 * hf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float v = ((m >> j) & 1u) ? o[j] : o[j] * p.slope;
-              o[j] = v;
-              sum1 += (double)v;
-            }
+            for (int j = 0; j < 4; ++j) o[j] = ((m >> j) & 1u) ? o[j] : o[j] * p.slope;
+            rs1 += (o[0] + o[1]) + (o[2] + o[3]);
           }
           const u32x4 ov = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
           __builtin_amdgcn_raw_buffer_store_b128(ov, rs_out, obase == TB_OOB ? TB_OOB : obase + (32 * blk + 4 * hf) * 4, 0, 0);
         }
+      sum1 += (double)rs1;
+      if constexpr (MODE == TB_TAIL) sum2 += (double)rs2;
     }
     __syncthreads();          // the input ring holds rel rows 2s+2 .. 2s+5; output-ring rows 4s-2 .. 4s+1 may be rewritten
   }
