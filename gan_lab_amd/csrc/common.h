@@ -87,3 +87,9 @@ bool gl_s2_roll_supported(int is_T, int N, int Cin, int Cout, int Hl, int Wl, co
 int gl_s2_roll_launch(int is_T, const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int Cout,
                       int Hl, int Wl, int Cin_p, int Cout_p, float bias_scale, int act, float slope, hipStream_t st,
                       const float* aff_s = nullptr, const float* aff_t = nullptr);
+
+// ---- conv_roll_blur.hip: the thin rolling 3x3 kernel in the wave-owns-a-column-block layout; blur = 1: conv + bias + LeakyReLU
+//      + binomial blur (+ sign bits), blur = 0: conv + bias + act ------------------------------------------------------------
+bool gl_roll_blur_supported(int N, int Cin, int Cout, int H, int W, const void* x, const void* y);
+int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, float* y, void* bits, int N, int Cin, int Cout,
+                        int H, int W, int Cin_p, int Cout_p, float bias_scale, float slope, hipStream_t st, int blur, int act);

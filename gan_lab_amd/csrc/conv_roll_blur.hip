@@ -41,11 +41,16 @@ struct RBArgs {
   int Cin_p, Cout_p;
   int cols, strips, spu;    // 64-pixel columns per row, row strips per column, steps (4 rows) per strip
   float bias_scale, slope;
+  int act;                  // plain form only (the blurred form is LeakyReLU by definition)
 };
 
 __device__ __forceinline__ float rb_act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-__global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
+// BLUR = false: the same wave-owns-a-column-block MFMA phase with a plain epilogue (+bias, activation, store) - the rolling
+// 3x3 kernel with half the LDS operand reads of conv.hip's conv_fwd_roll_kernel (wave owns a row).
+template <bool BLUR>
+__global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(RBArgs p) {
+  constexpr int RO = BLUR ? 1 : 0;       // the blurred form computes activation rows Y0 - 1 .. (one extra step)
   __shared__ __attribute__((aligned(16))) float ring[RB_SLOTS * RB_SLOT];       // 30720 B
   __shared__ __attribute__((aligned(16))) float xn[2 * 4 * 16 * 4];             // [side][wave][co][row]: own edge pixels
   __shared__ __attribute__((aligned(16))) float xe[2 * 4 * 16 * 4];             // [side][wave][co][row]: outside columns, partial
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
   bid /= p.cols;
   const int syi = bid % p.strips;
   const int n0 = bid / p.strips;
-  const int ns = min(p.spu, p.H / 4 - syi * p.spu);       // steps that OWN output rows; the kernel runs ns + 1
+  const int ns = min(p.spu, p.H / 4 - syi * p.spu);       // steps that OWN output rows; the blurred form runs ns + 1
+  const int nrun = BLUR ? ns + 1 : ns;
   const int ox0 = txi * RB_TW, Y0 = syi * p.spu * 4;
   const int plane = p.H * p.W;
   const float* xb = p.x + (long long)n0 * p.Cin * plane;
@@ -93,11 +99,11 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
   const int vo_lane = co_ok ? (int)(((long long)co * oplane + ox0 + w * 16 + kk * 4) * 4) : RB_OOB;
 
   float4 xr[RB_PT];
-  // rel row r of the strip = input row Y0 - 2 + r; rows outside the image and k >= nrows read as zeros
+  // rel row r of the strip = input row Y0 - RO - 1 + r; rows outside the image and k >= nrows read as zeros
   auto load_rows = [&](int rel0, int nrows) {
 #pragma unroll
     for (int i = 0; i < RB_PT; ++i) {
-      const int vy = Y0 - 2 + rel0 + lo_k[i];
+      const int vy = Y0 - RO - 1 + rel0 + lo_k[i];
       const bool ok = gbase[i] != RB_OOB && lo_k[i] < nrows && (unsigned)vy < (unsigned)p.H;
       const int off = ok ? gbase[i] + (int)((unsigned)vy * (unsigned)(p.W * 4)) : RB_OOB;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
@@ -130,8 +136,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
   store_rows(4, 2);
   __syncthreads();
 
-  for (int s = 0; s <= ns; ++s) {
-    // ---- MFMA phase: v rows Y0 - 1 + 4s + r4 (r4 < 4) of column block w from rel input rows 4s .. 4s+5 ----
+  for (int s = 0; s < nrun; ++s) {
+    // ---- MFMA phase: v rows Y0 - RO + 4s + r4 (r4 < 4) of column block w from rel input rows 4s .. 4s+5 ----
     int sb[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) sb[j] = ((4 * s + j) % RB_SLOTS) * RB_SLOT;
@@ -172,11 +178,33 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
         if (ky >= 0 && ky < 3)
           acc[r4] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot], wreg[(ky * 3 + kx) * 4 + c4], acc[r4], 0, 0, 0);
       }
-      if ((f & 7) == 3) ae = ring[eb[(f >> 3) / 3] + (f >> 3) % 3];     // operand of the outside columns' K-step f / 8
-      if ((f & 7) == 7)          // this wave's share of the fifth block: tap f / 8 of channel group w
-        acce = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, wedge[f >> 3], acce, 0, 0, 0);
-      if (f == 8) load_rows(4 * s + 6, s < ns ? 4 : 0);
+      if constexpr (BLUR) {
+        if ((f & 7) == 3) ae = ring[eb[(f >> 3) / 3] + (f >> 3) % 3];     // operand of the outside columns' K-step f / 8
+        if ((f & 7) == 7)          // this wave's share of the fifth block: tap f / 8 of channel group w
+          acce = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, wedge[f >> 3], acce, 0, 0, 0);
+      }
+      if (f == 8) load_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!BLUR) {
+      // ---- plain epilogue: +bias, activation, 16-byte stores of the four rows ----
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = Y0 + 4 * s + r4;
+        u32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[r4][r] + bv;
+          if (p.act == GANLAB_ACT_LRELU) t = gl_lrelu(t, p.slope);
+          o[r] = __float_as_uint(t);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, 0);
+        acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read
+      store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
+      __syncthreads();
+      continue;
     }
     // ---- activation; publish what the neighbours need ----
     f32x4 v[4];
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
       *reinterpret_cast<float4*>(xe + ((kk * 4 + w) * 16 + co) * 4) = float4{acce[0], acce[1], acce[2], acce[3]};
     acce = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the exchange buffers are complete
-    store_rows(4 * s + 6, s < ns ? 4 : 0);       // into the slots of rows 4s .. 4s+3
+    store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);       // into the slots of rows 4s .. 4s+3
     // ---- horizontal blur (unnormalised [1 2 1]) ----
     float4 nl = float4{0.f, 0.f, 0.f, 0.f}, nr = nl;      // left neighbour of pixel 0 / right neighbour of pixel 15 (by row)
     if (kk == 0) {
@@ -287,21 +315,23 @@ bool gl_roll_blur_supported(int N, int Cin, int Cout, int H, int W, const void* 
 }
 
 int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, float* y, void* bits, int N, int Cin, int Cout,
-                        int H, int W, int Cin_p, int Cout_p, float bias_scale, float slope, hipStream_t st) {
+                        int H, int W, int Cin_p, int Cout_p, float bias_scale, float slope, hipStream_t st, int blur,
+                        int act) {
   RBArgs a{};
   a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.bits = reinterpret_cast<unsigned short*>(bits);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Cin_p = Cin_p; a.Cout_p = Cout_p;
-  a.bias_scale = bias_scale; a.slope = slope;
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
   a.cols = W / RB_TW;
   const int steps = H / 4;
   const long long cols = (long long)a.cols * N;
   int k = 1;                   // row strips per column: >= ~4096 workgroups, >= 16 steps each (every strip pays one extra)
-  while (k < steps && cols * k < 4096 && (steps + k) / (k + 1) >= 16) ++k;
+  while (k < steps && cols * k < 4096 && (steps + k) / (k + 1) >= (blur ? 16 : 8)) ++k;
   a.spu = (steps + k - 1) / k;
   a.strips = (steps + a.spu - 1) / a.spu;
   const long long grid = cols * a.strips;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  GL_LAUNCH(conv_fwd_roll_blur_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (blur) GL_LAUNCH(conv_fwd_roll_blur_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_fwd_roll_blur_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -318,7 +348,17 @@ int ganlab_conv_fwd_blur_bits_f32(const float* x, const float* wp, const float* 
   if (!ganlab_conv_fwd_blur_supported(g, x, y)) return GANLAB_EUNSUPPORTED;
   const int cin_p = (g->Cin + 15) / 16 * 16, cout_p = (g->Cout + 63) / 64 * 64;
   return gl_roll_blur_launch(x, wp, bias, y, ybits, g->N, g->Cin, g->Cout, g->Hin, g->Win, cin_p, cout_p, bias_scale,
-                             slope, gl_stream(stream));
+                             slope, gl_stream(stream), 1, GANLAB_ACT_LRELU);
+}
+
+// experiment hook (tools/roll_col_bench.py): the plain conv through the column-block layout
+int ganlab_dbg_conv_fwd_roll_col_f32(const float* x, const float* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                                     float bias_scale, int act, float slope, void* stream) {
+  if (!x || !wp || !y || !g) return GANLAB_EINVAL;
+  if (!ganlab_conv_fwd_blur_supported(g, x, y)) return GANLAB_EUNSUPPORTED;
+  const int cin_p = (g->Cin + 15) / 16 * 16, cout_p = (g->Cout + 63) / 64 * 64;
+  return gl_roll_blur_launch(x, wp, bias, y, nullptr, g->N, g->Cin, g->Cout, g->Hin, g->Win, cin_p, cout_p, bias_scale,
+                             slope, gl_stream(stream), 0, act);
 }
 
 }  // extern "C"
