@@ -97,10 +97,11 @@ class _StepGraphs(object):
         self.graphs, self.pool, self.sig, self.calls = {}, None, None, 0
         self.block = self.real = None
         self.losses = {}
+        self.failed = None          # the exception of a capture that did not go through: this phase then steps eagerly
 
     def eligible(self):
         from . import parallel
-        return parallel.world_size() == 1 and torch.cuda.is_available()
+        return parallel.world_size() == 1 and torch.cuda.is_available() and self.failed is None
 
     def _common_signature(self, real):
         L = self.L
@@ -133,6 +134,11 @@ class _StepGraphs(object):
         try:
             with torch.cuda.graph(graph, pool=self.pool):
                 self.losses[key[0]].copy_(fn())
+        except Exception as exc:      # an op that cannot be captured (a host sync, an allocation outside the pool): no retry
+            self.failed = exc
+            import warnings
+            warnings.warn(f'step-graph capture of {key} failed ({type(exc).__name__}: {exc}); stepping eagerly', RuntimeWarning)
+            raise
         finally:
             L.opt_disc.dev_scalars = L.opt_gen.dev_scalars = None
             draws = rng.end_device_offsets()
@@ -233,16 +239,30 @@ class GraphedStep(_StepGraphs):
             self.real = torch.empty_like(real)
             self.real.copy_(real)
             if self.precapture:
-                for cut in self._all_cuts():
-                    kw = {'_mix': (cut, None)} if hasattr(g, 'draw_mixing_cutoff') else None
-                    for kind in ('d', 'g'):
-                        self._capture_half(kind, cut, kw)
+                try:
+                    for cut in self._all_cuts():
+                        kw = {'_mix': (cut, None)} if hasattr(g, 'draw_mixing_cutoff') else None
+                        for kind in ('d', 'g'):
+                            self._capture_half(kind, cut, kw)
+                except Exception:
+                    cut_d, kw_d = self._mix_kwargs()
+                    ld = self._d_half(real, kw_d)
+                    cut_g, kw_g = self._mix_kwargs()
+                    return ld, self._g_half(kw_g)
         self.real.copy_(real)
         out = []
         for kind in ('d', 'g'):
             cut, kw = self._mix_kwargs()
             if (kind, cut) not in self.graphs:
-                self._capture_half(kind, cut, kw)
+                try:
+                    self._capture_half(kind, cut, kw)
+                except Exception:
+                    # nothing of this half has run (a capture records): finish the iteration eagerly, stay eager afterwards
+                    out.append(self._d_half(real, kw) if kind == 'd' else self._g_half(kw))
+                    if kind == 'd':
+                        cut_g, kw_g = self._mix_kwargs()
+                        out.append(self._g_half(kw_g))
+                    return tuple(out)
             # the deferred critic update and the generator update both sit in the 'g' half
             out.append(self._replay((kind, cut), ('d', 'g') if kind == 'g' else ()))
         return tuple(out)
