@@ -57,6 +57,23 @@ def main():
     # deferred-InstanceNorm consumers (affine on load): k_conv_fwd_aff(a, s, t, w, g, scale), k_conv_wgrad_aff(gy, a, s, t, g, ..)
     ops.k_conv_fwd_aff = wrap('fwd', ops.k_conv_fwd_aff, 4)
     ops.k_conv_wgrad_aff = wrap('wgrad', ops.k_conv_wgrad_aff, 4)
+    # the rolling kernels with the blur folded in (the blur / tail pass they absorb is part of their time, not of their FLOPs):
+    # k_conv_fwd_blur_bits(x, w, bias, g, ..), k_conv_s2_fwd_blur_tail(a, s, t, w, bias, noise, nw, g, ..),
+    # k_conv_s2_dgrad_blur_act(gy, w, bits, g, ..)
+    def wrap_opt(name, fn, gi):          # these return None where they do not take the geometry: not a launch
+        def f(*args, **kw):
+            g = args[gi]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            if out is not None:
+                rec.append((name, g, e0, e1))
+            return out
+        return f
+    ops.k_conv_fwd_blur_bits = wrap_opt('fwd+blur', ops.k_conv_fwd_blur_bits, 3)
+    ops.k_conv_s2_fwd_blur_tail = wrap('fwd+blur+tail', ops.k_conv_s2_fwd_blur_tail, 7)
+    ops.k_conv_s2_dgrad_blur_act = wrap("dgrad+blur+act'", ops.k_conv_s2_dgrad_blur_act, 3)
     torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s0.record()
