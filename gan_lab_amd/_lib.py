@@ -83,6 +83,10 @@ SIGNATURES = {
     'ganlab_conv_s2_fwd_blur_tail_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int,
                                                   _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_s2_dgrad_blur_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_dgrad_rgb_sums_supported': (_c_int, [_GP, _c_int]),
+    'ganlab_conv_dgrad_rgb_sums_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_dgrad_rgb_sums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_int, _c_f, _c_f, _c_f, _c_int, _c_int,
+                                                _c_p, _c_sz, _c_p]),
     'ganlab_conv_fwd_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_act_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
     'ganlab_conv_fwd_mask_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),

@@ -42,15 +42,26 @@ struct RBArgs {
   int cols, strips, spu;    // 64-pixel columns per row, row strips per column, steps (4 rows) per strip
   float bias_scale, slope;
   int act;                  // plain form only (the blurred form is LeakyReLU by definition)
+  // MODE RB_RGB (the kernel as the INPUT GRADIENT of the critic's first 3x3 conv): nothing is stored; the gradient meets
+  // the layer in front - fromRGB, a 1x1 conv of the <= 4-channel image + LeakyReLU (progan/architectures.py:232-237) - right
+  // here: gz = result * lrelu'(mbits), part[(co*4 + c)][wg] = sum gz * img[c] (c < 3: fromRGB's weight gradient), c = 3: sum gz
+  const float* img;          // (N, img_c, H, W)
+  const unsigned char* mbits;   // sign bits of fromRGB's output, bit e of the NCHW-linear index
+  double* part;              // [Cout][4][grid]
+  int img_c;
 };
+enum { RB_PLAIN = 0, RB_BLUR = 1, RB_RGB = 2 };
 
 __device__ __forceinline__ float rb_act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // BLUR = false: the same wave-owns-a-column-block MFMA phase with a plain epilogue (+bias, activation, store) - the rolling
 // 3x3 kernel with half the LDS operand reads of conv.hip's conv_fwd_roll_kernel (wave owns a row).
-template <bool BLUR>
-__global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(RBArgs p) {
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_blur_kernel(RBArgs p) {
+  constexpr bool BLUR = MODE == RB_BLUR, RGB = MODE == RB_RGB;
   constexpr int RO = BLUR ? 1 : 0;       // the blurred form computes activation rows Y0 - 1 .. (one extra step)
+  __shared__ __attribute__((aligned(16))) float img_s[RGB ? 4 * 4 * 64 : 4];   // [c][row of the step][64 pixels]
+  __shared__ double red_s[RGB ? 4 * 16 * 4 : 1];
   __shared__ __attribute__((aligned(16))) float ring[RB_SLOTS * RB_SLOT];       // 30720 B
   __shared__ __attribute__((aligned(16))) float xn[2 * 4 * 16 * 4];             // [side][wave][co][row]: own edge pixels
   __shared__ __attribute__((aligned(16))) float xe[2 * 4 * 16 * 4];             // [side][wave][co][row]: outside columns, partial
@@ -122,6 +133,11 @@ __global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(R
   for (int r4 = 0; r4 < 4; ++r4) acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
   acce = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;       // horizontally blurred rows carried from the previous step
+  // RGB: this thread's share of the image rows of a step (tid < 64 * img_c: channel tid / 64, row (tid / 16) % 4, float4
+  // tid % 16), the per-channel sums of this lane's output channel `co`
+  [[maybe_unused]] float4 imgr = float4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+  [[maybe_unused]] const int img_item = (tid < 64 * p.img_c) ? ((tid >> 6) * plane + ((tid >> 4) & 3) * p.W + ox0 + 4 * (tid & 15)) : -1;
 
   // A-operand addressing.  Main blocks: pixel = lane & 15 of column block w, channel 4*c4 + kk.
   const int a_lane = kk * RB_RP + w * 16 + co + 3;     // + LP(4) - pad(1); `co` doubles as the pixel index here
@@ -137,6 +153,16 @@ __global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(R
   __syncthreads();
 
   for (int s = 0; s < nrun; ++s) {
+    [[maybe_unused]] unsigned mb[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+    if constexpr (RGB) {      // the tail's memory operands, requested before the MFMA phase
+      if (img_item >= 0)
+        imgr = *reinterpret_cast<const float4*>(p.img + (long long)n0 * p.img_c * plane + img_item + (Y0 + 4 * s) * p.W);
+      if (co_ok) {
+        const unsigned char* bp = p.mbits + ((((long long)n0 * p.Cout + co) * p.H + Y0 + 4 * s) * p.W + ox0 + w * 16 + kk * 4) / 8;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) mb[r4] = bp[r4 * (p.W >> 3)] >> (4 * (kk & 1));
+      }
+    }
     // ---- MFMA phase: v rows Y0 - RO + 4s + r4 (r4 < 4) of column block w from rel input rows 4s .. 4s+5 ----
     int sb[6];
 #pragma unroll
@@ -185,6 +211,27 @@ __global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(R
       }
       if (f == 8) load_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (RGB) {
+      __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the previous step's image rows neither
+      store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
+      if (img_item >= 0) *reinterpret_cast<float4*>(img_s + (tid >> 4) * 64 + 4 * (tid & 15)) = imgr;
+      __syncthreads();
+      // gz = gradient * lrelu'(fromRGB output); per-channel sums of gz * image and of gz: four pixels in fp32, then fp64
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        float gz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gz[r] = ((mb[r4] >> r) & 1u) ? acc[r4][r] : acc[r4][r] * p.slope;
+        acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float4 iv = *reinterpret_cast<const float4*>(img_s + (c * 4 + r4) * 64 + w * 16 + kk * 4);
+          rsum[c] += (double)(fmaf(gz[0], iv.x, gz[1] * iv.y) + fmaf(gz[2], iv.z, gz[3] * iv.w));
+        }
+        rsum[3] += (double)((gz[0] + gz[1]) + (gz[2] + gz[3]));
+      }
+      continue;
     }
     if constexpr (!BLUR) {
       // ---- plain epilogue: +bias, activation, 16-byte stores of the four rows ----
@@ -301,11 +348,59 @@ __global__ __launch_bounds__(256, BLUR ? 3 : 4) void conv_fwd_roll_blur_kernel(R
     }
     __syncthreads();   // the ring holds rows 4s+4 .. 4s+9; the exchange buffers may be rewritten
   }
+  if constexpr (RGB) {        // this workgroup's partial sums: lane groups, then waves (fixed order)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rsum[c] += __shfl_xor(rsum[c], 16, 64);
+      rsum[c] += __shfl_xor(rsum[c], 32, 64);
+    }
+    __syncthreads();
+    if (kk == 0)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red_s[(w * 16 + co) * 4 + c] = rsum[c];
+    __syncthreads();
+    if (tid < 64 && (tid >> 2) < p.Cout) {
+      const int c = tid & 3, ch = tid >> 2;
+      const double t = (red_s[(0 * 16 + ch) * 4 + c] + red_s[(1 * 16 + ch) * 4 + c]) +
+                       (red_s[(2 * 16 + ch) * 4 + c] + red_s[(3 * 16 + ch) * 4 + c]);
+      p.part[(long long)(ch * 4 + c) * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
+
+// gw[co][c] (c < img_c) = scale * sum_k part[co*4 + c][k], gb[co] = bias_scale * sum_k part[co*4 + 3][k]; `accumulate`: onto
+// what the outputs hold (a parameter's second gradient contribution of a step)
+__global__ void rb_rgb_finish_kernel(const double* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int chunks,
+                                     int img_c, float scale, float bias_scale, int accumulate) {
+  const int ch = blockIdx.x >> 2, c = blockIdx.x & 3;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < chunks; i += 64) t += part[(long long)blockIdx.x * chunks + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (threadIdx.x != 0) return;
+  if (c < img_c && gw != nullptr) {
+    float* d = gw + ch * img_c + c;
+    *d = ((accumulate & 1) ? *d : 0.f) + (float)(t * (double)scale);
+  } else if (c == 3 && gb != nullptr) {
+    gb[ch] = ((accumulate & 2) ? gb[ch] : 0.f) + (float)(t * (double)bias_scale);
+  }
 }
 
 }  // namespace
 
 // ---- host side (called from conv.hip's entry points) ----
+// row strips per column: >= ~4096 workgroups, >= 16 (blurred form: every strip pays one extra step) / 8 steps each
+static long long rb_plan(RBArgs& a, int N, int H, int W, int blur) {
+  a.cols = W / RB_TW;
+  const int steps = H / 4;
+  const long long cols = (long long)a.cols * N;
+  int k = 1;
+  while (k < steps && cols * k < 4096 && (steps + k) / (k + 1) >= (blur ? 16 : 8)) ++k;
+  a.spu = (steps + k - 1) / k;
+  a.strips = (steps + a.spu - 1) / a.spu;
+  return cols * a.strips;
+}
+
 bool gl_roll_blur_supported(int N, int Cin, int Cout, int H, int W, const void* x, const void* y) {
   const char* e = getenv("GANLAB_ROLL_BLUR");
   if (e != nullptr && e[0] == '0') return false;                 // A/B knob: conv kernel + blur pass
@@ -321,17 +416,10 @@ int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, floa
   a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.bits = reinterpret_cast<unsigned short*>(bits);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Cin_p = Cin_p; a.Cout_p = Cout_p;
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
-  a.cols = W / RB_TW;
-  const int steps = H / 4;
-  const long long cols = (long long)a.cols * N;
-  int k = 1;                   // row strips per column: >= ~4096 workgroups, >= 16 steps each (every strip pays one extra)
-  while (k < steps && cols * k < 4096 && (steps + k) / (k + 1) >= (blur ? 16 : 8)) ++k;
-  a.spu = (steps + k - 1) / k;
-  a.strips = (steps + a.spu - 1) / a.spu;
-  const long long grid = cols * a.strips;
+  const long long grid = rb_plan(a, N, H, W, blur);
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  if (blur) GL_LAUNCH(conv_fwd_roll_blur_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else GL_LAUNCH(conv_fwd_roll_blur_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (blur) GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_BLUR>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_PLAIN>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
@@ -349,6 +437,47 @@ int ganlab_conv_fwd_blur_bits_f32(const float* x, const float* wp, const float* 
   const int cin_p = (g->Cin + 15) / 16 * 16, cout_p = (g->Cout + 63) / 64 * 64;
   return gl_roll_blur_launch(x, wp, bias, y, ybits, g->N, g->Cin, g->Cout, g->Hin, g->Win, cin_p, cout_p, bias_scale,
                              slope, gl_stream(stream), 1, GANLAB_ACT_LRELU);
+}
+
+int ganlab_conv_dgrad_rgb_sums_supported(const ganlab_conv_geom* g, int img_c) {
+  if (!g || g->ks != 3 || g->pad != 1 || g->up || g->pool || img_c < 1 || img_c > 3) return 0;
+  return gl_roll_blur_supported(g->N, g->Cout, g->Cin, g->Hin, g->Win, nullptr, nullptr) ? 1 : 0;
+}
+
+size_t ganlab_conv_dgrad_rgb_sums_workspace(const ganlab_conv_geom* g) {
+  if (!ganlab_conv_dgrad_rgb_sums_supported(g, 3)) return 0;
+  RBArgs a{};
+  const long long grid = rb_plan(a, g->N, g->Hin, g->Win, 0);
+  return (size_t)g->Cin * 4 * (size_t)grid * sizeof(double);
+}
+
+/* The input gradient of the critic's first 3x3 conv (geometry g, weights wp as ganlab_conv_dgrad_f32 takes them) met by the
+ * backward of the fromRGB layer in front of it (1x1 conv of the img_c-channel image + LeakyReLU, progan/architectures.py:
+ * 232-237) inside the kernel: gz = dgrad(gy, w) * lrelu'(ybits); gw_rgb[co][c] = scale * sum gz[co] * img[c],
+ * gb_rgb[co] = bias_scale * sum gz[co] - the gradient tensor itself is not written.  acc_w / acc_b: add to what gw_rgb /
+ * gb_rgb hold.  For callers that do not need fromRGB's input gradient. */
+int ganlab_conv_dgrad_rgb_sums_f32(const float* gy, const float* wp, const unsigned* ybits, const float* img, float* gw_rgb,
+                                   float* gb_rgb, const ganlab_conv_geom* g, int img_c, float scale, float bias_scale,
+                                   float slope, int acc_w, int acc_b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gy || !wp || !ybits || !img || !g || (!gw_rgb && !gb_rgb)) return GANLAB_EINVAL;
+  if (!ganlab_conv_dgrad_rgb_sums_supported(g, img_c) || (reinterpret_cast<uintptr_t>(gy) & 15) ||
+      (reinterpret_cast<uintptr_t>(img) & 15))
+    return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < ganlab_conv_dgrad_rgb_sums_workspace(g)) return GANLAB_EWORKSPACE;
+  RBArgs a{};
+  a.x = gy; a.wp = wp; a.bias = nullptr; a.y = nullptr; a.bits = nullptr;
+  a.N = g->N; a.Cin = g->Cout; a.Cout = g->Cin; a.H = g->Hin; a.W = g->Win;     // roles swap: the operator consumes gy
+  a.Cin_p = (g->Cout + 15) / 16 * 16; a.Cout_p = (g->Cin + 63) / 64 * 64;
+  a.bias_scale = 0.f; a.slope = slope; a.act = GANLAB_ACT_NONE;
+  a.img = img; a.mbits = reinterpret_cast<const unsigned char*>(ybits); a.part = reinterpret_cast<double*>(workspace);
+  a.img_c = img_c;
+  const long long grid = rb_plan(a, g->N, g->Hin, g->Win, 0);
+  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  hipStream_t st = gl_stream(stream);
+  GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_RGB>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  GL_LAUNCH(rb_rgb_finish_kernel, dim3((unsigned)(g->Cin * 4)), dim3(64), 0, st, (const double*)a.part, gw_rgb, gb_rgb,
+            (int)grid, img_c, scale, bias_scale, (acc_w ? 1 : 0) | (acc_b ? 2 : 0));
+  return GL_CHECK_LAUNCH();
 }
 
 // experiment hook (tools/roll_col_bench.py): the plain conv through the column-block layout

@@ -1312,6 +1312,63 @@ class BlurHandoff(object):
         self.bits, self.slope, self.bias_scale, self.want_gb, self.gb, self.done = None, 0.2, 1.0, False, None, False
 
 
+RGB_HANDOFF = '_ganlab_rgb_handoff'
+
+
+class RgbHandoff(object):
+    """Link between the critic's fromRGB layer (1x1 conv of the image + LeakyReLU, progan/architectures.py:232-237) and the 3x3
+    conv that is its only reader: where nobody needs fromRGB's input gradient (the critic steps on detached fakes, and on the
+    real batch under ``no_grad_towards``), the reader's input-gradient kernel can finish fromRGB's backward itself - mask by
+    the sign bits, weight / bias gradient sums against the image - and never write the 2 GiB gradient tensor between them
+    (csrc/conv_roll_blur.hip, RB_RGB).  Only inside ``direct_param_grads`` (the sums go straight into the arena slots)."""
+    __slots__ = ('bits', 'slope', 'img', 'w', 'bias', 'scale', 'bias_scale')
+
+    def __init__(self):
+        self.bits = None
+
+
+def _rgb_fold_ok(h, g):
+    """May the input gradient of the conv with geometry ``g`` swallow the backward of the fromRGB layer ``h`` describes?"""
+    import os
+    if h is None or h.bits is None or torch.is_grad_enabled() or not _DIRECT[0] or not _want_param_grads() or \
+            os.environ.get('GANLAB_RGB_FOLD') == '0' or get_compute_dtype() != 'f32':
+        return False
+    x = h.img
+    if x.requires_grad and not (_NO_GRAD_TOWARDS[0] is not None and x.grad_fn is None and x.data_ptr() == _NO_GRAD_TOWARDS[0]):
+        return False            # somebody wants d / d image: the gradient tensor has to exist
+    for p_ in (h.w, h.bias):
+        if p_ is None:
+            continue
+        base = p_._base if p_._base is not None else p_
+        if not base.requires_grad or getattr(base, '_ganlab_arena', None) is None or base.grad is None or \
+                base.numel() != p_.numel():
+            return False
+    return bool(_lib.lib().ganlab_conv_dgrad_rgb_sums_supported(g.ref(), int(x.shape[1])))
+
+
+def k_conv_dgrad_rgb_sums(gz, w, h, g, scale):
+    """Input gradient of the 3x3 conv ``g`` on ``gz`` folded with fromRGB's backward: fromRGB's weight / bias gradients are
+    added into their arena slots; nothing else is written."""
+    gz, w = _c(gz, 'conv grad_out'), _c(w, 'conv weight')
+    assert tuple(gz.shape) == g.out_shape
+    _note('dgrad', g)
+    L = _lib.lib()
+
+    def slot(p_):
+        base = p_._base if p_._base is not None else p_
+        arena = base._ganlab_arena
+        acc = getattr(base, '_ganlab_written', -1) == arena.serial
+        base._ganlab_written = arena.serial
+        return base.grad, int(acc)
+    gw, acc_w = slot(h.w)
+    gb, acc_b = slot(h.bias) if h.bias is not None else (None, 0)
+    img = _c(h.img, 'image')
+    ws = torch.empty((L.ganlab_conv_dgrad_rgb_sums_workspace(g.ref()) + 7) // 8, dtype=torch.float64, device=gz.device)
+    check(L.ganlab_conv_dgrad_rgb_sums_f32(_p(gz), _p(_packed(w, PACK_DGRAD, scale)), h.bits.data_ptr(), _p(img), _p(gw), _p(gb),
+                                           g.ref(), int(img.shape[1]), h.scale, h.bias_scale, h.slope, acc_w, acc_b,
+                                           ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'conv_dgrad_rgb_sums')
+
+
 class _ConvDgradBlurAct(Function):
     """(gzA, gbA) = (lrelu'(bits) * blur(dgrad_B(gy, w)), bias_scale * sum gzA) in one kernel; linear in gy and in w.  Its
     derivative is the composition the separate passes have: the adjoint of blur^T o mask (``_ActBwdBlur``), then the pooled
@@ -1503,13 +1560,14 @@ class _ConvBiasAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, g, s, bias_scale, act, slope, blur=False, defer=False, in_slope=None, handoff_out=None,
-                handoff_in=None):
+                handoff_in=None, rgb_out=None, rgb_in=None):
         # defer: the (single) consumer of y applies this layer's lrelu'(y) to the gradient it sends back (its dgrad
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
         ctx.bias_ref = bias
         # handoff_out: this is layer A of a BlurHandoff pair (filled in below when the sign bits exist); handoff_in: layer B
         ctx.handoff_out, ctx.handoff_in = None, handoff_in
+        ctx.rgb_in = rgb_in         # this conv reads a fromRGB layer's output (RgbHandoff)
         if act != ACT_NONE and not blur and not defer and in_slope is None and conv_act_bwd_fusable(g) and \
                 (g.Ho * g.Wo) % 32 == 0 and mask_bits_ok_plane():
             # fromRGB: the gradient kernels take (gy, mask of y); the forward writes that mask as bits next to y
@@ -1517,6 +1575,9 @@ class _ConvBiasAct(Function):
             ctx.defer, ctx.in_slope = False, None
             ctx.bias_shape = bias.shape if bias is not None else None
             ctx.save_for_backward(x, w, bits)
+            if rgb_out is not None and g.ks == 1:       # fromRGB: its only reader may finish this layer's backward
+                rgb_out.bits, rgb_out.slope, rgb_out.img, rgb_out.w, rgb_out.bias = bits, slope, x, w, bias
+                rgb_out.scale, rgb_out.bias_scale = s, bias_scale
             return y
         ctx.defer, ctx.in_slope = bool(defer), in_slope
         assert not (defer and blur)
@@ -1561,7 +1622,7 @@ class _ConvBiasAct(Function):
                 if _sunk('gb'):
                     want_b = False
             return gx, (gw if ctx.needs_input_grad[1] else None), (gb.view(ctx.bias_shape) if want_b else None), \
-                None, None, None, None, None, None, None, None, None, None
+                None, None, None, None, None, None, None, None, None, None, None, None
         h = ctx.handoff_out
         if h is not None and h.done:
             # the pooled conv behind the blur already applied blur^T and this layer's LeakyReLU derivative in its input-
@@ -1584,7 +1645,11 @@ class _ConvBiasAct(Function):
         if _sunk('gb'):
             gb = None
         gx = None
-        if _wants_input_grad(ctx, x):
+        if _wants_input_grad(ctx, x) and ctx.in_slope is None and ctx.handoff_in is None and _rgb_fold_ok(ctx.rgb_in, ctx.g):
+            # x is fromRGB's output and nobody needs fromRGB's input gradient: this conv's input-gradient kernel sums
+            # fromRGB's weight / bias gradients into their arena slots; the gradient tensor in between is never written
+            k_conv_dgrad_rgb_sums(gz, w, ctx.rgb_in, ctx.g, ctx.s)
+        elif _wants_input_grad(ctx, x):
             hin = ctx.handoff_in
             if hin is not None:      # layer B of the pair: input gradient + layer A's blur^T, LeakyReLU', bias gradient
                 gx, gba = _ConvDgradBlurAct.apply(gz, w, hin.bits, ctx.g, ctx.s, hin.slope, hin.bias_scale,
@@ -1600,7 +1665,7 @@ class _ConvBiasAct(Function):
             if _sunk('gw'):
                 gw = None
         return gx, gw, (gb.view(ctx.bias_shape) if want_b and gb is not None else None), None, None, None, None, \
-            None, None, None, None, None, None
+            None, None, None, None, None, None, None, None
 
 
 def _fill_handoff(h, bits, slope, bias_scale, bias):
@@ -2687,7 +2752,7 @@ ACT_DEFERRED = '_ganlab_act_deferred'    # attribute on a conv2d(defer_act_grad=
 
 
 def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0, act=None, slope=0.2, pool=False,
-           blur=False, defer_act_grad=False, in_act_slope=None, in_blur_handoff=None):
+           blur=False, defer_act_grad=False, in_act_slope=None, in_blur_handoff=None, in_rgb_handoff=None):
     """blur?(act(avgpool2?(scale*conv2d(up2?(x), weight, padding)) + bias*bias_scale)) on the matrix cores.
     ``pool``: the D down layer conv -> AvgPool2d(2) -> +bias -> LeakyReLU (progan/architectures.py:261-284)
     as one stride-2 kernel when the shape qualifies, else composed from the plain kernels.
@@ -2712,7 +2777,7 @@ def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0,
             if _lib.lib().ganlab_blur_fused_supported(g.Ho, g.Wo):
                 h = BlurHandoff()
                 y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), ACT_LRELU, float(slope),
-                                       True, False, in_act_slope, h, None)
+                                       True, False, in_act_slope, h, None, None, in_rgb_handoff)
                 if h.bits is not None:      # its only reader may take over this layer's blur^T / LeakyReLU' (fused_sequential)
                     setattr(y, BLUR_HANDOFF, h)
         return y if y is not None else _Blur.apply(conv2d(x, weight, bias, scale, padding, up, bias_scale, act, slope,
@@ -2734,8 +2799,11 @@ def conv2d(x, weight, bias=None, scale=1.0, padding=0, up=False, bias_scale=1.0,
     if in_blur_handoff is not None and pool and in_act_slope is None and in_blur_handoff.bits is not None and \
             conv_s2_blur_ok(g):
         hin = in_blur_handoff
+    rgb = RgbHandoff() if (ks == 1 and a == ACT_LRELU and not up and not pool and cin <= 3) else None
     y = _ConvBiasAct.apply(x, weight, bias, g, float(scale), float(bias_scale), a, float(slope), False, defer,
-                           in_act_slope, None, hin)
+                           in_act_slope, None, hin, rgb, in_rgb_handoff if (ks == 3 and not up and not pool) else None)
+    if rgb is not None and rgb.bits is not None:
+        setattr(y, RGB_HANDOFF, rgb)
     if defer:
         setattr(y, ACT_DEFERRED, True)
     return y

@@ -159,7 +159,11 @@ class _DiscriminatorBody(object):
         return [Lambda(lambda x, group_size: concat_mbstd_layer(x, group_size), group_size=self.mbstd_group_size)]
 
     def forward(self, x):
-        x = x.view(-1, FMAP_SAMPLES + self.num_classes, self.curr_res, self.curr_res)
+        shape = (FMAP_SAMPLES + self.num_classes, self.curr_res, self.curr_res)
+        if x.dim() != 4 or tuple(x.shape[1:]) != shape:
+            # (a batch that already has this shape is taken as is: a view of a leaf is a node of its own, and
+            # ops.no_grad_towards / ops.RgbHandoff recognise the real batch by being that leaf)
+            x = x.view(-1, *shape)
         h = fused_sequential([self.fromrgb], x)
         rest = list(self.disc_blocks)
         if self.fade_in_phase:

@@ -297,7 +297,7 @@ class Conv2dEx(nn.Module):
         return s * (self.lrmul if self.use_lrmul else 1.0)
 
     def forward(self, x, up=False, act=None, slope=0.2, pool=False, bias_mod=None, blur=False, defer_act_grad=False,
-                in_act_slope=None, in_blur_handoff=None):
+                in_act_slope=None, in_blur_handoff=None, in_rgb_handoff=None):
         # (conv(x*wscale) + b) * lrmul  ==  scale*conv(x) + b*lrmul   (custom_layers.py:202-211)
         # pool / bias_mod: the D down layer  conv -> AvgPool2d -> Conv2dBias -> LeakyReLU  as one kernel
         bias, bias_scale = self.conv2d.bias, (self.lrmul if self.use_lrmul else 1.0)
@@ -306,7 +306,8 @@ class Conv2dEx(nn.Module):
             bias, bias_scale = bias_mod.bias, (bias_mod.lrmul if bias_mod.use_lrmul else 1.0)
         return ops.conv2d(x, self.conv2d.weight, bias, scale=self.scale, padding=self.padding, up=up,
                           bias_scale=bias_scale, act=act, slope=slope, pool=pool, blur=blur,
-                          defer_act_grad=defer_act_grad, in_act_slope=in_act_slope, in_blur_handoff=in_blur_handoff)
+                          defer_act_grad=defer_act_grad, in_act_slope=in_act_slope, in_blur_handoff=in_blur_handoff,
+                          in_rgb_handoff=in_rgb_handoff)
 
 
 class Conv2dBias(nn.Module):
@@ -406,9 +407,11 @@ def fused_sequential(mods, x):
     i, n = 0, len(flat)
     pending_slope = None     # the previous conv left its LeakyReLU derivative to the conv that comes next
     blur_handoff = None      # the previous conv -> LeakyReLU -> blur offers its blur^T / LeakyReLU' to the pooled conv behind it
+    rgb_handoff = getattr(x, ops.RGB_HANDOFF, None)     # x is a fromRGB output with this sequence as its only reader
     while i < n:
         m = flat[i]
         handoff, blur_handoff = blur_handoff, None
+        rgb, rgb_handoff = rgb_handoff, None
         up = False
         if isinstance(m, Upsample2x) and i + 1 < n and isinstance(flat[i + 1], Conv2dEx):
             up = True
@@ -449,6 +452,8 @@ def fused_sequential(mods, x):
             if isinstance(m, Conv2dEx):
                 if handoff is not None and 'pool' in kw:
                     kw['in_blur_handoff'] = handoff       # x has this one reader: ops.BlurHandoff
+                if rgb is not None and not up and 'pool' not in kw:
+                    kw['in_rgb_handoff'] = rgb            # ops.RgbHandoff
                 if pending_slope is not None:
                     kw['in_act_slope'] = pending_slope
                 # conv + LeakyReLU feeding the next conv directly (D block k -> block k+1): that conv's dgrad epilogue
@@ -462,6 +467,7 @@ def fused_sequential(mods, x):
             x = m(x, **kw)
             pending_slope = kw['slope'] if getattr(x, ops.ACT_DEFERRED, False) else None
             blur_handoff = getattr(x, ops.BLUR_HANDOFF, None) if kw.get('blur') else None
+            rgb_handoff = getattr(x, ops.RGB_HANDOFF, None)
         else:
             assert pending_slope is None
             x = m(x)

@@ -423,6 +423,16 @@ int ganlab_conv_s2_fwd_blur_tail_f32(const float* x, const float* wp, const floa
 int ganlab_conv_s2_dgrad_blur_act_bits_f32(const float* gy, const float* wp, const unsigned* ybits, float* gz, float* gb,
                                            const ganlab_conv_geom* g, float slope, float bias_scale, void* workspace,
                                            size_t workspace_bytes, void* stream);
+/* The input gradient of the critic's first 3x3 conv (geometry g, thin: csrc/conv_roll_blur.hip) met by the backward of the
+ * fromRGB layer in front of it (1x1 conv of the img_c <= 3 channel image + LeakyReLU, progan/architectures.py:232-237) inside
+ * the kernel, for callers that do not need fromRGB's own input gradient: gz = dgrad(gy, w) * lrelu'(ybits) is never written;
+ * gw_rgb[co][c] = scale * sum gz[co] * img[c], gb_rgb[co] = bias_scale * sum gz[co] (either may be NULL); acc_w / acc_b: add
+ * to what they hold.  wp: what ganlab_conv_dgrad_f32 takes. */
+int ganlab_conv_dgrad_rgb_sums_supported(const ganlab_conv_geom* g, int img_c);
+size_t ganlab_conv_dgrad_rgb_sums_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_dgrad_rgb_sums_f32(const float* gy, const float* wp, const unsigned* ybits, const float* img, float* gw_rgb,
+                                   float* gb_rgb, const ganlab_conv_geom* g, int img_c, float scale, float bias_scale,
+                                   float slope, int acc_w, int acc_b, void* workspace, size_t workspace_bytes, void* stream);
 int ganlab_conv_dgrad_act_bits_f32(const float* gy, const unsigned* ybits, const float* wp, float* gx,
                                    const ganlab_conv_geom* g, float slope, void* stream);
 int ganlab_conv_fwd_mask_bits_f32(const float* x, const float* wp, const unsigned* ybits, float* out,

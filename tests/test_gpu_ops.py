@@ -1219,6 +1219,57 @@ def test_pooled_conv_dgrad_blur_act_fused_kernel_equals_composed(ops, shape, mon
         assert (u - v).abs().max().item() <= 5e-5 * v.abs().max().item(), name
 
 
+@pytest.mark.parametrize('blur', [False, True], ids=['plain first conv', 'first conv + blur'])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 16), (1, 32, 128, 16), (3, 132, 64, 9)], ids=['64x64', '32x128', '132x64, 9 channels'])
+def test_fromrgb_backward_folded_into_first_conv_input_gradient(ops, shape, blur, monkeypatch):
+    """csrc/conv_roll_blur.hip, RB_RGB (ops.RgbHandoff): where nobody needs d / d image, the critic's first 3x3 conv finishes
+    the backward of the fromRGB layer in front of it inside its input-gradient kernel - mask by the sign bits, weight / bias
+    gradient sums against the image, straight into the arena slots - and the gradient tensor between the two layers is never
+    written.  Against the separate kernels: every parameter gradient of both layers, also when a second backward of the
+    same step accumulates on top (the critic sees two batches per step), and the fallback when the image wants its gradient."""
+    from torch import nn
+    from gan_lab_amd.optim import ParamArena
+    n, h, w, c = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr((shape, blur)).encode()))
+    img0, img1 = rnd(gen, n, 3, h, w), rnd(gen, n, 3, h, w)
+    wr, br = nn.Parameter(rnd(gen, c, 3, 1, 1).cuda()), nn.Parameter(rnd(gen, c).cuda())
+    wa, ba = nn.Parameter(rnd(gen, c, c, 3, 3).cuda()), nn.Parameter(rnd(gen, c).cuda())
+    arena = ParamArena([('wr', wr), ('br', br), ('wa', wa), ('ba', ba)])
+    cot = rnd(gen, n, c, h, w).cuda()
+
+    def sweep(img):
+        h0 = ops.conv2d(img, wr, br, scale=0.5, act='lrelu')
+        rgb = getattr(h0, ops.RGB_HANDOFF, None)
+        assert rgb is not None and rgb.bits is not None
+        y = ops.conv2d(h0, wa, ba, scale=0.1, padding=1, act='lrelu', blur=blur, in_rgb_handoff=rgb)
+        with ops.direct_param_grads(True):
+            (y * cot).sum().backward()
+
+    def run(fold, want_img_grad=False):
+        monkeypatch.setenv('GANLAB_RGB_FOLD', '1' if fold else '0')
+        arena.zero_grad()
+        a = img0.cuda().requires_grad_(want_img_grad)
+        sweep(a)
+        first = arena.gflat.clone()
+        sweep(img1.cuda())                 # second batch of the step: accumulates
+        return first, arena.gflat.clone(), (a.grad.clone() if want_img_grad else None)
+    launched = []
+    orig = ops.k_conv_dgrad_rgb_sums
+    monkeypatch.setattr(ops, 'k_conv_dgrad_rgb_sums', lambda *a_, **k_: (launched.append(1), orig(*a_, **k_))[1])
+    f1, f2, _ = run(True)
+    assert len(launched) == 2, 'the folded kernel did not run'
+    u1, u2, _ = run(False)
+    assert len(launched) == 2
+    for name, a_, b_ in (('first backward', f1, u1), ('accumulated', f2, u2)):
+        for k, o, sz in zip(arena.names, arena.offsets, arena.sizes):
+            ref = b_[o:o + sz]
+            assert (a_[o:o + sz] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (name, k)
+    g1, _, gi1 = run(True, want_img_grad=True)       # the image's gradient is wanted: the separate kernels run
+    assert len(launched) == 3 and gi1 is not None     # (only the second sweep - a plain image - folds)
+    g0, _, gi0 = run(False, want_img_grad=True)
+    assert torch.equal(gi1, gi0) and (g1 - g0).abs().max().item() <= 2e-5 * g0.abs().max().item()
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 64, 64, 16), (3, 3, 64, 96, 24)], ids=['3->16 64x64', '3->24 64x96'])
 def test_fromrgb_mask_bits_equal_float_masks(ops, shape, monkeypatch):
     """fromRGB (1x1 conv + LeakyReLU, progan/architectures.py:286-292) with its mask as bits: the forward writes y and
