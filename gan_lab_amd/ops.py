@@ -1565,6 +1565,9 @@ class _ConvBiasAct(Function):
         # epilogue), so backward takes gy as the pre-activation gradient.  in_slope: this conv IS such a consumer.
         ctx.g, ctx.s, ctx.bias_scale, ctx.act, ctx.slope, ctx.blur = g, s, bias_scale, act, slope, blur
         ctx.bias_ref = bias
+        # an undefined incoming gradient stays undefined (RgbHandoff: the reader of a fromRGB layer may have finished this
+        # layer's backward itself and sends nothing; materialised, that would be a 2 GiB tensor of zeros and two passes over it)
+        ctx.set_materialize_grads(False)
         # handoff_out: this is layer A of a BlurHandoff pair (filled in below when the sign bits exist); handoff_in: layer B
         ctx.handoff_out, ctx.handoff_in = None, handoff_in
         ctx.rgb_in = rgb_in         # this conv reads a fromRGB layer's output (RgbHandoff)
@@ -1604,6 +1607,8 @@ class _ConvBiasAct(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 15
         x, w, y = ctx.saved_tensors
         params = _want_param_grads()
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[2] and params

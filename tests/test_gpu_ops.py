@@ -1253,13 +1253,15 @@ def test_fromrgb_backward_folded_into_first_conv_input_gradient(ops, shape, blur
         first = arena.gflat.clone()
         sweep(img1.cuda())                 # second batch of the step: accumulates
         return first, arena.gflat.clone(), (a.grad.clone() if want_img_grad else None)
-    launched = []
-    orig = ops.k_conv_dgrad_rgb_sums
+    launched, separate = [], []
+    orig, orig_w = ops.k_conv_dgrad_rgb_sums, ops.k_conv_wgrad_act
     monkeypatch.setattr(ops, 'k_conv_dgrad_rgb_sums', lambda *a_, **k_: (launched.append(1), orig(*a_, **k_))[1])
+    monkeypatch.setattr(ops, 'k_conv_wgrad_act', lambda *a_, **k_: (separate.append(1), orig_w(*a_, **k_))[1])
     f1, f2, _ = run(True)
     assert len(launched) == 2, 'the folded kernel did not run'
+    assert not separate, "fromRGB's own backward ran as well (on a materialised zero gradient)"
     u1, u2, _ = run(False)
-    assert len(launched) == 2
+    assert len(launched) == 2 and len(separate) == 2
     for name, a_, b_ in (('first backward', f1, u1), ('accumulated', f2, u2)):
         for k, o, sz in zip(arena.names, arena.offsets, arena.sizes):
             ref = b_[o:o + sz]
