@@ -480,14 +480,4 @@ int ganlab_conv_dgrad_rgb_sums_f32(const float* gy, const float* wp, const unsig
   return GL_CHECK_LAUNCH();
 }
 
-// experiment hook (tools/roll_col_bench.py): the plain conv through the column-block layout
-int ganlab_dbg_conv_fwd_roll_col_f32(const float* x, const float* wp, const float* bias, float* y, const ganlab_conv_geom* g,
-                                     float bias_scale, int act, float slope, void* stream) {
-  if (!x || !wp || !y || !g) return GANLAB_EINVAL;
-  if (!ganlab_conv_fwd_blur_supported(g, x, y)) return GANLAB_EUNSUPPORTED;
-  const int cin_p = (g->Cin + 15) / 16 * 16, cout_p = (g->Cout + 63) / 64 * 64;
-  return gl_roll_blur_launch(x, wp, bias, y, nullptr, g->N, g->Cin, g->Cout, g->Hin, g->Win, cin_p, cout_p, bias_scale,
-                             slope, gl_stream(stream), 0, act);
-}
-
 }  // extern "C"

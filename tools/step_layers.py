@@ -74,6 +74,7 @@ def main():
     ops.k_conv_fwd_blur_bits = wrap_opt('fwd+blur', ops.k_conv_fwd_blur_bits, 3)
     ops.k_conv_s2_fwd_blur_tail = wrap('fwd+blur+tail', ops.k_conv_s2_fwd_blur_tail, 7)
     ops.k_conv_s2_dgrad_blur_act = wrap("dgrad+blur+act'", ops.k_conv_s2_dgrad_blur_act, 3)
+    ops.k_conv_dgrad_rgb_sums = wrap('dgrad+fromRGB bwd', ops.k_conv_dgrad_rgb_sums, 3)    # (gz, w, handoff, g, scale)
     torch.cuda.synchronize()
     s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s0.record()
