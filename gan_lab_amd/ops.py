@@ -382,12 +382,21 @@ def _wants_input_grad(ctx, x):
 # ---- parameter gradients written straight into the flat arena ---------------------------------------
 # ``loss.backward()`` hands every parameter gradient to an AccumulateGrad node: one ``grad += g`` launch per parameter and
 # use (~250 per StyleGAN step - a fifth of the launches of the launch-bound configurations).  Inside
-# ``with direct_param_grads():`` (the learners' backward sweeps, single-process runs) the gradient kernels of a parameter
+# ``with direct_param_grads():`` (the learners' backward sweeps) the gradient kernels of a parameter
 # that lives in a ``ParamArena`` write their result INTO its (zeroed) arena slot when it is the first contribution of this
 # step, and the Function returns None for it; later contributions of the same step (the critic is applied to two batches)
 # take the ordinary accumulating path.  Never active while a differentiable backward is being recorded.
 _DIRECT = [False]
 _SINK, _TAKEN = {}, {}
+
+
+def direct_grads_enabled():
+    """A/B knob GANLAB_DIRECT_GRADS=0.  The mechanism is the same with and without data parallelism: the reducer's
+    post-accumulate hooks fire when a parameter's AccumulateGrad node runs - after EVERY contributing Function, direct or not -
+    and a parameter whose Functions never ran (RgbHandoff) simply leaves its bucket to ``GradReducer.start``; the data-parallel
+    code path on one rank (GANLAB_DIST_WORLD1=1) ends bit-identical to the plain one (tools/dist1_probe.py)."""
+    import os
+    return os.environ.get('GANLAB_DIRECT_GRADS') != '0'
 
 
 class direct_param_grads(object):

@@ -248,8 +248,8 @@ class ProGANLearner(GANLearner):
         # when its last gradient has landed (parallel.GradReducer), the rest by start(); the generator forward of the
         # G step runs while they are in flight and _finish_d_update() waits
         self.reducer.arm(self.arena_d)
-        # single process: first-use parameter gradients land in the arena directly (no AccumulateGrad add per parameter)
-        with ops.no_grad_towards(xr), ops.direct_param_grads(parallel.world_size() == 1):
+        # first-use parameter gradients land in the arena directly (no AccumulateGrad add per parameter)
+        with ops.no_grad_towards(xr), ops.direct_param_grads(ops.direct_grads_enabled()):
             loss.backward()            # (no_grad_towards: d loss / d (real batch) is nobody's input - skip that kernel)
         self.reducer.start(self.arena_d.gflat)
         if not defer_update:
@@ -272,7 +272,7 @@ class ProGANLearner(GANLearner):
             self._finish_d_update()
         loss = self.loss_func_gen(self.disc_model(fake))
         self.reducer.arm(self.arena_g)           # buckets go out while the backward is still producing the others
-        with ops.direct_param_grads(parallel.world_size() == 1):
+        with ops.direct_param_grads(ops.direct_grads_enabled()):
             loss.backward()
         self.reducer.start(self.arena_g.gflat)
         self.reducer.finish()                    # Adam needs the averaged gradients; the EWMA follows the update

@@ -202,7 +202,7 @@ class GANLearner(object):
         # :573-578 - the minimax generator loss here is -BCE(D(G(z)), 0), like backprop_utils
         loss = self.loss_func_gen(out)
         self.reducer.arm(self.arena_g)
-        with ops.direct_param_grads(parallel.world_size() == 1):      # first-use gradients land in the arena directly
+        with ops.direct_param_grads(ops.direct_grads_enabled()):      # first-use gradients land in the arena directly
             loss.backward()
         self.reducer.allreduce(self.arena_g.gflat)
         self.opt_gen.step()
@@ -222,7 +222,7 @@ class GANLearner(object):
         if self.gradient_penalty is not None:
             loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
         self.reducer.arm(self.arena_d)
-        with ops.direct_param_grads(parallel.world_size() == 1):
+        with ops.direct_param_grads(ops.direct_grads_enabled()):
             loss.backward()
         self.reducer.allreduce(self.arena_d.gflat)
         self.opt_disc.step()
