@@ -68,6 +68,9 @@ SIGNATURES = {
     'ganlab_conv_pack_bf16': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_conv_fwd_bf16': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_bf16_splitk_plan': (_c_int, [_GP, _c_int]),
+    'ganlab_conv_fwd_bf16_splitk': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_dgrad_bf16_splitk': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p, _c_sz, _c_p]),
     'ganlab_conv_wgrad_bf16_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_bf16': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_mask_bits_supported': (_c_int, [_c_int, _c_int]),

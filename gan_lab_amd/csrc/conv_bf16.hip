@@ -80,6 +80,11 @@ struct BfArgs {
   int tiles_x, tiles_y, tiles_co;   // H, W: the resolution the 3x3 taps run at (2x the input's with UP, 2x the output's with POOL)
   float bias_scale, slope, oscale;  // y = act(oscale * (pooled) conv + bias * bias_scale)
   int act;
+  // split-K (few output tiles, long contraction: the 512-channel 16x16 layers at batch 8 are 64 workgroups): workgroup
+  // (tile, ks) contracts chunks [ks * ks_chunks, ..) and writes its raw accumulators at the taps' resolution to
+  // part[ks][n][co][H][W]; bf16_splitk_finish_kernel adds them in a fixed order, pools, scales, adds the bias, activates
+  int ksplit, ks_chunks;
+  float* part;
 };
 
 // ---- forward / input-gradient kernel ---------------------------------------------------------------------------
@@ -107,6 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int l16 = lane & 15, kgl = lane >> 4;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int ks = p.ksplit > 1 ? bid % p.ksplit : 0;
+  if (p.ksplit > 1) bid /= p.ksplit;
   const int co_t = bid % p.tiles_co;
   bid /= p.tiles_co;
   const int txi = bid % p.tiles_x;
@@ -190,9 +197,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
     bbase[nb] = (kgl * PR + (4 * wn + nb) / COLB) * PC + 16 * ((4 * wn + nb) % COLB) + l16 + 3;
   const int abase = kgl * COT + l16;
 
-  const int nchunks = p.CI / CK;
-  load_chunk(0);
-  for (int c = 0; c < nchunks; ++c) {
+  const int c_first = ks * p.ks_chunks;
+  const int nchunks = p.ksplit > 1 ? min(p.CI / CK, c_first + p.ks_chunks) : p.CI / CK;
+  load_chunk(c_first);
+  for (int c = c_first; c < nchunks; ++c) {
     store_chunk();
     __syncthreads();
     if (c + 1 < nchunks) load_chunk(c + 1);
@@ -213,6 +221,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
     __syncthreads();
   }
 
+  if (p.ksplit > 1) {      // raw partial sums at the taps' resolution; the finish kernel does the rest
+    const int oplane = p.H * p.W;
+    float* yb = p.part + ((long long)ks * p.N + n) * p.CO * oplane;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mb * 16 + kgl * 4 + r;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int oy = oy0 + (4 * wn + nb) / COLB, ox = ox0 + 16 * ((4 * wn + nb) % COLB) + l16;
+          yb[(long long)co * oplane + oy * p.W + ox] = acc[mb][nb][r];
+        }
+      }
+    return;
+  }
   // epilogue: lane holds channels co0 + 16mb + 4kgl + r of pixel (row, col); 16 lanes -> 64 contiguous bytes
   if constexpr (!POOL) {
     const int oplane = p.H * p.W;
@@ -255,6 +279,34 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(BfArgs p) {
         }
       }
   }
+}
+
+// y = act(oscale * pool?(sum_s part[s]) + bias * bias_scale): finishes a split-K launch (fixed summation order)
+__global__ void bf16_splitk_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                          int S, int N, int CO, int H, int W, int pool, float oscale, float bias_scale,
+                                          int act, float slope) {
+  const int oH = pool ? H >> 1 : H, oW = pool ? W >> 1 : W;
+  const long long total = (long long)N * CO * oH * oW, splane = (long long)N * CO * H * W;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % oW);
+  long long t = i / oW;
+  const int oy = (int)(t % oH);
+  t /= oH;                                   // n * CO + co
+  const int co = (int)(t % CO);
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* ps = part + s * splane + t * H * W;
+    if (pool) {
+      const float* q = ps + (2 * oy) * W + 2 * ox;
+      v += (q[0] + q[1]) + (q[W] + q[W + 1]);
+    } else {
+      v += ps[oy * W + ox];
+    }
+  }
+  v = v * oscale + (bias != nullptr ? bias[co] * bias_scale : 0.f);
+  if (act == GANLAB_ACT_LRELU) v = gl_lrelu(v, slope);
+  y[i] = v;
 }
 
 // ---- weight-gradient kernel --------------------------------------------------------------------------------------
@@ -810,15 +862,31 @@ long long ganlab_conv_pack_bf16(const float* w, void* out, int Cout, int Cin, in
 }
 
 // mode 0: plain; 1: UP (x is H/2 x W/2); 2: POOL (y is H/2 x W/2).  H, W: the resolution of the 3x3 taps.
+// Split factor of a forward / input-gradient launch at the taps' resolution H x W: only where the plain launch leaves most
+// of the 256 CUs idle, at least four 32-channel chunks per workgroup.
+static int bf16_splitk_plan(int N, int CI, int CO, int H, int W) {
+  const bool wide = W % 32 == 0 && H % 8 == 0;
+  const long long tiles = (long long)N * (wide ? (W / 32) * (H / 8) : (W / 16) * (H / 16)) * (CO / COT);
+  const int chunks = CI / CK;
+  if (tiles >= 128 || chunks < 8) return 1;
+  int S = (int)((256 + tiles - 1) / tiles);
+  if (S > 4) S = 4;
+  while (S > 1 && chunks / S < 4) --S;
+  return S < 2 ? 1 : S;
+}
+
 static int launch_fwd(const float* x, const void* wp, const float* bias, float* y, int N, int CI, int CO, int H, int W,
-                      float bias_scale, int act, float slope, int mode, float oscale, void* stream) {
+                      float bias_scale, int act, float slope, int mode, float oscale, void* stream, float* part = nullptr,
+                      int ksplit = 1) {
   BfArgs a;
+  a.ksplit = ksplit; a.part = part;
+  a.ks_chunks = ksplit > 1 ? (CI / CK + ksplit - 1) / ksplit : 0;
   a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp); a.bias = bias; a.y = y;
   a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
   const bool wide = W % 32 == 0 && H % 8 == 0;
   a.tiles_x = wide ? W / 32 : W / 16; a.tiles_y = wide ? H / 8 : H / 16; a.tiles_co = CO / COT;
   a.bias_scale = bias_scale; a.slope = slope; a.act = act; a.oscale = oscale;
-  const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
+  const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co * (ksplit > 1 ? ksplit : 1);
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
   const dim3 gd((unsigned)grid), bd(256);
   hipStream_t st = gl_stream(stream);
@@ -831,6 +899,12 @@ static int launch_fwd(const float* x, const void* wp, const float* bias, float* 
     else if (mode == 2) GL_LAUNCH((conv_fwd_bf16_kernel<16, 16, false, true>), gd, bd, 0, st, a);
     else GL_LAUNCH((conv_fwd_bf16_kernel<16, 16>), gd, bd, 0, st, a);
   }
+  if (ksplit > 1) {
+    const int pool = mode == 2;
+    const long long total = (long long)N * CO * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    GL_LAUNCH(bf16_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, bias, y,
+              ksplit, N, CO, H, W, pool, oscale, bias_scale, act, slope);
+  }
   return GL_CHECK_LAUNCH();
 }
 
@@ -841,6 +915,44 @@ int ganlab_conv_fwd_bf16(const float* x, const void* wp, const float* bias, floa
   const int m = g->up ? 2 : 1;        // conv(up2 x): UP; pool2(conv x): POOL with the 1/4 of the average
   return launch_fwd(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin * m, g->Win * m, bias_scale, act, slope,
                     g->up ? 1 : (g->pool ? 2 : 0), g->pool ? 0.25f : 1.f, stream);
+}
+
+/* split-K forms for layers with few output tiles (the 512-channel 16x16 layers at small batch): plan = number of K-splits
+ * (1: use the plain entry point), workspace = plan * N * Cout_of_the_operator * H * W floats at the taps' resolution */
+int ganlab_conv_bf16_splitk_plan(const ganlab_conv_geom* g, int dgrad) {
+  if (g == nullptr || !bf16_ok(g)) return 1;
+  const int m = g->up ? 2 : 1;
+  const char* e = getenv("GANLAB_BF16_SPLITK");
+  if (e != nullptr && e[0] == '0') return 1;
+  return dgrad ? bf16_splitk_plan(g->N, g->Cout, g->Cin, g->Hin * m, g->Win * m)
+               : bf16_splitk_plan(g->N, g->Cin, g->Cout, g->Hin * m, g->Win * m);
+}
+
+int ganlab_conv_fwd_bf16_splitk(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                                float bias_scale, int act, float slope, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (x == nullptr || wp == nullptr || y == nullptr || g == nullptr) return GANLAB_EINVAL;
+  if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
+  const int S = ganlab_conv_bf16_splitk_plan(g, 0);
+  const int m = g->up ? 2 : 1;
+  if (S < 2) return ganlab_conv_fwd_bf16(x, wp, bias, y, g, bias_scale, act, slope, stream);
+  if (workspace == nullptr || workspace_bytes < (size_t)S * g->N * g->Cout * g->Hin * m * g->Win * m * sizeof(float))
+    return GANLAB_EWORKSPACE;
+  return launch_fwd(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin * m, g->Win * m, bias_scale, act, slope,
+                    g->up ? 1 : (g->pool ? 2 : 0), g->pool ? 0.25f : 1.f, stream, reinterpret_cast<float*>(workspace), S);
+}
+
+int ganlab_conv_dgrad_bf16_splitk(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (gy == nullptr || wp == nullptr || gx == nullptr || g == nullptr) return GANLAB_EINVAL;
+  if (!bf16_ok(g)) return GANLAB_EUNSUPPORTED;
+  const int S = ganlab_conv_bf16_splitk_plan(g, 1);
+  const int m = g->up ? 2 : 1;
+  if (S < 2) return ganlab_conv_dgrad_bf16(gy, wp, gx, g, stream);
+  if (workspace == nullptr || workspace_bytes < (size_t)S * g->N * g->Cin * g->Hin * m * g->Win * m * sizeof(float))
+    return GANLAB_EWORKSPACE;
+  return launch_fwd(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin * m, g->Win * m, 0.f, GANLAB_ACT_NONE, 0.f,
+                    g->up ? 2 : (g->pool ? 1 : 0), g->pool ? 0.25f : 1.f, stream, reinterpret_cast<float*>(workspace), S);
 }
 
 int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream) {

@@ -494,8 +494,16 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         geom = g.bf_fused if g.bf_fused is not None else g.bf
         xin = k_up2(x, 1.0) if (g.up and g.bf_fused is None) else x
         wp = _packed_bf16(w, PACK_FWD, scale)
-        check(_lib.lib().ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(geom), bias_scale,
-                                              act, slope, _st()), 'conv_fwd_bf16')
+        L = _lib.lib()
+        split = L.ganlab_conv_bf16_splitk_plan(ctypes.byref(geom), 0)
+        if split >= 2:     # few output tiles, long contraction (512-channel 16x16 layers at small batch)
+            m = 2 if geom.up else 1
+            ws = torch.empty((split * geom.N * geom.Cout * geom.Hin * m * geom.Win * m,), dtype=torch.float32, device=x.device)
+            check(L.ganlab_conv_fwd_bf16_splitk(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(geom), bias_scale, act,
+                                                slope, _p(ws), ws.numel() * 4, _st()), 'conv_fwd_bf16_splitk')
+            return y
+        check(L.ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(geom), bias_scale,
+                                     act, slope, _st()), 'conv_fwd_bf16')
         return y
     if g.s2:   # stride-2 fused layer: conv+avgpool (S kernel) or upsample+conv (T kernel)
         wp = _packed(w, PACK_FWD, scale, s2_up=g.up)
@@ -534,14 +542,22 @@ def k_conv_dgrad(gy, w, g, scale):
     _note('dgrad', g)
     if g.bf is not None:
         wp = _packed_bf16(w, PACK_DGRAD, scale)
+        L = _lib.lib()
+
+        def run(geom, out):
+            split = L.ganlab_conv_bf16_splitk_plan(ctypes.byref(geom), 1)
+            if split >= 2:
+                m = 2 if geom.up else 1
+                ws = torch.empty((split * geom.N * geom.Cin * geom.Hin * m * geom.Win * m,), dtype=torch.float32,
+                                 device=gy.device)
+                check(L.ganlab_conv_dgrad_bf16_splitk(_p(gy), wp.data_ptr(), _p(out), ctypes.byref(geom), _p(ws),
+                                                      ws.numel() * 4, _st()), 'conv_dgrad_bf16_splitk')
+            else:
+                check(L.ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(out), ctypes.byref(geom), _st()), 'conv_dgrad_bf16')
+            return out
         if g.bf_fused is not None:     # the adjoint of the upsample (2 x 2 sum) / of the pool (upsample / 4) is in the kernel
-            gx = _new(g.in_shape, gy)
-            check(_lib.lib().ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(gx), ctypes.byref(g.bf_fused), _st()),
-                  'conv_dgrad_bf16')
-            return gx
-        gxv = _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy)
-        check(_lib.lib().ganlab_conv_dgrad_bf16(_p(gy), wp.data_ptr(), _p(gxv), ctypes.byref(g.bf), _st()),
-              'conv_dgrad_bf16')
+            return run(g.bf_fused, _new(g.in_shape, gy))
+        gxv = run(g.bf, _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy))
         return k_pool2(gxv, 1.0) if g.up else gxv
     if g.s2:
         wp = _packed(w, PACK_DGRAD, scale, s2_up=g.up)

@@ -160,6 +160,15 @@ long long ganlab_conv_pack_bf16(const float* w, void* out, int Cout, int Cin, in
 int ganlab_conv_fwd_bf16(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
                          float bias_scale, int act, float slope, void* stream);
 int ganlab_conv_dgrad_bf16(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+/* split-K forms of the two for layers with few output tiles (the 512-channel 16x16 layers at batch 8: 64 workgroups on 256
+ * CUs): ganlab_conv_bf16_splitk_plan = number of K-splits S (1: nothing to split); workspace: S * N * C * H * W floats at the
+ * taps' resolution (C: the operator's output channels), raw partial sums + a fixed-order finish (pool / scale / bias / act) */
+int ganlab_conv_bf16_splitk_plan(const ganlab_conv_geom* g, int dgrad);
+int ganlab_conv_fwd_bf16_splitk(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                                float bias_scale, int act, float slope, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int ganlab_conv_dgrad_bf16_splitk(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g);
 int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
                            void* workspace, size_t workspace_bytes, void* stream);

@@ -45,6 +45,9 @@ CASES = [
     (3, 128, 16, 16, 64, False, True, 'lrelu'),   # 16-wide maps: 16 x 16 pixel tiles; the weight gradient stays fp32
     (2, 64, 32, 48, 128, False, False, None),     # width a multiple of 16 only
     (3, 128, 12, 48, 64, True, True, 'lrelu'),    # upsample folded in: taps at 24 x 96 (3 strips, one 24-row segment)
+    (2, 256, 16, 16, 128, False, True, 'lrelu'),  # 4 output tiles, 8 K chunks: split-K (2 splits) forward and input gradient
+    (1, 512, 16, 16, 64, False, False, None),     # 1 tile, 16 chunks: 4 splits
+    (2, 384, 8, 8, 128, True, True, 'lrelu'),     # split-K behind the folded upsample (taps at 16 x 16), 12 chunks: 3 splits
 ]
 
 
@@ -115,7 +118,7 @@ def test_bf16_mode_leaves_unsupported_shapes_exact(ops):
 
 
 POOL_CASES = [(2, 64, 16, 64, 128, True, 'lrelu'), (3, 128, 32, 32, 64, False, None), (2, 64, 32, 16, 64, True, 'lrelu'),
-              (3, 64, 24, 96, 128, True, None)]
+              (3, 64, 24, 96, 128, True, None), (2, 256, 16, 16, 128, True, 'lrelu')]     # last: split-K, pooled in the finish
 
 
 @pytest.mark.parametrize('case', POOL_CASES, ids=[str(c) for c in POOL_CASES])
