@@ -99,6 +99,9 @@ SIGNATURES = {
     'ganlab_in_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     'ganlab_conv_aff_supported': (_c_int, [_GP]),
     'ganlab_conv_fwd_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_fwd_aff_tail_chunks': (_c_int, [_GP]),
+    'ganlab_conv_fwd_aff_tail_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f,
+                                              _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_wgrad_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_s2_aff_supported': (_c_int, [_GP]),
     'ganlab_conv_s2_fwd_aff_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),

@@ -357,6 +357,11 @@ struct ConvArgs {
   // [ks * ksplit_ci, (ks + 1) * ksplit_ci) and writes its raw partial sums to y + ks * ksplit_stride
   int ksplit, ksplit_ci;
   long long ksplit_stride;
+  // TAIL (AFF tile kernels as a whole generator layer, ganlab_conv_fwd_aff_tail_f32): y = act(conv + noise_w[c] * noise[n,hw]
+  // + bias) and the partial sums of y and y^2 of this workgroup's tile per (n, c): spart[(n*Cout + c)*chunks + tile][2]
+  const float* noise;
+  const float* noise_w;
+  double* spart;
 };
 
 template <int KS_, int MB_, int TWL_, int THL_, int NIL_, int XMODE_>
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_k
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
 constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the AFF kernels keep in LDS
-template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false>
+template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
@@ -1062,6 +1067,76 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
           if (!(m.w > 0.f)) acc[mb][nb][3] *= p.mslope;
         }
     }
+  }
+  if constexpr (TAIL) {
+    // the rest of a generator layer in the epilogue (stylegan/architectures.py:497-526): + noise_w * noise + bias,
+    // LeakyReLU, store, and the tile's share of the InstanceNorm statistics of the result (fp32 over this lane's <= 4*NB
+    // pixels, fp64 from there on: lane groups, waves, then the fixed-order finish over the tiles)
+    static_assert(!TAIL || (G::XMODE == XVEC && G::NI == 1), "TAIL: vector staging, one image per tile");
+    float nwv[MB], s1[MB], s2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int co = co0 + mb * 16 + (lane & 15);
+      nwv[mb] = (p.noise != nullptr && co < p.Cout) ? p.noise_w[co] : 0.f;
+      s1[mb] = 0.f;
+      s2[mb] = 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int j0 = wn * (16 * NB) + nb * 16 + (lane >> 4) * 4;
+      const int oy = oy0 + ((j0 >> G::TWL) & (TH - 1)), ox = ox0 + (j0 & (TW - 1));
+      const bool in = oy < p.Ho && ox < p.Wo;
+      float4 nz = float4{0.f, 0.f, 0.f, 0.f};
+      if (p.noise != nullptr && in) nz = *reinterpret_cast<const float4*>(p.noise + ((long long)n0 * p.Ho + oy) * p.Wo + ox);
+      const float nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int co = co0 + mb * 16 + (lane & 15);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(nzv[r], nwv[mb], acc[mb][nb][r] + bv[mb]);
+          if (p.act == GANLAB_ACT_LRELU) v[r] = gl_lrelu(v[r], p.slope);
+        }
+        if (in && co < p.Cout) {
+          *reinterpret_cast<float4*>(p.y + ((long long)n0 * p.Cout + co) * out_plane + (long long)oy * p.Wo + ox) =
+              float4{v[0], v[1], v[2], v[3]};
+          s1[mb] += (v[0] + v[1]) + (v[2] + v[3]);
+          s2[mb] += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+        }
+      }
+    }
+    __syncthreads();                         // the operand tiles are dead: their memory takes the waves' partial sums
+    double* red = reinterpret_cast<double*>(smem);       // [wave 4][MB * 16][2]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      double a = (double)s1[mb], b = (double)s2[mb];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if ((lane >> 4) == 0) {
+        red[((wn * MB + mb) * 16 + lane) * 2] = a;
+        red[((wn * MB + mb) * 16 + lane) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < MB * 16) {
+      const int co = co0 + tid;
+      if (co < p.Cout && p.spart != nullptr) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          a += red[((w4 * MB) * 16 + tid) * 2];
+          b += red[((w4 * MB) * 16 + tid) * 2 + 1];
+        }
+        const long long chunks = (long long)p.tiles_x * p.tiles_y, tile = (long long)tyi * p.tiles_x + txi;
+        double* dst = p.spart + (((long long)n0 * p.Cout + co) * chunks + tile) * 2;
+        dst[0] = a;
+        dst[1] = b;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -2161,6 +2236,75 @@ int ganlab_conv_fwd_aff_f32(const float* x, const float* wp, const float* aff_s,
     if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
     GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
   }
+  return GL_CHECK_LAUNCH();
+}
+
+// mean / rstd of every plane from the tile partials (fixed order, fp64)
+__global__ void conv_tail_stats_finish_kernel(const double* __restrict__ spart, float* __restrict__ mean,
+                                              float* __restrict__ rstd, long long planes, int chunks, double inv_hw, float eps) {
+  const long long pl = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pl >= planes) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += spart[(pl * chunks + k) * 2];
+    ss += spart[(pl * chunks + k) * 2 + 1];
+  }
+  const double m = s * inv_hw;
+  double var = ss * inv_hw - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[pl] = (float)m;
+  rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+/* statistics tiles per (n, c) plane ganlab_conv_fwd_aff_tail_f32 writes (workspace: N * Cout * tiles * 2 doubles); 0 = not
+ * a geometry that form takes */
+int ganlab_conv_fwd_aff_tail_chunks(const ganlab_conv_geom* g) {
+  if (!(ganlab_conv_aff_supported(g) & 1) || (g->Win % 32) != 0 || (g->Hin % 8) != 0) return 0;
+  const char* e = getenv("GANLAB_CONV_TAIL");
+  if (e != nullptr && e[0] == '0') return 0;
+  return (g->Win / 32) * (g->Hin / 8);
+}
+
+/* A plain 3x3 generator layer with a deferred-InstanceNorm input in ONE pass over the activations, thicker than the rolling
+ * ganlab_mod_conv_fwd_f32 takes (stylegan/architectures.py:497-526): y = act(conv(x * aff_s + aff_t, w) + noise_w * noise +
+ * bias * bias_scale); mean / rstd: the InstanceNorm statistics of y, from the tiles' partial sums. */
+int ganlab_conv_fwd_aff_tail_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                                 const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
+                                 const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  const int chunks = ganlab_conv_fwd_aff_tail_chunks(g);
+  if (chunks <= 0) return GANLAB_EUNSUPPORTED;
+  if (!x || !wp || !y || !aff_s || !aff_t || !mean || !rstd || (noise && !noise_w) || !aligned16(x) || !aligned16(wp) ||
+      !aligned16(y) || (noise && !aligned16(noise)))
+    return GANLAB_EINVAL;
+  const long long planes = (long long)g->N * g->Cout;
+  if (!workspace || workspace_bytes < (size_t)planes * chunks * 2 * sizeof(double)) return GANLAB_EWORKSPACE;
+  ConvArgs a{};
+  a.in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, 0);
+  a.in.aff_s = aff_s; a.in.aff_t = aff_t;
+  a.wp = wp; a.bias = bias; a.y = y;
+  a.Cout = g->Cout; a.Ho = g->Hin; a.Wo = g->Win;
+  a.Cin_p = round_up_c(g->Cin, cin_pad(3)); a.Cout_p = round_up_c(g->Cout, 64);
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  a.ksplit = 1;
+  a.noise = noise; a.noise_w = noise_w; a.spart = reinterpret_cast<double*>(workspace);
+  a.tiles_x = a.Wo / 32; a.tiles_y = a.Ho / 8; a.tiles_n = g->N;
+  hipStream_t st = gl_stream(stream);
+  if (g->Cout <= 32) {
+    using Cfg = FwdCfg<3, 2, 5, 3, 0, XVEC>;
+    a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+    GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  } else {
+    using Cfg = FwdCfg<3, 4, 5, 3, 0, XVEC>;
+    a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
+    GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  }
+  GL_LAUNCH(conv_tail_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, st, (const double*)a.spart,
+            mean, rstd, planes, chunks, 1.0 / ((double)g->Hin * g->Win), eps);
   return GL_CHECK_LAUNCH();
 }
 

@@ -2058,8 +2058,26 @@ def mod_conv_shape_ok(shape, weight, padding=1):
     return hit
 
 
+def conv_tail_shape_ok(shape, weight, padding=1):
+    """The same one-pass layer on the tile kernels (thicker layers): affine on load, noise + bias + LeakyReLU + statistics in
+    the conv's epilogue - where the affine-on-load forward AND weight gradient take the geometry."""
+    if get_compute_dtype() != 'f32' or padding != 1:
+        return False
+    key = ('tail', tuple(int(v) for v in shape), tuple(weight.shape))
+    hit = _AFF_OK.get(key)
+    if hit is None:
+        n, cin, h, w = key[1]
+        hit = False
+        if tuple(weight.shape[1:]) == (cin, 3, 3) and conv_aff_ok(shape, weight, False, padding):
+            g = ConvGeom(n, cin, h, w, int(weight.shape[0]), 3, 1, 0, 0)
+            hit = _lib.lib().ganlab_conv_fwd_aff_tail_chunks(ctypes.byref(g)) > 0
+        _AFF_OK[key] = hit
+    return hit
+
+
 def mod_conv_ok(d, weight, padding=1):
-    return isinstance(d, Deferred) and mod_conv_shape_ok(d.a.shape, weight, padding)
+    return isinstance(d, Deferred) and (mod_conv_shape_ok(d.a.shape, weight, padding) or
+                                        conv_tail_shape_ok(d.a.shape, weight, padding))
 
 
 def conv_aff_ok(shape, weight, up=False, padding=1):
@@ -2178,11 +2196,18 @@ class _ConvModTail(Function):
         noise = _c(noise) if noise is not None else None
         y = _new((n, cout, h, wd), a_in)
         mean, rstd = _new((n, cout), a_in), _new((n, cout), a_in)
-        chunks = L.ganlab_mod_conv_stat_chunks(g.ref())
-        ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
-        check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wp), _p(s_in), _p(t_in), _p(bias), _p(noise), _p(noise_w), _p(y),
-                                        _p(mean), _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws), ws.numel() * 8,
-                                        _st()), 'mod_conv_fwd')
+        if mod_conv_shape_ok(a_in.shape, w):       # thin layer: the rolling-window kernel
+            chunks = L.ganlab_mod_conv_stat_chunks(g.ref())
+            ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
+            check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wp), _p(s_in), _p(t_in), _p(bias), _p(noise), _p(noise_w), _p(y),
+                                            _p(mean), _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws), ws.numel() * 8,
+                                            _st()), 'mod_conv_fwd')
+        else:                                      # thicker layers: the tile kernels' TAIL epilogue
+            chunks = L.ganlab_conv_fwd_aff_tail_chunks(g.ref())
+            ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
+            check(L.ganlab_conv_fwd_aff_tail_f32(_p(a_in), _p(wp), _p(s_in), _p(t_in), _p(bias), _p(noise), _p(noise_w), _p(y),
+                                                 _p(mean), _p(rstd), g.ref(), bias_scale, act, slope, eps, _p(ws),
+                                                 ws.numel() * 8, _st()), 'conv_fwd_aff_tail')
         style_c = _c(style) if style is not None else None
         s_, t_ = _affine_from_stats(mean, rstd, style_c, n, cout)
         ctx.save_for_backward(a_in, s_in, t_in, w, y, mean, rstd, style_c, noise)

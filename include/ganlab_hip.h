@@ -489,6 +489,15 @@ int ganlab_conv_aff_supported(const ganlab_conv_geom* g);
 int ganlab_conv_fwd_aff_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
                             float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
 /* ganlab_conv_wgrad_f32 with b = a*s + t as the x operand (workspace: ganlab_conv_wgrad_workspace) */
+/* The same layer one size up: a plain 3x3 generator layer (Cout > 16, W % 32 == 0, H % 8 == 0) with a deferred-InstanceNorm
+ * input and its whole tail in the conv kernel's epilogue (stylegan/architectures.py:497-526): y = act(conv(x * aff_s + aff_t, w)
+ * + noise_w * noise + bias * bias_scale), mean / rstd = InstanceNorm statistics of y.  ganlab_conv_fwd_aff_tail_chunks: tiles
+ * per plane (workspace: N * Cout * tiles * 2 doubles), 0 where the form does not apply. */
+int ganlab_conv_fwd_aff_tail_chunks(const ganlab_conv_geom* g);
+int ganlab_conv_fwd_aff_tail_f32(const float* x, const float* wp, const float* aff_s, const float* aff_t, const float* bias,
+                                 const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
+                                 const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 int ganlab_conv_wgrad_aff_f32(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
                               const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes, void* stream);
 /* Upsample + conv3x3 (up = 1) with a deferred low-resolution input: bit 0 = forward, bit 1 = weight gradient */

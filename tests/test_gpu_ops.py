@@ -1147,6 +1147,39 @@ def test_conv_lrelu_blur_fused_kernel_equals_composed(ops, shape, monkeypatch):
     assert (pre.reshape(-1).numpy()[bad].__abs__() < 1e-5).all() and bad.mean() < 1e-4, int(bad.sum())
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 32, 32, 64), (1, 48, 80, 16, 96), (2, 64, 64, 8, 32), (3, 17, 24, 24, 64)],
+                         ids=['32->32 32x64', '48->80 16x96', '64->64 8x32', '17->24 24x64'])
+def test_conv_aff_tail_epilogue_equals_composed(ops, shape):
+    """conv.hip, TAIL epilogue of the affine-on-load tile kernels: a plain 3x3 generator layer with a deferred-InstanceNorm
+    input - conv, + noise, + bias, LeakyReLU and the InstanceNorm statistics of the result (stylegan/architectures.py:497-526)
+    - in ONE kernel, against the composed form (affine-on-load conv kernel, then the bias / noise / act / statistics pass):
+    activation, the (s, t) of the deferred output, and every gradient of a loss on the normalised output."""
+    n, cin, cout, h, w = shape
+    gen = torch.Generator().manual_seed(zlib.crc32(repr(shape).encode()) + 7)
+    x0, w0 = rnd(gen, n, cin, h, w), rnd(gen, cout, cin, 3, 3)
+    b0, nw0, st0 = rnd(gen, 1, cout, 1, 1), rnd(gen, 1, cout, 1, 1), rnd(gen, n, 2 * cout)
+    nz = rnd(gen, n, 1, h, w).cuda()
+    s_in, t_in = (rnd(gen, n, cin) * 0.5 + 1).cuda(), rnd(gen, n, cin).cuda()
+    cot = rnd(gen, n, cout, h, w).cuda()
+    assert ops.conv_tail_shape_ok((n, cin, h, w), w0) and not ops.mod_conv_shape_ok((n, cin, h, w), w0)
+
+    def run(fused):
+        x, wt = x0.cuda().requires_grad_(True), w0.cuda().requires_grad_(True)
+        b, nw, st = (t_.cuda().requires_grad_(True) for t_ in (b0, nw0, st0))
+        src = ops.Deferred(x, s_in, t_in, None, None, None)
+        if fused:
+            d = ops.conv_mod_tail(src, wt, 0.06, b, nz, nw, st, bias_scale=1.0, act='lrelu', slope=0.2, eps=1e-8)
+        else:
+            c = ops.conv_aff(src, wt, 0.06, up=False)
+            d = ops.layer_tail_deferred(c, b, nz, nw, st, bias_scale=1.0, act='lrelu', slope=0.2, blur=False, eps=1e-8)
+        out = ops.materialize(d)
+        (out * cot).sum().backward()
+        return [t_.detach() for t_ in (d.a, d.s, d.t, out, x.grad, wt.grad, b.grad, nw.grad, st.grad)]
+    a, b_ = run(True), run(False)
+    for name, u, v in zip(['a', 's', 't', 'normalised output', 'gx', 'gw', 'gbias', 'gnoise_w', 'gstyle'], a, b_):
+        assert (u - v).abs().max().item() <= 5e-5 * v.abs().max().item(), name
+
+
 S2_BLUR_CASES = [(2, 32, 16, 16, 32), (1, 24, 9, 6, 64), (2, 32, 16, 128, 32), (1, 17, 16, 4, 96)]
 S2_BLUR_IDS = ['32->16 16x32', '24->9 6x64', 'row strips 128x32', '17->16 two steps 4x96']
 
