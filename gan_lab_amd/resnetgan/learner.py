@@ -208,6 +208,18 @@ class GANLearner(object):
         self.opt_gen.step()
         return loss.detach()
 
+    def _pair_critic_batches(self, xgenb, xb):
+        """May the critic see the generated and the real batch as one?  Only when no critic layer couples samples (a
+        BatchNorm would take its statistics over both) and the output is the plain score.  GANLAB_RESNET_PAIR=0: A/B."""
+        if os.environ.get('GANLAB_RESNET_PAIR') == '0' or xgenb.numel() != xb.numel():
+            return False
+        key, ok = getattr(self, '_pairable', (None, False))
+        if key != id(self.disc_model):
+            ok = not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in self.disc_model.modules()) and \
+                not hasattr(self.disc_model, 'linear_aux')
+            self._pairable = (id(self.disc_model), ok)
+        return ok
+
     def d_step(self, xb, zb=None, eps_interp=None):
         """resnetgan/learner.py:606-672: generator frozen but in train mode (its BatchNorm running
         statistics keep moving, :621-622); no drift term on this path."""
@@ -218,7 +230,15 @@ class GANLearner(object):
                                       distribution=self.latent_distribution, device=c.dev)
         with torch.no_grad():
             xgenb = self.gen_model(zb)
-        loss = self.loss_func_disc(self.disc_model(xgenb), self.disc_model(xb))
+        if self._pair_critic_batches(xgenb, xb):
+            # one critic pass over [generated; real]: every critic layer is per-sample (LayerNorm), so the outputs are the
+            # two separate passes' (resnetgan/learner.py:640-651) and each parameter gets ONE gradient contribution from
+            # the pair instead of two - half the launches of the first-order critic work at this launch-bound size
+            n = xgenb.shape[0]
+            out = self.disc_model(torch.cat((xgenb, xb.view_as(xgenb))))
+            loss = self.loss_func_disc(out[:n], out[n:])
+        else:
+            loss = self.loss_func_disc(self.disc_model(xgenb), self.disc_model(xb))
         if self.gradient_penalty is not None:
             loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)
         self.reducer.arm(self.arena_d)

@@ -252,6 +252,48 @@ def test_resnet_training_iterations_match_reference(res):
     assert n_checked > 1000
 
 
+@pytest.mark.parametrize('res', [32, 64])
+def test_resnet_paired_critic_pass_equals_two_passes(res, monkeypatch):
+    """The critic iteration scores [generated; real] in ONE pass (every critic layer is per-sample); the loss, every
+    critic gradient and the update equal those of the reference's two passes (resnetgan/learner.py:640-651) up to the
+    order of the weight-gradient sums."""
+    G = load_golden(f'resnet{res}.npz')
+    out = {}
+    for pair in ('0', '1'):
+        monkeypatch.setenv('GANLAB_RESNET_PAIR', pair)
+        cfg, Learner = make_learner(res, len_latent=int(G['len_latent']), lr_base=float(G['lr']))
+        cfg.fmap_g, cfg.fmap_d = int(G['fmap_g']), int(G['fmap_d'])
+        L = Learner(cfg)
+        L.gen_model.load_state_dict(sub(G, 'g0.'))
+        L.disc_model.load_state_dict(sub(G, 'd0.'))
+        L.gen_model.train()
+        L.disc_model.train()
+        L.set_requires_grad_disc(True)
+        p = 'i0.d0.'
+        real, zd, eps = t(G[p + 'real']).cuda(), t(G[p + 'zd']).cuda(), t(G[p + 'eps_interp']).cuda()
+        assert L._pair_critic_batches(torch.empty_like(real), real) == (pair == '1')
+        ld = L.d_step(real, zb=zd, eps_interp=eps)
+        out[pair] = (ld.cpu(), L.arena_d.gflat.detach().cpu().clone(),
+                     {k: v.detach().cpu().clone() for k, v in L.disc_model.named_parameters()},
+                     {k: v.grad.detach().cpu().clone() for k, v in L.disc_model.named_parameters()})
+    assert_close(out['1'][0], out['0'][0], 1e-6, 'loss_d')
+    assert_close(out['1'][1], out['0'][1], 1e-5, 'critic gradients')
+    assert out['0'][1].abs().max() > 0
+    checked = 0
+    for k, v in out['0'][2].items():
+        # Adam(beta1=0) moves an element by ~lr*sign(g): elements whose gradient is at rounding level may flip, the rest
+        # must have moved alike
+        g = out['0'][3][k]
+        m = g.abs() > 1e-3 * g.abs().max()
+        if g.abs().max() == 0 or not m.any():
+            continue
+        assert_close(out['1'][3][k], g, 1e-5, 'gradient ' + k)
+        du0, du1 = (v - sub(G, 'd0.')[k])[m], (out['1'][2][k] - sub(G, 'd0.')[k])[m]
+        assert (du1 - du0).abs().max() <= 1e-2 * du0.abs().max(), k
+        checked += int(m.sum())
+    assert checked > 1000
+
+
 def test_resnet_full_width_step_vs_oracle():
     """Config #5 at its real width (fmap 64, 64x64, latent 128), batch 8: one generator iteration and one
     critic iteration (WGAN + WGAN-GP) against the oracle on the same weights and draws.  The oracle runs
