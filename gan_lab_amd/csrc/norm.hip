@@ -193,6 +193,26 @@ __global__ void ln_bwdbwd_apply_kernel(const float* __restrict__ x, const float*
   }
 }
 
+// BatchNorm bookkeeping between the statistics and the apply pass in ONE launch (was ~11 C-element ATen launches per
+// layer and forward): out = {mean[C], biased var[C], rstd[C], scale[C] = rstd * weight}, the running estimates move by
+// ``momentum`` (unbiased variance, nn.BatchNorm2d) and the batch counter by one.
+__global__ void bn_finalize_kernel(const float* __restrict__ mom, const float* __restrict__ weight,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ batches, float* __restrict__ out, int C, float eps,
+                                   float keep, float momentum, float unbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && batches) batches[0] += 1;
+  if (c >= C) return;
+  const float mean = mom[c * 3], var = mom[c * 3 + 1];
+  const float rstd = rsqrtf(var + eps);
+  out[c] = mean;
+  out[C + c] = var;
+  out[2 * C + c] = rstd;
+  out[3 * C + c] = weight ? rstd * weight[c] : rstd;
+  if (running_mean) running_mean[c] = running_mean[c] * keep + momentum * mean;
+  if (running_var) running_var[c] = running_var[c] * keep + momentum * (var * unbias);
+}
+
 }  // namespace
 
 #define ST gl_stream(stream)
@@ -267,6 +287,15 @@ int ganlab_bn_stats_f32(const float* x, float* out, int N, int C, long long HW, 
   if (N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   return rowsums_launch(x, nullptr, x, nullptr, nullptr, nullptr, nullptr, out, C, RowGeom{(long long)N * HW, HW, C * HW, HW},
                         1, workspace, workspace_bytes, stream);
+}
+
+int ganlab_bn_finalize_f32(const float* mom, const float* weight, float* running_mean, float* running_var,
+                           long long* batches, float* out, int C, float eps, float momentum, float unbias,
+                           void* stream) {
+  if (!mom || !out || C <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, ST, mom, weight, running_mean,
+            running_var, batches, out, C, eps, (float)(1.0 - (double)momentum), momentum, unbias);
+  return GL_CHECK_LAUNCH();
 }
 
 int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,

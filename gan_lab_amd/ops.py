@@ -2472,34 +2472,43 @@ def _row_workspace(rows, length, device):
 
 
 class _BatchNormTrain(Function):
-    """nn.BatchNorm2d in training mode on fused kernels (csrc/norm.hip): batch statistics (2 launches), normalise +
-    affine (1), backward sums = the parameter gradients (2) and the input gradient (1).  First order only - the
-    generator is never inside a gradient penalty.  Returns (y, batch mean, biased batch variance)."""
+    """nn.BatchNorm2d in training mode on fused kernels (csrc/norm.hip): batch statistics (2 launches), the C-element
+    bookkeeping - rstd, scale, running estimates, batch counter - in one (``bn_finalize``), normalise + affine (1);
+    backward sums = the parameter gradients (2) and the input gradient (1).  First order only - the generator is never
+    inside a gradient penalty.  Returns (y, batch mean, biased batch variance)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, running_mean, running_var, momentum, batches):
         x = _c(x)
         n, c, hw = _nchw(x)
+        m = n * hw
         L = _lib.lib()
-        ws = _row_workspace(c, n * hw, x.device)
+        ws = _row_workspace(c, m, x.device)
         mom = _new((c, 3), x)
         check(L.ganlab_bn_stats_f32(_p(x), _p(mom), n, c, hw, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()),
               'bn_stats')
-        mean, var = mom[:, 0].contiguous(), mom[:, 1].contiguous()
-        rstd = torch.rsqrt(var + eps)                       # C-element vectors
-        scale = (rstd * weight if weight is not None else rstd).contiguous()
+        fin = _new((4, c), x)                                # mean, var, rstd, scale = rstd * weight
+        for buf in (running_mean, running_var, batches):
+            assert buf is None or (buf.is_contiguous() and buf.device == x.device)
+        assert batches is None or batches.dtype == torch.int64
+        check(L.ganlab_bn_finalize_f32(_p(mom), _p(_c(weight)) if weight is not None else None,
+                                       _p(running_mean) if running_mean is not None else None,
+                                       _p(running_var) if running_var is not None else None,
+                                       ctypes.c_void_p(batches.data_ptr()) if batches is not None else None, _p(fin), c,
+                                       float(eps), float(momentum), m / max(m - 1, 1), _st()), 'bn_finalize')
+        mean, var, rstd, scale = fin[0], fin[1], fin[2], fin[3]
         y = torch.empty_like(x)
         check(L.ganlab_bn_apply_f32(_p(x), _p(mean), _p(scale), _p(_c(bias)) if bias is not None else None, _p(y), n, c,
                                     hw, _st()), 'bn_apply')
-        ctx.save_for_backward(x, weight, mean, rstd)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, mean, rstd, scale)
+        ctx.has_weight, ctx.has_bias = weight is not None, bias is not None
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _gm, _gv):
-        x, weight, mean, rstd = ctx.saved_tensors
+        x, mean, rstd, scale = ctx.saved_tensors
         gy = _c(gy)
         n, c, hw = _nchw(x)
         L = _lib.lib()
@@ -2509,28 +2518,21 @@ class _BatchNormTrain(Function):
                                        ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'bn_bwd_sums')
         gx = None
         if ctx.needs_input_grad[0]:
-            pre = (rstd * weight if weight is not None else rstd).contiguous()
             gx = torch.empty_like(x)
-            check(L.ganlab_bn_bwd_apply_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(sums), _p(pre), _p(gx), n, c, hw,
+            check(L.ganlab_bn_bwd_apply_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(sums), _p(scale), _p(gx), n, c, hw,
                                             _st()), 'bn_bwd_apply')
         want_p = _want_param_grads()
-        gw = sums[:, 1].contiguous() if (weight is not None and want_p and ctx.needs_input_grad[1]) else None
-        gb = sums[:, 0].contiguous() if (ctx.has_bias and want_p and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None
+        gw = sums[:, 1] if (ctx.has_weight and want_p and ctx.needs_input_grad[1]) else None
+        gb = sums[:, 0] if (ctx.has_bias and want_p and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5, batches=None):
     """nn.BatchNorm2d semantics (biased variance for the normalisation, unbiased for the running estimate): fused
-    kernels in training mode, one per-channel affine with the running statistics in eval mode."""
-    n, c, hw = _nchw(x)
-    m = n * hw
+    kernels in training mode (``batches``: the module's ``num_batches_tracked``, counted by the same launch that moves the
+    running estimates), one per-channel affine with the running statistics in eval mode."""
     if training:
-        y, mean, var = _BatchNormTrain.apply(x, weight, bias, float(eps))
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (m / max(m - 1, 1)), alpha=momentum)
-        return y
+        return _BatchNormTrain.apply(x, weight, bias, float(eps), running_mean, running_var, float(momentum), batches)[0]
     xc = chan_affine(x, None, -running_mean)          # centred, like the training path
     rstd = torch.rsqrt(running_var + eps)
     return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)

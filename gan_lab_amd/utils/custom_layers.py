@@ -181,11 +181,12 @@ class BatchNorm2d(nn.BatchNorm2d):
     kernels (ops.batch_norm: channel sums + per-channel affines)."""
 
     def forward(self, x):
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+        count = self.training and self.track_running_stats and self.num_batches_tracked is not None
         use_batch = self.training or not self.track_running_stats
-        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, use_batch,
-                              momentum=self.momentum, eps=self.eps)
+        track = self.training and self.track_running_stats
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean if track or not use_batch else None,
+                              self.running_var if track or not use_batch else None, use_batch,
+                              momentum=self.momentum, eps=self.eps, batches=self.num_batches_tracked if count else None)
 
 
 class LayerNorm(nn.LayerNorm):

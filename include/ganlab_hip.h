@@ -315,11 +315,18 @@ int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* r
  *   bn_stats:     out[c] = {batch mean, biased batch variance, 0}    (fp64 partial sums, evaluated in fp64)
  *   bn_bwd_sums:  out[c] = {sum gy (= d/d bias), sum gy * xhat (= d/d weight), 0}
  *   bn_bwd_apply: gx = pre[c] * (gy - s0/L - xhat * s1/L), pre = rstd * weight, L = N*HW
- *   bn_apply:     y = (x - mean[c]) * scale[c] + shift[c]  (centred form: keeps the rounding error at eps*|y|) */
+ *   bn_apply:     y = (x - mean[c]) * scale[c] + shift[c]  (centred form: keeps the rounding error at eps*|y|)
+ *   bn_finalize:  from bn_stats' out: {mean[C], var[C], rstd[C] = rsqrt(var + eps), scale[C] = rstd * weight} into
+ *                 out[4][C]; running_mean / running_var (may be NULL) move by ``momentum`` towards the batch mean /
+ *                 UNBIASED variance (var * unbias, unbias = L/(L-1)), *batches (may be NULL) += 1 - everything
+ *                 nn.BatchNorm2d.forward does besides normalising (torch/nn/modules/batchnorm.py), one launch */
 int ganlab_bn_stats_f32(const float* x, float* out, int N, int C, long long HW, void* workspace, size_t workspace_bytes,
                         void* stream);
 int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,
                         int C, long long HW, void* stream);
+int ganlab_bn_finalize_f32(const float* mom, const float* weight, float* running_mean, float* running_var,
+                           long long* batches, float* out, int C, float eps, float momentum, float unbias,
+                           void* stream);
 int ganlab_bn_bwd_sums_f32(const float* gy, const float* x, const float* mean, const float* rstd, float* out, int N,
                            int C, long long HW, void* workspace, size_t workspace_bytes, void* stream);
 int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd, const float* sums,
