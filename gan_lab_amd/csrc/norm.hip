@@ -180,16 +180,23 @@ __global__ void ln_project_kernel(const float* __restrict__ a, const float* __re
   }
 }
 
-// out[n,m] = c1[n] * xhat[n,m] + c2[n] * pu[n,m] + c3[n] * gx[n,m]
+// out[n,m] = c1[n] * xhat[n,m] + c2[n] * pu[n,m] + c3[n] * gx[n,m] with the per-row coefficients of the LayerNorm double
+// backward formed here from the two sets of row sums (sums = {sum ghat, sum ghat*xhat, .}, usums = {sum u, sum u*xhat,
+// sum u*ghat}; a, beta, ubar, pbar, r = those / M):  c1 = -rstd^2 (r - a ubar - beta pbar), c2 = -rstd beta, c3 = -rstd pbar
 __global__ void ln_bwdbwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, const float* __restrict__ pu,
-                                       const float* __restrict__ gx, const float* __restrict__ c1,
-                                       const float* __restrict__ c2, const float* __restrict__ c3,
-                                       float* __restrict__ out, long long total, long long M) {
+                                       const float* __restrict__ gx, const float* __restrict__ sums,
+                                       const float* __restrict__ usums, float* __restrict__ out, long long total,
+                                       long long M, float inv) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / M;
-    const float xh = (x[i] - mean[n]) * rstd[n];
-    out[i] = c1[n] * xh + c2[n] * pu[i] + c3[n] * gx[i];
+    const float rs = rstd[n];
+    const float a = sums[n * 3] * inv, beta = sums[n * 3 + 1] * inv;
+    const float ubar = usums[n * 3] * inv, pbar = usums[n * 3 + 1] * inv, r = usums[n * 3 + 2] * inv;
+    const float mut = r - a * ubar - beta * pbar;
+    const float c1 = -(rs * rs) * mut, c2 = -rs * beta, c3 = -rs * pbar;
+    const float xh = (x[i] - mean[n]) * rs;
+    out[i] = c1 * xh + c2 * pu[i] + c3 * gx[i];
   }
 }
 
@@ -327,11 +334,10 @@ int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, 
 }
 
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
-                               const float* c1, const float* c2, const float* c3, float* out, int N, long long M,
-                               void* stream) {
-  if (!x || !mean || !rstd || !pu || !gx || !c1 || !c2 || !c3 || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
-  GL_LAUNCH(ln_bwdbwd_apply_kernel, dim3(ew_blocks((long long)N * M)), dim3(256), 0, ST, x, mean, rstd, pu, gx, c1,
-            c2, c3, out, (long long)N * M, M);
+                               const float* sums, const float* usums, float* out, int N, long long M, void* stream) {
+  if (!x || !mean || !rstd || !pu || !gx || !sums || !usums || !out || N <= 0 || M <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(ln_bwdbwd_apply_kernel, dim3(ew_blocks((long long)N * M)), dim3(256), 0, ST, x, mean, rstd, pu, gx, sums,
+            usums, out, (long long)N * M, M, 1.0f / (float)M);
   return GL_CHECK_LAUNCH();
 }
 

@@ -2651,16 +2651,8 @@ class _LayerNormBwd(Function):
                 check(L.ganlab_coldot_f32(_p(gy), _p(pu), None, None, _p(g_w), None, n, m, _st()), 'ln_coldot')
         else:
             g_gy = pu
-        # tiny per-row arithmetic on N-element vectors
-        inv = 1.0 / m
-        a, beta = sums[:, 0] * inv, sums[:, 1] * inv
-        ubar, pbar, r = usums[:, 0] * inv, usums[:, 1] * inv, usums[:, 2] * inv
-        mut = r - a * ubar - beta * pbar
-        c1 = (-(rstd * rstd) * mut).contiguous()
-        c2 = (-rstd * beta).contiguous()
-        c3 = (-rstd * pbar).contiguous()
-        g_x = torch.empty_like(x)
-        check(L.ganlab_ln_bwdbwd_apply_f32(_p(x), _p(mean), _p(rstd), _p(pu), _p(gx), _p(c1), _p(c2), _p(c3), _p(g_x),
+        g_x = torch.empty_like(x)       # the per-row coefficients come from (sums, usums) inside the kernel
+        check(L.ganlab_ln_bwdbwd_apply_f32(_p(x), _p(mean), _p(rstd), _p(pu), _p(gx), _p(sums), _p(usums), _p(g_x),
                                            n, m, _st()), 'ln_bwdbwd_apply')
         return g_gy, g_x, g_w, None, None, None
 

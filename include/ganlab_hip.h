@@ -294,7 +294,9 @@ int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void
  *   ln_rowsums:      per row n, several blocks per row + a fixed-order finish (deterministic), out = [N][3]:
  *                    t = a*(wa ? wa[m] : 1):  s0 = sum t,  s1 = sum t*xhat,  s2 = sum a*b2*(w2 ? w2[m] : 1) (b2 nullable)
  *   ln_project:      out = (wo ? wo[m] : 1) * rstd[n] * (a*(wa ? wa[m] : 1) - s0/M - xhat*s1/M)   (= wo * P_x(a*wa))
- *   ln_bwdbwd_apply: out = c1[n] * xhat + c2[n] * pu + c3[n] * gx    (d/dx of the double backward, csrc/norm.hip) */
+ *   ln_bwdbwd_apply: out = c1[n] * xhat + c2[n] * pu + c3[n] * gx    (d/dx of the double backward); the row coefficients
+ *                    are formed in the kernel from sums = ln_rowsums(gy, w) and usums = ln_rowsums(u, b2 = gy, w2 = w):
+ *                    c1 = -rstd^2 (u2 - s0 u0 - s1 u1), c2 = -rstd s1, c3 = -rstd u1, every sum divided by M */
 int ganlab_ln_affine_fwd_f32(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
                              float* y, int N, long long M, void* stream);
 int ganlab_colscale_f32(const float* a, const float* w, float* out, int N, long long M, void* stream);
@@ -307,8 +309,7 @@ int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const
 int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* sums, const float* wo, float* out, int N, long long M, void* stream);
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
-                               const float* c1, const float* c2, const float* c3, float* out, int N, long long M,
-                               void* stream);
+                               const float* sums, const float* usums, float* out, int N, long long M, void* stream);
 /* ---- fused BatchNorm2d (training mode, first order) of the ResNet generators (csrc/norm.hip) --------------------
  * resnetgan/resblocks.py:15-121 -> NormalizeLayer('BatchNorm') = nn.BatchNorm2d (custom_layers.py:100-107).  A row is
  * a channel (N segments of HW elements); workspace as ganlab_ln_rowsums_workspace(C, N*HW).
