@@ -50,7 +50,8 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=None)
-    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--warmup', type=int, default=None,
+                   help='untimed steps (default 1; config 2: 5, so that the step graphs are captured before the timed region)')
     p.add_argument('--config', type=int, choices=(2, 3, 4, 5), default=3, help='BASELINE.json configuration (3 = headline)')
     p.add_argument('--res', type=int, default=None, help='override the resolution (StyleGAN configs)')
     p.add_argument('--batch', type=int, default=None, help='override the per-GPU batch')
@@ -76,6 +77,8 @@ def parse():
     a.batch = a.batch or dflt[2]
     a.dtype = a.dtype or dflt[3]
     a.steps = a.steps or dflt[4]
+    if a.warmup is None:
+        a.warmup = 5 if a.config == 2 else 1
     return a
 
 
@@ -262,8 +265,8 @@ class InSituKernelTimer(object):
             (ops._packed_bf16(w, mode, scale) if g.bf is not None else ops._packed(w, mode, scale))
 
         def fwd(x, w, bias, g, *a, **k):
-            if len(self.events) >= self.MAX_EVENTS or not self._match(g):
-                return f0(x, w, bias, g, *a, **k)
+            if len(self.events) >= self.MAX_EVENTS or not self._match(g) or torch.cuda.is_current_stream_capturing():
+                return f0(x, w, bias, g, *a, **k)      # (an event recorded into a graph capture cannot be read back)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             prepack(w, ops.PACK_FWD, a[0] if a else k['scale'], g)    # keep the (cached) weight packing out of the bracket
             e0.record()
@@ -273,7 +276,7 @@ class InSituKernelTimer(object):
             return y
 
         def dgrad(gy, w, g, scale):
-            if len(self.events) >= self.MAX_EVENTS or not self._match(g):
+            if len(self.events) >= self.MAX_EVENTS or not self._match(g) or torch.cuda.is_current_stream_capturing():
                 return d0(gy, w, g, scale)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             prepack(w, ops.PACK_DGRAD, scale, g)
