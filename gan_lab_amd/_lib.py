@@ -155,17 +155,19 @@ SIGNATURES = {
     'ganlab_u8_box_decode_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),
     'ganlab_chan_affine_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_mul_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),
-    'ganlab_ln_affine_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_ln_affine_fwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_int, _c_f, _c_p]),
     'ganlab_colscale_f32': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_coldot_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_ln_rowsums_workspace': (_c_sz, [_c_int, _c_ll]),
-    'ganlab_ln_rowsums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_sz, _c_p]),
+    'ganlab_ln_rowsums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_sz, _c_p, _c_p,
+                                       _c_f, _c_p]),
     'ganlab_ln_project_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_ln_bwdbwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_bn_stats_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p, _c_sz, _c_p]),
     'ganlab_bn_finalize_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_f, _c_f, _c_p]),
-    'ganlab_bn_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
-    'ganlab_bn_bwd_sums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p, _c_sz, _c_p]),
+    'ganlab_bn_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_int, _c_f, _c_p]),
+    'ganlab_bn_bwd_sums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p, _c_sz, _c_p, _c_p, _c_f,
+                                        _c_p]),
     'ganlab_bn_bwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'ganlab_tanh_fwd_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
     'ganlab_tanh_bwd_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_p]),

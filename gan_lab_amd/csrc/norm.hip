@@ -23,15 +23,18 @@ inline unsigned ew_blocks(long long n) {
   return (unsigned)(b < 1 ? 1 : (b > EW_MAX_BLOCKS ? EW_MAX_BLOCKS : b));
 }
 
-// y[n,m] = (x[n,m] - mean[n]) * rstd[n] * w[m] + b[m]     (w / b nullable: 1 / 0)
+// y[n,m] = act((x[n,m] - mean[n]) * rstd[n] * w[m] + b[m])     (w / b nullable: 1 / 0; act: the LeakyReLU / ReLU that
+// follows the normalisation in every residual block, resnetgan/resblocks.py:48-49 - one pass instead of two)
 __global__ void ln_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const float* __restrict__ w,
-                                     const float* __restrict__ b, float* __restrict__ y, long long total, long long M) {
+                                     const float* __restrict__ b, float* __restrict__ y, long long total, long long M,
+                                     int act, float slope) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / M, m = i - n * M;
     float v = (x[i] - mean[n]) * rstd[n];
     if (w != nullptr) v *= w[m];
     if (b != nullptr) v += b[m];
+    if (act == GANLAB_ACT_LRELU) v = gl_lrelu(v, slope);
     y[i] = v;
   }
 }
@@ -41,7 +44,7 @@ __global__ void ln_affine_fwd_kernel(const float* __restrict__ x, const float* _
 // side of the ReLU that follows (seen in the float64-judged ResNet step test)
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                float* __restrict__ y, long long total4, int C, long long hw4) {
+                                float* __restrict__ y, long long total4, int C, long long hw4, int act, float slope) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i / hw4) % C);
     const float mu = mean[c], sc = scale[c], sh = shift != nullptr ? shift[c] : 0.f;
@@ -50,15 +53,20 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     v.y = (v.y - mu) * sc + sh;
     v.z = (v.z - mu) * sc + sh;
     v.w = (v.w - mu) * sc + sh;
+    if (act == GANLAB_ACT_LRELU) {
+      v.x = gl_lrelu(v.x, slope); v.y = gl_lrelu(v.y, slope);
+      v.z = gl_lrelu(v.z, slope); v.w = gl_lrelu(v.w, slope);
+    }
     reinterpret_cast<float4*>(y)[i] = v;
   }
 }
 __global__ void bn_apply1_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                 float* __restrict__ y, long long total, int C, long long HW) {
+                                 float* __restrict__ y, long long total, int C, long long HW, int act, float slope) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i / HW) % C);
-    y[i] = (x[i] - mean[c]) * scale[c] + (shift != nullptr ? shift[c] : 0.f);
+    const float v = (x[i] - mean[c]) * scale[c] + (shift != nullptr ? shift[c] : 0.f);
+    y[i] = act == GANLAB_ACT_LRELU ? gl_lrelu(v, slope) : v;
   }
 }
 
@@ -107,7 +115,8 @@ __device__ __forceinline__ long long row_addr(const RowGeom& g, int r, long long
 __global__ void ln_rowsums_kernel(const float* __restrict__ a, const float* __restrict__ wa,
                                   const float* __restrict__ x, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ b2,
-                                  const float* __restrict__ w2, double* __restrict__ part, RowGeom g, long long len) {
+                                  const float* __restrict__ w2, double* __restrict__ part, RowGeom g, long long len,
+                                  const float* __restrict__ yact, float* __restrict__ gz, float slope) {
   __shared__ double red[3][4];
   const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
   const long long lo = sidx * len, hi = (lo + len < g.L) ? lo + len : g.L;
@@ -115,7 +124,11 @@ __global__ void ln_rowsums_kernel(const float* __restrict__ a, const float* __re
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (long long m = lo + threadIdx.x; m < hi; m += 256) {
     const long long i = row_addr(g, n, m);
-    const float av = a[i];
+    float av = a[i];
+    if (yact != nullptr) {      // a = gradient at the OUTPUT of the LeakyReLU behind the normalisation: gz = a * lrelu'(y),
+      if (!(yact[i] > 0.f)) av *= slope;      // stored for the projection / parameter-gradient passes that follow
+      gz[i] = av;
+    }
     const float t = wa != nullptr ? av * wa[m] : av;
     s0 += (double)t;
     s1 += (double)t * (double)((x[i] - mu) * rs);
@@ -227,10 +240,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mom, const float* _
 extern "C" {
 
 int ganlab_ln_affine_fwd_f32(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
-                             float* y, int N, long long M, void* stream) {
+                             float* y, int N, long long M, int act, float slope, void* stream) {
   if (!x || !mean || !rstd || !y || N <= 0 || M <= 0) return GANLAB_EINVAL;
   GL_LAUNCH(ln_affine_fwd_kernel, dim3(ew_blocks((long long)N * M)), dim3(256), 0, ST, x, mean, rstd, w, b, y,
-            (long long)N * M, M);
+            (long long)N * M, M, act, slope);
   return GL_CHECK_LAUNCH();
 }
 
@@ -254,8 +267,9 @@ size_t ganlab_ln_rowsums_workspace(int N, long long M) {
 
 static int rowsums_launch(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* b2, const float* w2, float* out, int rows, RowGeom g, int moments,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  if (!a || !x || !out || rows <= 0 || g.L <= 0) return GANLAB_EINVAL;
+                          void* workspace, size_t workspace_bytes, void* stream, const float* yact = nullptr,
+                          float* gz = nullptr, float slope = 1.f) {
+  if (!a || !x || !out || rows <= 0 || g.L <= 0 || (yact != nullptr) != (gz != nullptr)) return GANLAB_EINVAL;
   if (!workspace || workspace_bytes < ganlab_ln_rowsums_workspace(rows, g.L)) return GANLAB_EWORKSPACE;
   int S = (int)((g.L + 4095) / 4096);
   if (S > ROWSUM_MAX_SPLIT) S = ROWSUM_MAX_SPLIT;
@@ -264,7 +278,7 @@ static int rowsums_launch(const float* a, const float* wa, const float* x, const
   S = (int)((g.L + len - 1) / len);
   double* part = reinterpret_cast<double*>(workspace);
   GL_LAUNCH(ln_rowsums_kernel, dim3((unsigned)S, (unsigned)rows), dim3(256), 0, ST, a, wa, x, mean, rstd, b2, w2, part,
-            g, len);
+            g, len, yact, gz, slope);
   GL_LAUNCH(ln_rowsums_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ST, part, out, rows, S,
             moments, 1.0 / (double)g.L);
   return GL_CHECK_LAUNCH();
@@ -272,10 +286,10 @@ static int rowsums_launch(const float* a, const float* wa, const float* x, const
 
 int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* b2, const float* w2, float* out, int N, long long M, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, const float* yact, float* gz, float slope, void* stream) {
   if (!mean || !rstd) return GANLAB_EINVAL;
   return rowsums_launch(a, wa, x, mean, rstd, b2, w2, out, N, RowGeom{M, M, 0, M}, 0, workspace, workspace_bytes,
-                        stream);
+                        stream, yact, gz, slope);
 }
 
 int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
@@ -306,22 +320,24 @@ int ganlab_bn_finalize_f32(const float* mom, const float* weight, float* running
 }
 
 int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,
-                        int C, long long HW, void* stream) {
+                        int C, long long HW, int act, float slope, void* stream) {
   if (!x || !mean || !scale || !y || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   const long long total = (long long)N * C * HW;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
     GL_LAUNCH(bn_apply_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, ST, x, mean, scale, shift, y, total / 4, C,
-              HW / 4);
+              HW / 4, act, slope);
   else
-    GL_LAUNCH(bn_apply1_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST, x, mean, scale, shift, y, total, C, HW);
+    GL_LAUNCH(bn_apply1_kernel, dim3(ew_blocks(total)), dim3(256), 0, ST, x, mean, scale, shift, y, total, C, HW, act,
+              slope);
   return GL_CHECK_LAUNCH();
 }
 
 int ganlab_bn_bwd_sums_f32(const float* gy, const float* x, const float* mean, const float* rstd, float* out, int N,
-                           int C, long long HW, void* workspace, size_t workspace_bytes, void* stream) {
+                           int C, long long HW, void* workspace, size_t workspace_bytes, const float* yact, float* gz,
+                           float slope, void* stream) {
   if (!mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return GANLAB_EINVAL;
   return rowsums_launch(gy, nullptr, x, mean, rstd, nullptr, nullptr, out, C, RowGeom{(long long)N * HW, HW, C * HW, HW},
-                        0, workspace, workspace_bytes, stream);
+                        0, workspace, workspace_bytes, stream, yact, gz, slope);
 }
 
 int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd, const float* sums,

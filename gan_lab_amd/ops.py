@@ -2478,7 +2478,7 @@ class _BatchNormTrain(Function):
     inside a gradient penalty.  Returns (y, batch mean, biased batch variance)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, running_mean, running_var, momentum, batches):
+    def forward(ctx, x, weight, bias, eps, running_mean, running_var, momentum, batches, act_slope):
         x = _c(x)
         n, c, hw = _nchw(x)
         m = n * hw
@@ -2498,9 +2498,13 @@ class _BatchNormTrain(Function):
                                        float(eps), float(momentum), m / max(m - 1, 1), _st()), 'bn_finalize')
         mean, var, rstd, scale = fin[0], fin[1], fin[2], fin[3]
         y = torch.empty_like(x)
+        # act_slope: the LeakyReLU / ReLU behind the normalisation (resnetgan/resblocks.py:48-49) applied by the same pass;
+        # its backward is applied by bn_bwd_sums as it loads the gradient (sign(y) = sign of the pre-activation)
         check(L.ganlab_bn_apply_f32(_p(x), _p(mean), _p(scale), _p(_c(bias)) if bias is not None else None, _p(y), n, c,
-                                    hw, _st()), 'bn_apply')
-        ctx.save_for_backward(x, mean, rstd, scale)
+                                    hw, ACT_LRELU if act_slope is not None else ACT_NONE,
+                                    float(act_slope) if act_slope is not None else 1.0, _st()), 'bn_apply')
+        ctx.save_for_backward(x, mean, rstd, scale, y if act_slope is not None else None)
+        ctx.act_slope = act_slope
         ctx.has_weight, ctx.has_bias = weight is not None, bias is not None
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
@@ -2508,14 +2512,18 @@ class _BatchNormTrain(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, _gm, _gv):
-        x, mean, rstd, scale = ctx.saved_tensors
+        x, mean, rstd, scale, yact = ctx.saved_tensors
         gy = _c(gy)
         n, c, hw = _nchw(x)
         L = _lib.lib()
         ws = _row_workspace(c, n * hw, x.device)
         sums = _new((c, 3), x)
+        gz = torch.empty_like(gy) if yact is not None else None      # gy * lrelu'(y), written by the sums pass
         check(L.ganlab_bn_bwd_sums_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(sums), n, c, hw,
-                                       ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'bn_bwd_sums')
+                                       ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _p(yact), _p(gz),
+                                       float(ctx.act_slope) if yact is not None else 1.0, _st()), 'bn_bwd_sums')
+        if gz is not None:
+            gy = gz
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
@@ -2524,18 +2532,21 @@ class _BatchNormTrain(Function):
         want_p = _want_param_grads()
         gw = sums[:, 1] if (ctx.has_weight and want_p and ctx.needs_input_grad[1]) else None
         gb = sums[:, 0] if (ctx.has_bias and want_p and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5, batches=None):
+def batch_norm(x, weight, bias, running_mean, running_var, training, momentum=0.1, eps=1e-5, batches=None,
+               act_slope=None):
     """nn.BatchNorm2d semantics (biased variance for the normalisation, unbiased for the running estimate): fused
     kernels in training mode (``batches``: the module's ``num_batches_tracked``, counted by the same launch that moves the
     running estimates), one per-channel affine with the running statistics in eval mode."""
     if training:
-        return _BatchNormTrain.apply(x, weight, bias, float(eps), running_mean, running_var, float(momentum), batches)[0]
+        return _BatchNormTrain.apply(x, weight, bias, float(eps), running_mean, running_var, float(momentum), batches,
+                                     act_slope)[0]
     xc = chan_affine(x, None, -running_mean)          # centred, like the training path
     rstd = torch.rsqrt(running_var + eps)
-    return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
+    y = chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
+    return y if act_slope is None else bias_act(y, act='lrelu', slope=act_slope)
 
 
 def batch_norm_composed(x, weight, bias, eps=1e-5):
@@ -2550,14 +2561,16 @@ def batch_norm_composed(x, weight, bias, eps=1e-5):
     return chan_affine(xc, rstd * weight if weight is not None else rstd, bias)
 
 
-def _ln_rowsums(a, wa, x, mean, rstd, n, m, b2=None, w2=None):
-    """[N][3] row sums (see ganlab_ln_rowsums_f32): sum a*wa, sum a*wa*xhat, sum a*b2*w2."""
+def _ln_rowsums(a, wa, x, mean, rstd, n, m, b2=None, w2=None, yact=None, gz=None, slope=1.0):
+    """[N][3] row sums (see ganlab_ln_rowsums_f32): sum a*wa, sum a*wa*xhat, sum a*b2*w2; with ``yact`` a is first multiplied
+    by lrelu'(yact) and that product is also written to ``gz``."""
     L = _lib.lib()
     nbytes = L.ganlab_ln_rowsums_workspace(n, m)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
     out = _new((n, 3), x)
     check(L.ganlab_ln_rowsums_f32(_p(a), _p(wa), _p(x), _p(mean), _p(rstd), _p(b2), _p(w2), _p(out), n, m,
-                                  ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _st()), 'ln_rowsums')
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _p(yact), _p(gz), float(slope), _st()),
+          'ln_rowsums')
     return out
 
 
@@ -2574,7 +2587,7 @@ class _LayerNorm(Function):
     4 backward, 7 for the backward of the backward (WGAN-GP through the critic)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, act_slope):
         x = _c(x)
         n = x.shape[0]
         m = x.numel() // n
@@ -2586,56 +2599,70 @@ class _LayerNorm(Function):
         ws = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
         check(L.ganlab_row_stats_f32(_p(x), _p(mean), _p(rstd), n, m, eps, _p(ws), ws.numel() * 8, _st()), 'ln_stats')
         y = torch.empty_like(x)
-        check(L.ganlab_ln_affine_fwd_f32(_p(x), _p(mean), _p(rstd), _p(w), _p(b), _p(y), n, m, _st()), 'ln_affine_fwd')
-        ctx.save_for_backward(x, weight, mean, rstd)   # the weight INPUT: the double backward reaches the parameter
+        # act_slope: the LeakyReLU / ReLU behind the normalisation (resnetgan/resblocks.py:48-49) in the same pass; the
+        # backward applies its derivative while loading the gradient for the row sums (sign(y) = sign of the pre-activation)
+        check(L.ganlab_ln_affine_fwd_f32(_p(x), _p(mean), _p(rstd), _p(w), _p(b), _p(y), n, m,
+                                         ACT_LRELU if act_slope is not None else ACT_NONE,
+                                         float(act_slope) if act_slope is not None else 1.0, _st()), 'ln_affine_fwd')
+        # the weight INPUT is saved: the double backward reaches the parameter
+        ctx.save_for_backward(x, weight, mean, rstd, y if act_slope is not None else None)
+        ctx.act_slope = act_slope
         ctx.wshape = weight.shape if weight is not None else None
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, mean, rstd = ctx.saved_tensors
+        x, weight, mean, rstd, yact = ctx.saved_tensors
         w = weight.reshape(-1) if weight is not None else None      # tracked under create_graph
         want_p = _want_param_grads() and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        gx, gw, gb = _LayerNormBwd.apply(gy, x, w, mean, rstd, want_p)
+        gx, gw, gb = _LayerNormBwd.apply(gy, x, w, mean, rstd, want_p, yact, ctx.act_slope)
         if gw is not None and ctx.wshape is not None:
             gw = gw.reshape(ctx.wshape)
             gb = gb.reshape(ctx.wshape) if ctx.has_bias else None
         else:
             gw = gb = None
-        return gx, gw, gb if ctx.has_bias else None, None
+        return gx, gw, gb if ctx.has_bias else None, None, None
 
 
 class _LayerNormBwd(Function):
     """(gy, x, w) -> (gx, gw, gb); its own backward is the analytic double backward for a cotangent of gx (the
-    gradient-penalty pass never keeps gw / gb: ops.input_grad_only)."""
+    gradient-penalty pass never keeps gw / gb: ops.input_grad_only).  With ``yact`` (the output of a LayerNorm fused with
+    its LeakyReLU) gy is the gradient BEHIND the activation: gz = gy * lrelu'(yact) is formed by the row-sums pass and takes
+    gy's place everywhere below; lrelu'' = 0, so the double backward only gains the same mask on its d/d gy."""
 
     @staticmethod
-    def forward(ctx, gy, x, w, mean, rstd, want_param_grads):
+    def forward(ctx, gy, x, w, mean, rstd, want_param_grads, yact=None, act_slope=None):
         gy = _c(gy)
         w = _c(w) if w is not None else None
         n = x.shape[0]
         m = x.numel() // n
         L = _lib.lib()
-        sums = _ln_rowsums(gy, w, x, mean, rstd, n, m)                 # a = mean(ghat), beta = mean(ghat * xhat)
+        if yact is not None:
+            gz = torch.empty_like(gy)
+            sums = _ln_rowsums(gy, w, x, mean, rstd, n, m, yact=yact, gz=gz, slope=act_slope)
+            gy = gz
+        else:
+            sums = _ln_rowsums(gy, w, x, mean, rstd, n, m)             # a = mean(ghat), beta = mean(ghat * xhat)
         gx = _ln_project(gy, w, x, mean, rstd, sums, None, n, m)       # P_x(gy * w)
         gw = gb = None
         if want_param_grads and w is not None:
             gw, gb = _new((m,), x), _new((m,), x)
             check(L.ganlab_coldot_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(gw), _p(gb), n, m, _st()), 'ln_param_grad')
-        ctx.save_for_backward(gy, x, w, mean, rstd, gx, sums)
+        ctx.save_for_backward(gy, x, w, mean, rstd, gx, sums, yact)
+        ctx.act_slope = act_slope
         ctx.set_materialize_grads(False)
         return gx, gw, gb
 
     @staticmethod
     @once_differentiable
     def backward(ctx, u, ggw, ggb):
-        gy, x, w, mean, rstd, gx, sums = ctx.saved_tensors
+        gy, x, w, mean, rstd, gx, sums, yact = ctx.saved_tensors
         if ggw is not None or ggb is not None:
             raise NotImplementedError('LayerNorm double backward through the parameter gradients is not needed by the '
                                       'GAN losses (the penalty differentiates the INPUT gradient only)')
         if u is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         u = _c(u)
         n = x.shape[0]
         m = x.numel() // n
@@ -2654,13 +2681,16 @@ class _LayerNormBwd(Function):
         g_x = torch.empty_like(x)       # the per-row coefficients come from (sums, usums) inside the kernel
         check(L.ganlab_ln_bwdbwd_apply_f32(_p(x), _p(mean), _p(rstd), _p(pu), _p(gx), _p(sums), _p(usums), _p(g_x),
                                            n, m, _st()), 'ln_bwdbwd_apply')
-        return g_gy, g_x, g_w, None, None, None
+        if yact is not None:
+            g_gy = k_act_bwd(g_gy, yact, ctx.act_slope)
+        return g_gy, g_x, g_w, None, None, None, None, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5):
+def layer_norm(x, weight, bias, eps=1e-5, act_slope=None):
     """nn.LayerNorm(normalized_shape = x.shape[1:]) semantics: per-sample statistics over all features (biased
-    variance), then the elementwise affine - fused kernels with an analytic double backward (csrc/norm.hip)."""
-    return _LayerNorm.apply(x, weight, bias, float(eps))
+    variance), then the elementwise affine - fused kernels with an analytic double backward (csrc/norm.hip).
+    ``act_slope``: LeakyReLU(act_slope) (0 = ReLU) of the result in the same passes, forward and backward."""
+    return _LayerNorm.apply(x, weight, bias, float(eps), None if act_slope is None else float(act_slope))
 
 
 def layer_norm_composed(x, weight, bias, eps=1e-5):

@@ -7,6 +7,8 @@ architectures use so that e.g. ``Sequential(Upsample, Conv2dEx, blur)`` or
 ``Sequential(Conv2dEx(bias), LeakyReLU)`` run as ONE kernel while the module tree (and therefore
 the checkpoint layout) stays that of the reference.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -180,22 +182,23 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameter / buffer container (same state_dict keys) whose forward runs on the HIP
     kernels (ops.batch_norm: channel sums + per-channel affines)."""
 
-    def forward(self, x):
+    def forward(self, x, act_slope=None):
         count = self.training and self.track_running_stats and self.num_batches_tracked is not None
         use_batch = self.training or not self.track_running_stats
         track = self.training and self.track_running_stats
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean if track or not use_batch else None,
                               self.running_var if track or not use_batch else None, use_batch,
-                              momentum=self.momentum, eps=self.eps, batches=self.num_batches_tracked if count else None)
+                              momentum=self.momentum, eps=self.eps, batches=self.num_batches_tracked if count else None,
+                              act_slope=act_slope)
 
 
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm([C, R, R]) parameter container whose forward (and first / second derivatives, for
     WGAN-GP) runs on the HIP kernels (ops.layer_norm)."""
 
-    def forward(self, x):
+    def forward(self, x, act_slope=None):
         assert tuple(x.shape[1:]) == tuple(self.normalized_shape), (x.shape, self.normalized_shape)
-        return ops.layer_norm(x, self.weight, self.bias, eps=self.eps)
+        return ops.layer_norm(x, self.weight, self.bias, eps=self.eps, act_slope=act_slope)
 
 
 class Tanh(nn.Module):
@@ -225,8 +228,13 @@ class NormalizeLayer(nn.Module):
         else:
             raise Exception(f'`norm_type` == "{norm_type}" not supported.')
 
-    def forward(self, x):
-        return self.norm(x)
+    def forward(self, x, act_slope=None):
+        """``act_slope``: the LeakyReLU that follows (fused_sequential) - Batch / LayerNorm apply it in their own passes."""
+        if act_slope is None:
+            return self.norm(x)
+        if isinstance(self.norm, (BatchNorm2d, LayerNorm)):
+            return self.norm(x, act_slope=act_slope)
+        return ops.bias_act(self.norm(x), act='lrelu', slope=act_slope)
 
 
 # -- minibatch stddev ------------------------------------------------------------------------------ #
@@ -390,6 +398,7 @@ def fused_sequential(mods, x):
          Conv2dBias / LinearBias [, LeakyReLU]     -> one bias+act pass
          Conv2dEx, LeakyReLU, Blur2d               -> blur backward fused with LeakyReLU' + bias gradient
          Blur2d, Conv2dBias [, LeakyReLU]          -> one blur+bias+act pass
+         NormalizeLayer, LeakyReLU                 -> Batch / LayerNorm apply the activation (and its backward) themselves
        Everything else falls through to the module's own (HIP) forward.  nn.Sequential children are
        flattened first."""
     flat = []
@@ -469,6 +478,12 @@ def fused_sequential(mods, x):
             pending_slope = kw['slope'] if getattr(x, ops.ACT_DEFERRED, False) else None
             blur_handoff = getattr(x, ops.BLUR_HANDOFF, None) if kw.get('blur') else None
             rgb_handoff = getattr(x, ops.RGB_HANDOFF, None)
+        elif isinstance(m, NormalizeLayer) and isinstance(nxt, LeakyReLU) and os.environ.get('GANLAB_NORM_ACT') != '0':
+            # NormalizeLayer, LeakyReLU (every residual block, resblocks.py:48-49) -> the activation and its backward ride in
+            # the normalisation's own passes
+            assert pending_slope is None
+            x = m(x, act_slope=nxt.negative_slope)
+            i += 1
         else:
             assert pending_slope is None
             x = m(x)

@@ -287,25 +287,29 @@ int ganlab_mul_f32(const float* a, const float* b, float* out, long long n, void
  * resnetgan/resblocks.py:15-121 -> NormalizeLayer('LayerNorm') = nn.LayerNorm (custom_layers.py:100-107).  A sample
  * is a row of M = C*R*R elements; mean / rstd come from ganlab_instnorm_stats_f32(planes = N, HW = M);
  * P_x(g) = rstd * (g - mean(g) - xhat * mean(g * xhat)) per row.
- *   ln_affine_fwd:   y = (x - mean[n]) * rstd[n] * w[m] + b[m]                          (w, b nullable)
+ *   ln_affine_fwd:   y = act((x - mean[n]) * rstd[n] * w[m] + b[m])                     (w, b nullable; act = GANLAB_ACT_LRELU
+ *                    folds in the LeakyReLU / ReLU that follows the normalisation in every residual block,
+ *                    resnetgan/resblocks.py:48-49)
  *   colscale:        out[n,m] = a[n,m] * w[m]                                           (ghat = gy * w)
  *   coldot:          o1[m] = sum_n a * f,  f = (x - mean[n]) * rstd[n] (mean given) or x;  o2[m] = sum_n a (nullable)
  *                    -> gw, gb of the backward; d/dw of the double backward
  *   ln_rowsums:      per row n, several blocks per row + a fixed-order finish (deterministic), out = [N][3]:
- *                    t = a*(wa ? wa[m] : 1):  s0 = sum t,  s1 = sum t*xhat,  s2 = sum a*b2*(w2 ? w2[m] : 1) (b2 nullable)
+ *                    t = a*(wa ? wa[m] : 1):  s0 = sum t,  s1 = sum t*xhat,  s2 = sum a*b2*(w2 ? w2[m] : 1) (b2 nullable);
+ *                    with yact (the fused layer's OUTPUT) the backward of that LeakyReLU is applied on load,
+ *                    a <- a * lrelu'(yact), and the masked gradient is also stored to gz for the passes that follow
  *   ln_project:      out = (wo ? wo[m] : 1) * rstd[n] * (a*(wa ? wa[m] : 1) - s0/M - xhat*s1/M)   (= wo * P_x(a*wa))
  *   ln_bwdbwd_apply: out = c1[n] * xhat + c2[n] * pu + c3[n] * gx    (d/dx of the double backward); the row coefficients
  *                    are formed in the kernel from sums = ln_rowsums(gy, w) and usums = ln_rowsums(u, b2 = gy, w2 = w):
  *                    c1 = -rstd^2 (u2 - s0 u0 - s1 u1), c2 = -rstd s1, c3 = -rstd u1, every sum divided by M */
 int ganlab_ln_affine_fwd_f32(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
-                             float* y, int N, long long M, void* stream);
+                             float* y, int N, long long M, int act, float slope, void* stream);
 int ganlab_colscale_f32(const float* a, const float* w, float* out, int N, long long M, void* stream);
 int ganlab_coldot_f32(const float* a, const float* x, const float* mean, const float* rstd, float* o1, float* o2,
                       int N, long long M, void* stream);
 size_t ganlab_ln_rowsums_workspace(int N, long long M);
 int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* b2, const float* w2, float* out, int N, long long M, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          size_t workspace_bytes, const float* yact, float* gz, float slope, void* stream);
 int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* sums, const float* wo, float* out, int N, long long M, void* stream);
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
@@ -314,9 +318,9 @@ int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* r
  * resnetgan/resblocks.py:15-121 -> NormalizeLayer('BatchNorm') = nn.BatchNorm2d (custom_layers.py:100-107).  A row is
  * a channel (N segments of HW elements); workspace as ganlab_ln_rowsums_workspace(C, N*HW).
  *   bn_stats:     out[c] = {batch mean, biased batch variance, 0}    (fp64 partial sums, evaluated in fp64)
- *   bn_bwd_sums:  out[c] = {sum gy (= d/d bias), sum gy * xhat (= d/d weight), 0}
+ *   bn_bwd_sums:  out[c] = {sum gy (= d/d bias), sum gy * xhat (= d/d weight), 0}; yact / gz / slope as in ln_rowsums
  *   bn_bwd_apply: gx = pre[c] * (gy - s0/L - xhat * s1/L), pre = rstd * weight, L = N*HW
- *   bn_apply:     y = (x - mean[c]) * scale[c] + shift[c]  (centred form: keeps the rounding error at eps*|y|)
+ *   bn_apply:     y = act((x - mean[c]) * scale[c] + shift[c])  (centred form: keeps the rounding error at eps*|y|)
  *   bn_finalize:  from bn_stats' out: {mean[C], var[C], rstd[C] = rsqrt(var + eps), scale[C] = rstd * weight} into
  *                 out[4][C]; running_mean / running_var (may be NULL) move by ``momentum`` towards the batch mean /
  *                 UNBIASED variance (var * unbias, unbias = L/(L-1)), *batches (may be NULL) += 1 - everything
@@ -324,12 +328,13 @@ int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* r
 int ganlab_bn_stats_f32(const float* x, float* out, int N, int C, long long HW, void* workspace, size_t workspace_bytes,
                         void* stream);
 int ganlab_bn_apply_f32(const float* x, const float* mean, const float* scale, const float* shift, float* y, int N,
-                        int C, long long HW, void* stream);
+                        int C, long long HW, int act, float slope, void* stream);
 int ganlab_bn_finalize_f32(const float* mom, const float* weight, float* running_mean, float* running_var,
                            long long* batches, float* out, int C, float eps, float momentum, float unbias,
                            void* stream);
 int ganlab_bn_bwd_sums_f32(const float* gy, const float* x, const float* mean, const float* rstd, float* out, int N,
-                           int C, long long HW, void* workspace, size_t workspace_bytes, void* stream);
+                           int C, long long HW, void* workspace, size_t workspace_bytes, const float* yact, float* gz,
+                           float slope, void* stream);
 int ganlab_bn_bwd_apply_f32(const float* gy, const float* x, const float* mean, const float* rstd, const float* sums,
                             const float* pre, float* gx, int N, int C, long long HW, void* stream);
 /* nn.Tanh of the ResNet generators (resnetgan/architectures.py:55, :93) */

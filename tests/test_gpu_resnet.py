@@ -67,11 +67,14 @@ def test_batch_norm_train_and_eval():
         ref.bias.copy_(torch.randn(6) * .3)
     mine.load_state_dict(ref.state_dict())
     mine.cuda()
-    for step in range(2):
+    for step in range(3):
         x = torch.randn(5, 6, 8, 12) * 2 + 0.5
         xr = x.clone().requires_grad_(True)
         xg = x.clone().cuda().requires_grad_(True)
-        yr, y = ref(xr), mine(xg)
+        if step == 2:     # the ReLU behind it applied by the normalisation's own passes, forward and backward
+            yr, y = F.relu(ref(xr)), mine(xg, act_slope=0.0)
+        else:
+            yr, y = ref(xr), mine(xg)
         assert_close(y.cpu(), yr, 1e-5, 'bn fwd')
         cot = torch.randn_like(x)
         ref.zero_grad()
@@ -89,10 +92,13 @@ def test_batch_norm_train_and_eval():
     assert_close(mine(x.cuda()).cpu(), ref(x), 1e-5, 'bn eval')
 
 
+@pytest.mark.parametrize('fused_slope', [None, 0.0, 0.2])
 @pytest.mark.parametrize('shape', [(4, 3, 8, 8), (2, 8, 16, 16), (3, 5, 4, 4),
                                    (3, 16, 32, 32), (2, 32, 64, 64)])      # the last two: several statistics blocks per row
-def test_layer_norm_first_and_second_order(shape):
-    """LayerNorm([C,R,R]) inside a WGAN-GP style double backward: d/dtheta of |d out / d x|^2."""
+def test_layer_norm_first_and_second_order(shape, fused_slope):
+    """LayerNorm([C,R,R]) inside a WGAN-GP style double backward: d/dtheta of |d out / d x|^2.  ``fused_slope``: the
+    LeakyReLU behind it applied by the normalisation's own passes (forward, backward and double backward) against
+    nn.LayerNorm followed by leaky_relu."""
     from gan_lab_amd.utils.custom_layers import LayerNorm
     torch.manual_seed(2)
     ref = torch.nn.LayerNorm(list(shape[1:]))
@@ -107,8 +113,13 @@ def test_layer_norm_first_and_second_order(shape):
 
     def run(mod, x, w2):
         x = x.clone().requires_grad_(True)
-        y = mod(x)
-        out = (F.relu(y) * w2).sum(dim=(1, 2, 3))
+        if fused_slope is None:
+            y = mod(x)
+        elif mod is mine:
+            y = mod(x, act_slope=fused_slope)
+        else:
+            y = F.leaky_relu(mod(x), fused_slope)
+        out = (F.relu(y - 0.1) * w2).sum(dim=(1, 2, 3))
         gx, = torch.autograd.grad(out, x, torch.ones_like(out), create_graph=True)
         pen = (gx ** 2).sum() + out.sum()
         mod.zero_grad()
