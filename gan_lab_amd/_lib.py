@@ -162,6 +162,7 @@ SIGNATURES = {
     'ganlab_ln_rowsums_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p, _c_sz, _c_p, _c_p,
                                        _c_f, _c_p]),
     'ganlab_ln_project_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'ganlab_ln_bwd_cols_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_ln_bwdbwd_apply_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
     'ganlab_bn_stats_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p, _c_sz, _c_p]),
     'ganlab_bn_finalize_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_f, _c_f, _c_f, _c_p]),

@@ -97,6 +97,29 @@ __global__ void coldot_kernel(const float* __restrict__ a, const float* __restri
   if (o2 != nullptr) o2[m] = s2;
 }
 
+// LayerNorm backward's projection and its parameter gradients in ONE pass over (a, x) - thread per column, rows in order:
+//   gx[n,m] = rstd[n] * (a[n,m] * w[m] - s0[n]/M - xhat[n,m] * s1[n]/M)       (= ln_project with wa = w)
+//   gw[m] = sum_n a[n,m] * xhat[n,m],   gb[m] = sum_n a[n,m]                    (= coldot, same summation order)
+__global__ void ln_bwd_cols_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ x,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ sums, float* __restrict__ gx, float* __restrict__ gw,
+                                   float* __restrict__ gb, int N, long long M, float inv_len) {
+  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float wm = w[m];
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const long long i = (long long)n * M + m;
+    const float av = a[i], rs = rstd[n];
+    const float xh = (x[i] - mean[n]) * rs;
+    gx[i] = rs * (av * wm - sums[n * 3] * inv_len - xh * sums[n * 3 + 1] * inv_len);
+    s1 += av * xh;
+    s2 += av;
+  }
+  gw[m] = s1;
+  gb[m] = s2;
+}
+
 // Row sums with several blocks per row (a critic LayerNorm has only N = batch rows of up to 2^18 elements):
 //   t = a[n,m] * (wa ? wa[m] : 1);  s0 = sum t;  s1 = sum t * xhat;  s2 = sum a * b2 * (w2 ? w2[m] : 1)  (b2 nullable)
 // grid = (S, N): block (s, n) reduces the slice [s*len, (s+1)*len) of row n into part[(n*S + s)*3 ..] (fp64);
@@ -257,6 +280,14 @@ int ganlab_coldot_f32(const float* a, const float* x, const float* mean, const f
                       int N, long long M, void* stream) {
   if (!a || !x || !o1 || N <= 0 || M <= 0 || ((mean == nullptr) != (rstd == nullptr))) return GANLAB_EINVAL;
   GL_LAUNCH(coldot_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ST, a, x, mean, rstd, o1, o2, N, M);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_ln_bwd_cols_f32(const float* a, const float* w, const float* x, const float* mean, const float* rstd,
+                           const float* sums, float* gx, float* gw, float* gb, int N, long long M, void* stream) {
+  if (!a || !w || !x || !mean || !rstd || !sums || !gx || !gw || !gb || N <= 0 || M <= 0) return GANLAB_EINVAL;
+  GL_LAUNCH(ln_bwd_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ST, a, w, x, mean, rstd, sums, gx, gw,
+            gb, N, M, 1.0f / (float)M);
   return GL_CHECK_LAUNCH();
 }
 

@@ -2644,11 +2644,13 @@ class _LayerNormBwd(Function):
             gy = gz
         else:
             sums = _ln_rowsums(gy, w, x, mean, rstd, n, m)             # a = mean(ghat), beta = mean(ghat * xhat)
-        gx = _ln_project(gy, w, x, mean, rstd, sums, None, n, m)       # P_x(gy * w)
         gw = gb = None
-        if want_param_grads and w is not None:
-            gw, gb = _new((m,), x), _new((m,), x)
-            check(L.ganlab_coldot_f32(_p(gy), _p(x), _p(mean), _p(rstd), _p(gw), _p(gb), n, m, _st()), 'ln_param_grad')
+        if want_param_grads and w is not None:       # projection and parameter gradients in one pass over (gy, x)
+            gx, gw, gb = torch.empty_like(x), _new((m,), x), _new((m,), x)
+            check(L.ganlab_ln_bwd_cols_f32(_p(gy), _p(w), _p(x), _p(mean), _p(rstd), _p(sums), _p(gx), _p(gw), _p(gb), n, m,
+                                           _st()), 'ln_bwd_cols')
+        else:
+            gx = _ln_project(gy, w, x, mean, rstd, sums, None, n, m)   # P_x(gy * w)
         ctx.save_for_backward(gy, x, w, mean, rstd, gx, sums, yact)
         ctx.act_slope = act_slope
         ctx.set_materialize_grads(False)

@@ -312,6 +312,10 @@ int ganlab_ln_rowsums_f32(const float* a, const float* wa, const float* x, const
                           size_t workspace_bytes, const float* yact, float* gz, float slope, void* stream);
 int ganlab_ln_project_f32(const float* a, const float* wa, const float* x, const float* mean, const float* rstd,
                           const float* sums, const float* wo, float* out, int N, long long M, void* stream);
+/* ln_bwd_cols: the first-order backward's projection AND parameter gradients in one pass over (a, x), thread per column:
+ * gx = rstd[n] * (a*w[m] - s0[n]/M - xhat*s1[n]/M) (= ln_project with wa = w), gw[m] = sum_n a*xhat, gb[m] = sum_n a (= coldot) */
+int ganlab_ln_bwd_cols_f32(const float* a, const float* w, const float* x, const float* mean, const float* rstd,
+                           const float* sums, float* gx, float* gw, float* gb, int N, long long M, void* stream);
 int ganlab_ln_bwdbwd_apply_f32(const float* x, const float* mean, const float* rstd, const float* pu, const float* gx,
                                const float* sums, const float* usums, float* out, int N, long long M, void* stream);
 /* ---- fused BatchNorm2d (training mode, first order) of the ResNet generators (csrc/norm.hip) --------------------
