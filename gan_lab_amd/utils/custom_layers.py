@@ -423,8 +423,16 @@ def fused_sequential(mods, x):
         handoff, blur_handoff = blur_handoff, None
         rgb, rgb_handoff = rgb_handoff, None
         up = False
+        up_after = None
         if isinstance(m, Upsample2x) and i + 1 < n and isinstance(flat[i + 1], Conv2dEx):
-            up = True
+            if flat[i + 1].ks == 1 and flat[i + 1].padding == 0 and i + 2 == n and \
+                    os.environ.get('GANLAB_UP_COMMUTE') != '0':
+                # a pointwise conv (with its bias) commutes with the nearest upsample element for element: run it on the
+                # quarter-size map and upsample its result - the residual blocks' [upsample, 1x1 conv] skip, resblocks.py:55
+                # (only as the END of a sequence: nothing behind it can then pair up with the conv)
+                up_after = m
+            else:
+                up = True
             i += 1
             m = flat[i]
         nxt = flat[i + 1] if i + 1 < n else None
@@ -478,6 +486,10 @@ def fused_sequential(mods, x):
             pending_slope = kw['slope'] if getattr(x, ops.ACT_DEFERRED, False) else None
             blur_handoff = getattr(x, ops.BLUR_HANDOFF, None) if kw.get('blur') else None
             rgb_handoff = getattr(x, ops.RGB_HANDOFF, None)
+            if up_after is not None:
+                assert pending_slope is None and blur_handoff is None
+                x = up_after(x)
+                rgb_handoff = None
         elif isinstance(m, NormalizeLayer) and isinstance(nxt, LeakyReLU) and os.environ.get('GANLAB_NORM_ACT') != '0':
             # NormalizeLayer, LeakyReLU (every residual block, resblocks.py:48-49) -> the activation and its backward ride in
             # the normalisation's own passes

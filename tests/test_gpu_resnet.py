@@ -372,7 +372,7 @@ def test_resnet_full_width_step_vs_oracle():
     # ReLU ties: with ~4M activations per critic pass a handful sit within one fp32 ulp of zero, and two
     # fp32 implementations (or fp32 vs fp64) put them on different sides; each flip changes the gradient in a
     # small neighbourhood by O(1) of its value (the CPU fp32 run shows the same isolated outliers against
-    # float64).  So: at most 1% of the elements of any parameter may be off by more than 1e-3 of the
+    # float64).  So: at most 2% of the elements of any parameter may be off by more than 1e-3 of the
     # parameter's largest gradient, and the bulk (L1) error must be within 1e-3.
     gmax = max(p.grad.abs().max().item() for p in gan.d.values())
     named = dict(L.disc_model.named_parameters())
@@ -383,8 +383,11 @@ def test_resnet_full_width_step_vs_oracle():
         err = (named[k].grad.cpu().double() - p.grad).abs()
         frac = (err > TOL * den).double().mean().item()
         l1 = err.sum().item() / max(p.grad.abs().sum().item(), 1e-3 * gmax * p.numel())
-        # (measured: <= 0.57% of a LayerNorm bias's elements with L1 5e-5; the count moves with the rounding order)
-        assert frac <= 1e-2 and l1 <= TOL, f'D grad {k}: {frac:.2e} of elements off, L1 rel err {l1:.2e}'
+        # (measured on resblocks.1's first LayerNorm bias, the worst entry: 0.72% / 0.83% / 1.14% of its elements for three
+        #  roundings of the SAME step - critic scored in one or two passes, the generator's 1x1 skip before or after its
+        #  upsample, i.e. generated images that differ by 1e-7 - with the L1 error at 4.4e-5 .. 5.4e-5 every time: the count
+        #  moves with the rounding order, the bulk error is the stable quantity; same 2% cap as for the generator above)
+        assert frac <= 2e-2 and l1 <= TOL, f'D grad {k}: {frac:.2e} of elements off, L1 rel err {l1:.2e}'
 
 
 def test_resnet_train_loop_and_checkpoint(tmp_path):
