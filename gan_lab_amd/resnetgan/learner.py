@@ -235,7 +235,7 @@ class GANLearner(object):
             # two separate passes' (resnetgan/learner.py:640-651) and each parameter gets ONE gradient contribution from
             # the pair instead of two - half the launches of the first-order critic work at this launch-bound size
             n = xgenb.shape[0]
-            out = self.disc_model(torch.cat((xgenb, xb.view_as(xgenb))))
+            out = self.disc_model(torch.cat((xgenb, xb.reshape(xgenb.shape))))
             loss = self.loss_func_disc(out[:n], out[n:])
         else:
             loss = self.loss_func_disc(self.disc_model(xgenb), self.disc_model(xb))
