@@ -29,55 +29,64 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const ganlab_pack_desc* 
     if (descs[mid].block0 <= b) lo = mid; else hi = mid - 1;
   }
   const ganlab_pack_desc d = descs[lo];
+  // One thread per WEIGHT POSITION (all of its taps), not per output element: the taps of (co, ci) are 36 contiguous bytes
+  // of the source, read once here instead of by 9 (plain), 16 (stride-2) or 9 (bf16) threads of far-apart workgroups; the
+  // stores of a tap stay coalesced across the threads (adjacent threads = adjacent output columns).
   const long long e = (b - d.block0) * 256 + threadIdx.x;
-  if (e >= d.total) return;
   const float* w = d.src;
   if (d.kind == GANLAB_PACKKIND_PLAIN) {
     const int KK = d.ks * d.ks, dgrad = d.mode == GANLAB_PACK_DGRAD;
     const int rows = dgrad ? d.Cout : d.Cin, cols = dgrad ? d.Cin : d.Cout;
     const int rows_p = round_up_c(rows, d.ks == 1 ? 32 : 16), cols_p = round_up_c(cols, 64);
-    const int col = (int)(e % cols_p);
-    const long long t = e / cols_p;
-    const int row = (int)(t % rows_p), tap = (int)(t / rows_p);
-    float v = 0.f;
-    if (row < rows && col < cols) {
-      const int co = dgrad ? row : col, ci = dgrad ? col : row, st = dgrad ? (KK - 1 - tap) : tap;
-      v = d.scale * w[((long long)co * d.Cin + ci) * KK + st];
-    }
-    reinterpret_cast<float*>(d.dst)[e] = v;
+    const long long plane = (long long)rows_p * cols_p;
+    if (e >= plane) return;
+    const int col = (int)(e % cols_p), row = (int)(e / cols_p);
+    const bool in = row < rows && col < cols;
+    const int co = dgrad ? row : col, ci = dgrad ? col : row;
+    const float* ws = w + ((long long)co * d.Cin + ci) * KK;
+    float* out = reinterpret_cast<float*>(d.dst) + e;
+    for (int tap = 0; tap < KK; ++tap)
+      out[tap * plane] = in ? d.scale * ws[dgrad ? (KK - 1 - tap) : tap] : 0.f;
   } else if (d.kind == GANLAB_PACKKIND_S2) {
     const int transpose = d.mode;
     const int rows = transpose ? d.Cout : d.Cin, cols = transpose ? d.Cin : d.Cout;
     const int rows_p = round_up_c(rows, 16), cols_p = round_up_c(cols, 64);
-    const int col = (int)(e % cols_p);
-    const long long t = e / cols_p;
-    const int row = (int)(t % rows_p), tap = (int)(t / rows_p);
-    float v = 0.f;
-    if (row < rows && col < cols) {
-      const int co = transpose ? row : col, ci = transpose ? col : row;
+    const long long plane = (long long)rows_p * cols_p;
+    if (e >= plane) return;
+    const int col = (int)(e % cols_p), row = (int)(e / cols_p);
+    const bool in = row < rows && col < cols;
+    const int co = transpose ? row : col, ci = transpose ? col : row;
+    float k9[9];
+    const float* ws = w + ((long long)co * d.Cin + ci) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k9[t] = in ? ws[t] : 0.f;
+    float* out = reinterpret_cast<float*>(d.dst) + e;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
       const int a = tap >> 2, bb = tap & 3;
-      const float* ws = w + ((long long)co * d.Cin + ci) * 9;
+      float v = 0.f;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) v += comb_s2(d.up, a, ky) * comb_s2(d.up, bb, kx) * ws[ky * 3 + kx];
-      v *= d.scale;
+        for (int kx = 0; kx < 3; ++kx) v += comb_s2(d.up, a, ky) * comb_s2(d.up, bb, kx) * k9[ky * 3 + kx];
+      out[tap * plane] = v * d.scale;
     }
-    reinterpret_cast<float*>(d.dst)[e] = v;
   } else {      // GANLAB_PACKKIND_BF16: [chunk = ci/32][tap][kg = (ci%32)/8][CO][ci%8]
     const int dg = d.mode == GANLAB_PACK_DGRAD;
     const int CO = dg ? d.Cin : d.Cout;
+    if (e >= d.total / 9) return;
     const int j = (int)(e & 7);
     long long t = e >> 3;
     const int co = (int)(t % CO);
     t /= CO;
     const int kg = (int)(t & 3);
-    t >>= 2;
-    const int tap = (int)(t % 9);
-    const int chunk = (int)(t / 9);
+    const int chunk = (int)(t >> 2);
     const int ci = chunk * 32 + kg * 8 + j;
-    const float v = dg ? w[((long long)ci * d.Cin + co) * 9 + (8 - tap)] : w[((long long)co * d.Cin + ci) * 9 + tap];
-    reinterpret_cast<__bf16*>(d.dst)[e] = (__bf16)(v * d.scale);
+    const float* ws = dg ? w + ((long long)ci * d.Cin + co) * 9 : w + ((long long)co * d.Cin + ci) * 9;
+    __bf16* out = reinterpret_cast<__bf16*>(d.dst);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      out[((((long long)chunk * 9 + tap) * 4 + kg) * CO + co) * 8 + j] = (__bf16)(ws[dg ? 8 - tap : tap] * d.scale);
   }
 }
 

@@ -255,7 +255,8 @@ def _repack_range(r):
             d.src, d.dst = e.w.data_ptr(), e.out.data_ptr()
             d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = kind, cout, cin, ks, mode, up, scale, \
                 total, blocks
-            blocks += (total + 255) // 256
+            # one thread per weight position, all of its taps (csrc/pack.hip pack_many_kernel)
+            blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else ks * ks)) + 255) // 256
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         tab = (keys, host.to(items[0][1].w.device), blocks)
         _PACK_TABLES[r] = tab

@@ -471,7 +471,9 @@ int ganlab_conv_wgrad_act_bits_f32(const float* gy, const unsigned* ybits, const
  * The packed forms ganlab_conv_pack_f32 / ganlab_conv_s2_pack_f32 / ganlab_conv_pack_bf16 produce, rebuilt for a whole
  * table of weights after the optimiser rewrote them (Conv2dEx.forward multiplies by wscale on every call,
  * custom_layers.py:202-211; here the scaled re-layout is cached between optimiser steps).  `descs_device`: device copy of
- * n_desc descriptors sorted by block0; descriptor i owns blocks [block0, block0 + ceil(total / 256)). */
+ * n_desc descriptors sorted by block0.  One thread re-lays out one weight position with all of its taps (36 contiguous
+ * source bytes), so descriptor i owns blocks [block0, block0 + ceil(total / taps / 256)) with taps = ks*ks (PLAIN), 16
+ * (S2: the K4 taps of the stride-2 kernels) or 9 (BF16). */
 #define GANLAB_PACKKIND_PLAIN 0
 #define GANLAB_PACKKIND_S2 1
 #define GANLAB_PACKKIND_BF16 2
