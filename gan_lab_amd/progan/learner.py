@@ -216,6 +216,21 @@ class ProGANLearner(GANLearner):
             return xb
         return ops.lerp(ops.k_up2(ops.k_pool2(xb, 0.25), 1.0), xb, self.gen_model.alpha)
 
+    def _pair_critic_batches(self, xgenb, xb):
+        """May the critic score the generated and the real batch in one pass (the penalty-free / WGAN-GP branch of d_step)?
+        Only when the minibatch-stddev groups stay inside each half: batch a multiple of the group size.
+        GANLAB_CRITIC_PAIR=0: A/B."""
+        import os
+        if os.environ.get('GANLAB_CRITIC_PAIR') == '0' or xgenb.numel() != xb.numel():
+            return False
+        key, per_sample = getattr(self, '_pairable', (None, False))
+        if key != id(self.disc_model):
+            per_sample = not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in self.disc_model.modules())
+            self._pairable = (id(self.disc_model), per_sample)
+        g = getattr(self.disc_model, 'mbstd_group_size', 4)
+        n = xgenb.shape[0]
+        return per_sample and (g == -1 or (n >= g and n % g == 0))
+
     def d_step(self, xb, zb=None, defer_update=False, gen_kwargs=None, eps_interp=None):
         """One discriminator iteration (progan/learner.py:734-816).  ``xb``: real batch on the device,
         already at the current resolution.  Returns the (device) loss scalar."""
@@ -238,7 +253,16 @@ class ProGANLearner(GANLearner):
             d_gen, d_real = (self.disc_model(xgenb), d_pen) if gp == 'r1' else (d_pen, self.disc_model(xb))
             loss = self.loss_func_disc(d_gen, d_real) + bp.gp_from_output(d_pen, xr, gp, c.lda, c.gamma)
         else:
-            d_gen, d_real = self.disc_model(xgenb), self.disc_model(xb)
+            if self._pair_critic_batches(xgenb, xb):
+                # one critic pass over [generated; real]: the only layer that looks across samples, the minibatch-stddev
+                # statistic, works on CONTIGUOUS groups of 4 (custom_layers.py:117-140: x.view(G, group_size, ...)), which a
+                # batch that is a multiple of 4 keeps inside its own half - the outputs are the two separate passes'
+                # (progan/learner.py:786-800) and every critic parameter gets one gradient contribution from the pair
+                n = xgenb.shape[0]
+                out = self.disc_model(torch.cat((xgenb, xb.reshape(xgenb.shape))))
+                d_gen, d_real = out[:n], out[n:]
+            else:
+                d_gen, d_real = self.disc_model(xgenb), self.disc_model(xb)
             loss = self.loss_func_disc(d_gen, d_real)
             if gp is not None:
                 loss = loss + self.calc_gp(xgenb, xb, eps_interp=eps_interp)

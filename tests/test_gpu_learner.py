@@ -487,3 +487,39 @@ def test_training_step_frees_its_activations_without_the_cyclic_collector():
         P.FMAP_BASE, P.FMAP_MAX = 8192, 512
     assert calls['mod'] >= 4, calls            # the modulated layer was on the path
     assert a2 <= a1, (a1, a2)
+
+
+@pytest.mark.parametrize('batch,paired', [(8, True), (4, True), (6, False)])
+def test_progan_paired_critic_pass_equals_two_passes(batch, paired, monkeypatch):
+    """The WGAN-GP critic iteration scores [generated; real] in ONE pass when the minibatch-stddev groups (contiguous
+    groups of 4, custom_layers.py:117-140) stay inside each half - a batch that is a multiple of 4; loss and every critic
+    gradient equal those of the reference's two passes (progan/learner.py:786-800) up to the order of the weight-gradient
+    sums.  A batch of 6 (one group = the whole batch) must NOT pair."""
+    from gan_lab_amd import rng
+    out = {}
+    for pair in ('0', '1'):
+        monkeypatch.setenv('GANLAB_CRITIC_PAIR', pair)
+        torch.manual_seed(5)
+        rng.manual_seed(5)
+        L = make_learner('progan', 16, batch=batch, loss='wgan', gradient_penalty='wgan-gp', random_seed=5)
+        L.gen_model.train()
+        L.disc_model.train()
+        g = torch.Generator().manual_seed(9)
+        real = (torch.rand(batch, 3, 16, 16, generator=g) * 2 - 1).cuda()
+        zd = torch.randn(batch, 16, generator=g).cuda()
+        eps = torch.rand(batch, 1, 1, 1, generator=g).cuda()
+        if pair == '0':
+            w0 = L.arena_d.flat.detach().clone(), L.arena_g.flat.detach().clone()
+        else:
+            with torch.no_grad():
+                L.arena_d.flat.copy_(w0[0])
+                L.arena_g.flat.copy_(w0[1])
+            from gan_lab_amd import ops
+            ops.bump_weight_epoch()
+        assert L._pair_critic_batches(torch.empty_like(real), real) == (pair == '1' and paired)
+        L.set_requires_grad_disc(True)
+        ld = L.d_step(real, zb=zd, eps_interp=eps, defer_update=True)
+        out[pair] = (ld.cpu(), L.arena_d.gflat.detach().cpu().clone())
+    assert out['0'][1].abs().max() > 0
+    assert_close(out['1'][0], out['0'][0], 1e-6, 'loss_d')
+    assert_close(out['1'][1], out['0'][1], 1e-5, 'critic gradients')
