@@ -522,13 +522,29 @@ def dry_run_dist(a, json_fd):
                                         cutoff_trunc_trick=None, log_every=0, random_seed=7))
     L.reducer = parallel.GradReducer(bucket_mb=0.02)           # several buckets even for this toy network
     ok, launched = True, []
+
+    class _DirectWrite(torch.autograd.Function):
+        """What ops.direct_param_grads does on the GPU: the gradient kernel writes the parameter's arena slot itself and the
+        Function hands the engine NO gradient for it.  The bucket hooks must still fire for such a parameter (AccumulateGrad
+        runs its post-accumulate hooks on an undefined gradient too) - otherwise every single-use parameter would silently
+        leave its bucket to start() and the overlap would be gone."""
+        @staticmethod
+        def forward(ctx, p, coef):
+            ctx.p, ctx.coef = p, coef
+            return (p.detach() * coef).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.p.grad.add_(g * ctx.coef)
+            return None, None
     dist.barrier()
     t0 = time.perf_counter()
     for it in range(a.steps):
         for arena in (L.arena_d, L.arena_g):
             arena.zero_grad()
             coef = float(rank + 1 + it)
-            loss = sum((p * coef).sum() for p in arena.params)         # d loss / d p == coef on this rank
+            # d loss / d p == coef on this rank; every other parameter takes the direct-write route
+            loss = sum(_DirectWrite.apply(p, coef) if i % 2 else (p * coef).sum() for i, p in enumerate(arena.params))
             L.reducer.arm(arena)
             loss.backward()
             L.reducer.start(arena.gflat)
@@ -548,7 +564,8 @@ def dry_run_dist(a, json_fd):
                'steps': a.steps, 'warmup': 0, 'ms_per_step': round(dt / max(a.steps, 1) * 1e3, 3), 'dry_run': True,
                'gradients_averaged_correctly_on_every_rank': bool(flags.item()),
                'd_arena_buckets': len(rep['bounds']), 'bucket_order_agreed': rep['agreed'],
-               'buckets_launched_inside_backward_per_reduction': launched}
+               'buckets_launched_inside_backward_per_reduction': launched,
+               'every_other_parameter_written_directly': True}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     dist.barrier()
     dist.destroy_process_group()

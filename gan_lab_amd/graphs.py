@@ -97,6 +97,10 @@ class _StepGraphs(object):
         self.graphs, self.pool, self.sig, self.calls = {}, None, None, 0
         self.block = self.real = None
         self.losses = {}
+        # what the captured launches read through raw pointers and nothing else owns: the packed-weight buffers and the
+        # descriptor tables of the batched re-pack that existed when a graph was captured.  The pack cache may drop them
+        # (ops.bump_weight_epoch() without ranges: cache overflow, GraphedGenerator, growth) - the graphs must not lose them
+        self.keepalive = []
         self.failed = None          # the exception of a capture that did not go through: this phase then steps eagerly
 
     def eligible(self):
@@ -104,8 +108,13 @@ class _StepGraphs(object):
         return parallel.world_size() == 1 and torch.cuda.is_available() and self.failed is None
 
     def _common_signature(self, real):
+        # ``_graph_gen``: bumped by the learner whenever it rebuilds arenas or optimisers (an ``id()`` can be recycled by a
+        # checkpoint load at the same resolution).  ``ops.pack_generation()``: bumped when the pack cache is flushed or a
+        # descriptor table is rebuilt - the graphs own what they captured (``keepalive``), but a re-capture then packs
+        # into the live cache again instead of carrying a private copy of every packed weight forever.
+        # The batch's leading size is NOT part of it: a short last batch steps eagerly and the graphs stay (__call__)
         L = self.L
-        return (id(L.opt_disc), id(L.opt_gen), id(L.arena_d), id(L.arena_g), L.batch_size, tuple(real.shape), real.device,
+        return (getattr(L, '_graph_gen', 0), ops.pack_generation(), L.batch_size, tuple(real.shape[1:]), real.device,
                 ops.get_compute_dtype(), bool(L.gen_model.training), bool(L.disc_model.training))
 
     def _check(self, sig):
@@ -127,6 +136,7 @@ class _StepGraphs(object):
         # (one launch per parameter range, descriptor table already on the device) is what gets captured
         ops.mark_packs_stale()
         known = set(ops._PACK_CACHE.keys())
+        self._own_pack_state()
         start = rng._STATE['offset']
         rng.begin_device_offsets(self.block)
         L.opt_disc.dev_scalars, L.opt_gen.dev_scalars = base + 16, base + 28
@@ -147,7 +157,20 @@ class _StepGraphs(object):
             for k in [k for k in ops._PACK_CACHE if k not in known]:
                 del ops._PACK_CACHE[k]
             ops.mark_packs_stale()
+            self._own_pack_state()          # tables uploaded / entries re-packed while this capture ran
         self.graphs[key] = (graph, draws)
+
+    def _own_pack_state(self):
+        seen = {id(t) for t in self.keepalive}
+        for e in ops._PACK_CACHE.values():
+            for t in (e.out, e.w):
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    self.keepalive.append(t)
+        for tab in ops._PACK_TABLES.values():
+            if id(tab[1]) not in seen:
+                seen.add(id(tab[1]))
+                self.keepalive.append(tab[1])
 
     def _replay(self, key, opts):
         """``opts``: which optimisers step inside this graph (their step counts advance on the host here)."""
@@ -230,7 +253,8 @@ class GraphedStep(_StepGraphs):
         g = L.gen_model
         self._check(self._common_signature(real) + (g.curr_res, bool(g.fade_in_phase)))
         self.calls += 1
-        if not self.eligible() or self.calls <= self.warmup:
+        off_size = real.shape[0] != L.batch_size or (self.real is not None and real.shape != self.real.shape)
+        if not self.eligible() or self.calls <= self.warmup or off_size:
             cut_d, kw_d = self._mix_kwargs()
             ld = self._d_half(real, kw_d)
             cut_g, kw_g = self._mix_kwargs()

@@ -184,6 +184,7 @@ class _PackEntry(object):
 
 _PACK_CACHE = {}
 _PACK_SERIAL = [0]
+_PACK_GEN = [0]          # bumped when buffers a captured graph may point at are dropped: full flush, table rebuild
 _PACK_RANGES = {}        # (lo, hi) byte range -> serial of its last rewrite
 _PACK_TABLES = {}        # (lo, hi) -> (entry keys, device descriptor table, total blocks)
 _KIND_PLAIN, _KIND_S2, _KIND_BF16 = 0, 1, 2
@@ -194,12 +195,18 @@ def bump_weight_epoch(ranges=None):
     address ranges), or without arguments to drop every packed weight."""
     _PACK_SERIAL[0] += 1
     if ranges is None:
+        _PACK_GEN[0] += 1
         _PACK_CACHE.clear()
         _PACK_TABLES.clear()
         _PACK_RANGES.clear()
         return
     for r in ranges:
         _PACK_RANGES[(int(r[0]), int(r[1]))] = _PACK_SERIAL[0]
+
+
+def pack_generation():
+    """Changes whenever the cache dropped buffers that an earlier reader may still hold raw pointers to (graphs.py)."""
+    return _PACK_GEN[0]
 
 
 def mark_packs_stale():
@@ -258,6 +265,8 @@ def _repack_range(r):
             # one thread per weight position, all of its taps (csrc/pack.hip pack_many_kernel)
             blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else ks * ks)) + 255) // 256
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        if tab is not None:
+            _PACK_GEN[0] += 1       # the old table's memory goes back to the allocator
         tab = (keys, host.to(items[0][1].w.device), blocks)
         _PACK_TABLES[r] = tab
     check(L.ganlab_pack_many(tab[1].data_ptr(), len(items), tab[2], _st()), 'pack_many')

@@ -138,6 +138,10 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         touched = []
+        if self.dev_scalars is not None and len(self.param_groups) != 1:
+            # host_scalars() describes ONE (lr, step count): a replayed multi-group optimiser would train every group with
+            # group 0's.  graphs.GraphedStep only captures the learners' single-group Adam.
+            raise RuntimeError('FusedAdam.dev_scalars (step-graph capture) supports exactly one parameter group')
         for group in self.param_groups:
             params = [p for p in group['params'] if p.grad is not None]
             if not params:

@@ -122,6 +122,7 @@ class ProGANLearner(GANLearner):
     def _make_arenas(self, first=False, old_lagged=None):
         """Flat parameter / gradient arenas for G and D (+ the EWMA shadow of G)."""
         dev = self.config.dev
+        self._graph_gen = getattr(self, '_graph_gen', 0) + 1    # captured step graphs point into the old arenas (graphs.py)
         self.reducer.abandon()                   # hooks of the arenas this call replaces (growth / checkpoint load)
         ops.bump_weight_epoch()                  # packed weights of the old arenas (their aliases keep the memory alive)
         self.arena_g = ParamArena(self.gen_model.named_parameters(), dev)
@@ -160,6 +161,7 @@ class ProGANLearner(GANLearner):
         c = self.config
         adam_gan = configure_adam_for_gan(lr_base=c.lr_base, betas=(c.beta1, c.beta2), eps=c.eps, wd=c.wd)
         fade = self.gen_model.fade_in_phase
+        self._graph_gen = getattr(self, '_graph_gen', 0) + 1    # ... and at the old optimisers' moment buffers
         self.opt_gen = adam_gan(params=list(self.gen_model.most_parameters(excluded_params=[] if fade else _EXCL_G)))
         self.opt_disc = adam_gan(params=list(self.disc_model.most_parameters(excluded_params=[] if fade else _EXCL_D)))
 

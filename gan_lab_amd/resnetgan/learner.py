@@ -142,6 +142,7 @@ class GANLearner(object):
             print('\n    Ready to train!\n')
 
     def _make_arenas(self):
+        self._graph_gen = getattr(self, '_graph_gen', 0) + 1    # captured step graphs point into the old arenas (graphs.py)
         self.arena_g = ParamArena(self.gen_model.named_parameters(), self.config.dev)
         self.arena_d = ParamArena(self.disc_model.named_parameters(), self.config.dev)
         parallel.broadcast_params(self.arena_g.flat)
@@ -157,6 +158,7 @@ class GANLearner(object):
                              "[ 'adam', 'rmsprop', 'momentum', 'sgd' ]")
         c = self.config
         adam_gan = configure_adam_for_gan(lr_base=c.lr_base, betas=(c.beta1, c.beta2), eps=c.eps, wd=c.wd)
+        self._graph_gen = getattr(self, '_graph_gen', 0) + 1
         self.opt_gen = adam_gan(params=list(self.gen_model.parameters()))
         self.opt_disc = adam_gan(params=list(self.disc_model.parameters()))
 

@@ -76,6 +76,8 @@ class NearestPool2x(nn.Module):
     """NearestPool2d stand-in (custom_layers.py:59-65): F.interpolate(scale_factor=.5, mode='nearest') = x[..., ::2, ::2]."""
 
     def forward(self, x):
+        if x.dim() == 3:
+            x = x.view(-1, *x.shape)
         return ops.resample(x, 'nearest_down')
 
 

@@ -236,6 +236,20 @@ def test_bench_launcher_starts_two_ranks_dry_run():
     assert all(e >= 3 for e in early[2:]), early      # afterwards the buckets leave while the backward still runs
 
 
+def test_bench_launcher_dry_run_at_the_real_world_size():
+    """The same rehearsal with 8 gloo ranks - the node the driver's scaling run uses: port, environment, the rank-0
+    relay and the rank-agreed bucket order at the real world size.  Every other parameter of the rehearsal writes its
+    gradient straight into the arena and returns None to the engine (what ops.direct_param_grads does on the GPU): the
+    buckets must still leave from inside the backward."""
+    rc, lines, rec, err = _run_bench(['--gpus', '8', '--dry-run-dist', '--steps', '2'], timeout=600)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and rec is not None, lines
+    assert rec['n_gpus'] == 8 and rec['world_size_observed'] == 8
+    assert rec['gradients_averaged_correctly_on_every_rank'] is True and rec['bucket_order_agreed'] is True
+    assert rec['every_other_parameter_written_directly'] is True
+    assert all(e >= 3 for e in rec['buckets_launched_inside_backward_per_reduction'][2:])
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """--gpus must equal the launcher's WORLD_SIZE: no silent single-rank run that prints n_gpus 1."""
     rc, lines, rec, err = _run_bench(['--gpus', '2', '--dry-run-dist'], env_extra={'WORLD_SIZE': '1', 'RANK': '0'})

@@ -322,15 +322,24 @@ def test_direct_parameter_gradients_equal_the_accumulated_ones():
     assert b[4] == 0
 
 
-@pytest.mark.parametrize('kind', ['stylegan', 'progan'])
-def test_graphed_step_equals_eager(kind):
+@pytest.mark.parametrize('kind,flush', [('stylegan', None), ('progan', None), ('stylegan', 'keepalive'),
+                                        ('stylegan', 'recapture')])
+def test_graphed_step_equals_eager(kind, flush, monkeypatch):
     """graphs.GraphedStep: the stabilised iteration replayed as HIP graphs (device-resident Philox position and Adam
     scalars, one graph per style-mixing cut and half) against the same learner stepping eagerly - parameters, Adam moments,
-    EWMA generator, the running w average and both losses BIT FOR BIT after 6 iterations, 4 of them replayed."""
-    from gan_lab_amd import progressive as P, rng
+    EWMA generator, the running w average and both losses BIT FOR BIT after 6 iterations, 4 of them replayed.
+
+    ``flush`` (use-after-free): after the first replayed iteration the pack cache is flushed
+    (``ops.bump_weight_epoch()``: what a cache overflow, a sampling graph or a growth event does) and the freed memory is
+    recycled and scribbled over.  'keepalive': the graphs survive (the cache generation is pinned for the test) and must
+    replay through the buffers and descriptor tables they hold references to; 'recapture': the generation in the
+    signature drops them, two eager iterations and a fresh capture follow.  Both must still equal the eager run."""
+    from gan_lab_amd import ops, progressive as P, rng
     from gan_lab_amd.graphs import GraphedStep
     gen = torch.Generator().manual_seed(17)
     reals = [(torch.rand(4, 3, 32, 32, generator=gen) * 2 - 1).cuda() for _ in range(6)]
+    if flush == 'keepalive':
+        monkeypatch.setattr(ops, 'pack_generation', lambda: 0)
 
     def run(graphed):
         P.FMAP_BASE, P.FMAP_MAX = 1024, 64
@@ -345,7 +354,14 @@ def test_graphed_step_equals_eager(kind):
         torch.manual_seed(10)               # the WGAN-GP interpolation weights come from torch's device generator
         stepper = GraphedStep(L, warmup=2)
         losses = []
-        for x in reals:
+        for it, x in enumerate(reals):
+            if graphed and flush and it == 3:
+                assert stepper.graphs, 'nothing was captured before the flush'
+                ops.bump_weight_epoch()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                junk = [torch.full((1 << 18,), float('nan'), device='cuda') for _ in range(64)]   # recycle what was freed
+                del junk
             if graphed:
                 ld, lg = stepper(x)
             else:

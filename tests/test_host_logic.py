@@ -8,6 +8,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 from util import load_golden
 
@@ -409,3 +410,86 @@ def test_resampler_tables_reproduce_interpolate(mode, scale, tmode):
                     for a in range(t):
                         dense[o, idx[o, a]] += w[o, a]
                 assert np.abs(dense - mat).max() < 1e-7
+
+
+def test_post_accumulate_hook_fires_for_a_directly_written_gradient():
+    """ops.direct_param_grads writes a parameter's gradient into its arena slot and returns None to the engine; the
+    data-parallel bucket hooks (parallel.GradReducer) rely on AccumulateGrad still running its post-accumulate hooks for
+    such a parameter.  That is undocumented torch behaviour: this pins it, so an upgrade cannot silently turn the overlap
+    of the gradient exchange with the backward off."""
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, p, x):
+            ctx.p = p
+            ctx.save_for_backward(x)
+            return (p.detach() * x).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, = ctx.saved_tensors
+            ctx.p.grad.add_(g * x)          # the kernel's direct write
+            return None, None
+
+    p = torch.nn.Parameter(torch.arange(4.0))
+    q = torch.nn.Parameter(torch.ones(4))
+    p.grad, q.grad = torch.zeros(4), torch.zeros(4)
+    fired = []
+    p.register_post_accumulate_grad_hook(lambda t: fired.append('p'))
+    q.register_post_accumulate_grad_hook(lambda t: fired.append('q'))
+    x = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    (Direct.apply(p, x) + (q * x).sum()).backward()
+    assert sorted(fired) == ['p', 'q'], fired
+    assert torch.equal(p.grad, x) and torch.equal(q.grad, x)
+
+
+def test_fused_adam_refuses_device_scalars_with_several_groups():
+    """One (lr, step count) triple lives on the device for a replayed step: a second parameter group would
+    silently train with the first one's."""
+    from gan_lab_amd.optim import FusedAdam
+    a, b = torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(4))
+    a.grad, b.grad = torch.ones(4), torch.ones(4)
+    opt = FusedAdam([{'params': [a]}, {'params': [b], 'lr': 1e-4}])
+    opt.dev_scalars = 1234
+    with pytest.raises(RuntimeError, match='exactly one parameter group'):
+        opt.step()
+
+
+def test_step_graphs_own_what_they_captured(monkeypatch):
+    """captured step graphs hold raw pointers into the pack cache's buffers and descriptor tables.
+    Host side of the fix: (i) the graphs keep strong references to every buffer / table alive at capture, (ii) a flush
+    of the cache or a table rebuild changes ``ops.pack_generation()``, which is part of the graphs' signature, (iii) the
+    learner's generation counter - not ``id()`` of arenas / optimisers - identifies what was captured, (iv) the batch's
+    leading size is not part of the signature (a short last batch steps eagerly, the graphs stay)."""
+    from gan_lab_amd import graphs, ops
+
+    class _Net(object):
+        training, curr_res, fade_in_phase = True, 8, False
+
+    class _L(object):
+        batch_size = 4
+        gen_model = disc_model = _Net()
+        _graph_gen = 3
+
+    monkeypatch.setattr(ops, '_PACK_CACHE', {})
+    monkeypatch.setattr(ops, '_PACK_TABLES', {})
+    e = ops._PackEntry()
+    e.w, e.out = torch.zeros(3), torch.ones(5)
+    ops._PACK_CACHE['k'] = e
+    tab = torch.zeros(7, dtype=torch.uint8)
+    ops._PACK_TABLES[(0, 1)] = (('k',), tab, 1)
+    sg = graphs._StepGraphs(_L())
+    sg._own_pack_state()
+    held = {id(t) for t in sg.keepalive}
+    assert {id(e.out), id(e.w), id(tab)} <= held
+    gen0 = ops.pack_generation()
+    sig0 = sg._common_signature(torch.zeros(4, 3, 8, 8))
+    assert sig0 == sg._common_signature(torch.zeros(3, 3, 8, 8))        # (iv)
+    ops.bump_weight_epoch()                                              # full flush (cache overflow, growth, sampling graph)
+    assert ops.pack_generation() == gen0 + 1 and not ops._PACK_CACHE
+    assert sg._common_signature(torch.zeros(4, 3, 8, 8)) != sig0         # (ii)
+    assert sg.keepalive and sg.keepalive[0] is not None                  # (i) still referenced after the flush
+    sig1 = sg._common_signature(torch.zeros(4, 3, 8, 8))
+    _L._graph_gen += 1                                                   # (iii) arenas / optimisers rebuilt
+    assert sg._common_signature(torch.zeros(4, 3, 8, 8)) != sig1
+    ops.bump_weight_epoch([(0, 16)])                                     # an optimiser step: nothing dropped
+    assert ops.pack_generation() == gen0 + 1
