@@ -14,7 +14,8 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SO_PATH = os.path.join(CSRC, 'libganlab_hip.so')
+# GANLAB_HIP_LIB: file name of an A/B build of the same library under csrc/ (make VARIANT=...); never a fallback
+SO_PATH = os.path.join(CSRC, os.path.basename(os.environ.get('GANLAB_HIP_LIB', '') or 'libganlab_hip.so'))
 
 _c_int, _c_ll, _c_f, _c_p, _c_sz, _c_u64 = (ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p,
                                              ctypes.c_size_t, ctypes.c_uint64)
@@ -42,6 +43,8 @@ class PackDesc(ctypes.Structure):
 SIGNATURES = {
     'ganlab_abi_version': (_c_int, []),
     'ganlab_last_launch': (_c_int, [ctypes.c_char_p, _c_int, ctypes.POINTER(ctypes.c_uint)]),
+    'ganlab_launch_count': (ctypes.c_ulonglong, []),
+    'ganlab_launch_history': (_c_int, [_c_int, ctypes.c_char_p, _c_int, ctypes.POINTER(ctypes.c_uint)]),
     'ganlab_conv_geom_size': (_c_int, []),
     'ganlab_conv_out_hw': (_c_int, [_GP, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'ganlab_conv_pack_f32': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_p]),
@@ -241,6 +244,24 @@ def last_launch():
     grid = ctypes.c_uint(0)
     n = lib().ganlab_last_launch(buf, 1024, ctypes.byref(grid))
     return (buf.value.decode() if n > 0 else None), int(grid.value)
+
+
+def launch_count():
+    """Kernels this thread has launched through the library so far."""
+    return int(lib().ganlab_launch_count())
+
+
+def launches_since(count):
+    """[(symbol, workgroups)] of this thread's launches after ``launch_count()`` returned ``count`` (oldest first; the
+    library keeps the last 16)."""
+    n = min(launch_count() - count, 16)
+    out = []
+    buf = ctypes.create_string_buffer(1024)
+    grid = ctypes.c_uint(0)
+    for back in range(n - 1, -1, -1):
+        if lib().ganlab_launch_history(back, buf, 1024, ctypes.byref(grid)) > 0:
+            out.append((buf.value.decode(), int(grid.value)))
+    return out
 
 
 _ERR = {-1: 'GANLAB_EINVAL (bad argument)', -2: 'GANLAB_EWORKSPACE (workspace too small)',

@@ -211,7 +211,8 @@ def reference_checkpoint_dict(learner, g_names, d_names, extra=None):
     c = learner.config
     cpu = lambda sd: OrderedDict((k, v.detach().cpu().clone()) for k, v in sd.items())  # noqa: E731
     cfg_state = {k: v for k, v in vars(c).items()}
-    nl = nn.LeakyReLU(negative_slope=c.leakiness) if c.nonlinearity.casefold() == 'leaky relu' else nn.ReLU()
+    nl = {'leaky relu': lambda: nn.LeakyReLU(negative_slope=c.leakiness), 'tanh': nn.Tanh}.get(c.nonlinearity.casefold(),
+                                                                                             nn.ReLU)()
     lagged = learner.materialize_lagged_generator() if c.use_ewma_gen else None
     lagged_params = None
     if c.use_ewma_gen and learner.lagged_params is not None:

@@ -16,12 +16,22 @@ static thread_local int gl_launch_status = GANLAB_OK;
 // ganlab_last_launch(): bench.py names the kernel it prices from what was actually dispatched.
 extern thread_local const void* gl_last_kernel_fn;
 extern thread_local unsigned gl_last_grid;
+// ... and of the GL_LAUNCH_RING launches before it (ganlab_launch_count / ganlab_launch_history): an entry point may
+// launch several kernels (a weight gradient and its slot reduction), a test that asserts WHICH kernels a step dispatched
+// reads every launch between two counter values
+#define GL_LAUNCH_RING 16
+extern thread_local const void* gl_ring_fn[GL_LAUNCH_RING];
+extern thread_local unsigned gl_ring_grid[GL_LAUNCH_RING];
+extern thread_local unsigned long long gl_launch_count;
 #define GL_LAUNCH(k, grid, ...)                                                  \
   do {                                                                           \
     (void)hipGetLastError();                                                     \
     const dim3 gl_grid_ = (grid);                                                \
     gl_last_kernel_fn = reinterpret_cast<const void*>(k);                        \
     gl_last_grid = gl_grid_.x * gl_grid_.y * gl_grid_.z;                         \
+    gl_ring_fn[gl_launch_count % GL_LAUNCH_RING] = gl_last_kernel_fn;            \
+    gl_ring_grid[gl_launch_count % GL_LAUNCH_RING] = gl_last_grid;               \
+    ++gl_launch_count;                                                           \
     hipLaunchKernelGGL(k, gl_grid_, __VA_ARGS__);                                \
     if (hipGetLastError() != hipSuccess) gl_launch_status = GANLAB_ELAUNCH;      \
   } while (0)
@@ -68,6 +78,17 @@ __device__ __forceinline__ double gl_block_sum_256d(double v, double* red) {
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
+
+// Accumulation chains.  An fp32 MFMA accumulator is ONE k-ordered fmaf chain per output (bit for bit): over a 4608-term
+// contraction its rounding error grows like sqrt(K) and the thick kernels were 2-2.5x further from float64 than ATen's
+// blocked sums (tools/op_error_probe.py).  The kernels with more than one K-chunk therefore keep a SECOND accumulator set:
+// every GL_ACC_DUMP_TERMS products the running chain is added into it and restarts from zero - chains of <= 144 terms
+// summed by a second chain of K / 144 partials, the error of a single chain of ~(144 + K / 144) terms.  -DGL_ACC_DUMP=0
+// builds the single-chain kernels (A/B: tools/acc_dump_ab.sh).
+#ifndef GL_ACC_DUMP
+#define GL_ACC_DUMP 1
+#endif
+constexpr int GL_ACC_DUMP_TERMS = 144;
 
 __device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 

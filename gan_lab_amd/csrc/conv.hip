@@ -30,6 +30,9 @@
 
 thread_local const void* gl_last_kernel_fn = nullptr;
 thread_local unsigned gl_last_grid = 0;
+thread_local const void* gl_ring_fn[GL_LAUNCH_RING] = {};
+thread_local unsigned gl_ring_grid[GL_LAUNCH_RING] = {};
+thread_local unsigned long long gl_launch_count = 0;
 
 namespace {
 
@@ -380,6 +383,8 @@ struct FwdCfg {
   static constexpr int NWI = KK * CI_T * CO_T / 4;  // float4 weight items per chunk
   static constexpr int WPT = ceil_div_c(NWI, 256);
   static constexpr bool STRIP = MB_ == 1 && XMODE_ != XSCALAR;
+  // chunks per accumulator dump (0: single chain - the 1x1 / linear layers contract <= 512 terms, split-K'd further)
+  static constexpr int DUMP = (GL_ACC_DUMP && KS_ == 3) ? (GL_ACC_DUMP_TERMS / (KK * CI_T) > 0 ? GL_ACC_DUMP_TERMS / (KK * CI_T) : 1) : 0;
   static_assert(NB >= 1, "pixel tile too small");
 };
 
@@ -559,8 +564,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_strip_kernel(ConvArgs p) {
 //     neighbouring columns: at any time the workgroups in flight read and write the SAME image rows, i.e. whole
 //     4 KB rows of HBM pages, instead of 160-byte pieces of rows 4 KB apart.  Measured on the north-star conv
 //     (tools/strip_ablate.py): MFMA + LDS alone 1.16 ms, with the scattered reads and writes 1.77 ms.
+// (16x16 tiles carry a 18x24 patch per channel through the prefetch registers: two workgroups per CU is what they fit)
 template <class Cfg>
-__global__ __launch_bounds__(256, 3) void conv_fwd_strip2_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (Cfg::G::TW == 16 ? 2 : 3)) void conv_fwd_strip2_kernel(ConvArgs p) {
   GL_T(0)
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, NB = Cfg::NB, CI_T = Cfg::CI_T;
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_k
 // has no room for the strip bookkeeping).
 constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the AFF kernels keep in LDS
 template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
-__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4) ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
@@ -951,6 +957,15 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int DUMP = Cfg::DUMP;
+  [[maybe_unused]] f32x4 acc2[DUMP ? MB : 1][DUMP ? NB : 1];
+  [[maybe_unused]] int since_dump = 0;
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   XRegs<G, XS_t::PT> xr;
   float4 wr[WPT];
@@ -1027,6 +1042,24 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR ? 2 : 3)) void conv_
         }
       }
     }
+    if constexpr (DUMP > 0) {       // the chain of the last DUMP chunks joins the second-level sum and restarts
+      if (++since_dump == DUMP && ci0 + CI_T < c_end) {
+        since_dump = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc2[mb][nb] += acc[mb][nb];
+            acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+    }
+  }
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
   }
   // ---- epilogue: + bias, activation, NCHW store ----
   // The patch is the MFMA's A operand and the weights its B operand, so D is [pixel][channel]: a lane holds pixels
@@ -1519,8 +1552,11 @@ int dispatch_geom(const ConvArgs& a, hipStream_t st) {
     if (KS == 3 && mode == XVECUP) return launch_fwd<FwdCfg<3, MB, 4, 4, 0, XVECUP>>(a, st);
     return launch_fwd<FwdCfg<KS, MB, 4, 4, 0, XSCALAR>>(a, st);
   }
-  if (a.Wo >= 8) return launch_fwd<FwdCfg<KS, MB, 3, 3, 2, XSCALAR>>(a, st);
-  return launch_fwd<FwdCfg<KS, MB, 2, 2, 4, XSCALAR>>(a, st);
+  // (the 64-channel tile with a second accumulator set does not fit the element-wise staged multi-image tiles'
+  // registers: those take the 32-channel tile)
+  constexpr int MBS = (GL_ACC_DUMP && KS == 3 && MB == 4) ? 2 : MB;
+  if (a.Wo >= 8) return launch_fwd<FwdCfg<KS, MBS, 3, 3, 2, XSCALAR>>(a, st);
+  return launch_fwd<FwdCfg<KS, MBS, 2, 2, 4, XSCALAR>>(a, st);
 }
 
 template <int KS>
@@ -1785,6 +1821,7 @@ int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
   else if (Cout <= 32) mb = 2;
   else if (px_tiles * ceil_div(Cout, 64) >= 256) mb = 4;
   else if (px_tiles * ceil_div(Cout, 32) >= 256) mb = 2;
+  if (GL_ACC_DUMP && ks == 3 && mb == 4 && Wo < 16) mb = 2;      // as dispatch_geom does
   const long long wgs = px_tiles * ceil_div(Cout, 16 * mb);
   // K-chunk of the kernel that will run: 32 (1x1), 16 (vector-staged 16x16 tiles with <= 32 output channels per
   // workgroup), else 8; a scalar-staged fallback for unaligned pointers halves it, which keeps every split non-empty
@@ -1981,10 +2018,9 @@ extern "C" int ganlab_dbg_set_phase_buf(void* buf) {
 
 extern "C" {
 
-int ganlab_last_launch(char* name, int cap, unsigned* grid) {
-  if (grid) *grid = gl_last_grid;
-  if (gl_last_kernel_fn == nullptr) return 0;
-  const char* mangled = hipKernelNameRefByPtr(gl_last_kernel_fn, nullptr);
+static int gl_symbol_of(const void* fn, char* name, int cap) {
+  if (fn == nullptr) return 0;
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
   if (mangled == nullptr) return 0;
   int status = 0;
   char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
@@ -1996,6 +2032,20 @@ int ganlab_last_launch(char* name, int cap, unsigned* grid) {
   }
   free(dem);
   return n;
+}
+
+int ganlab_last_launch(char* name, int cap, unsigned* grid) {
+  if (grid) *grid = gl_last_grid;
+  return gl_symbol_of(gl_last_kernel_fn, name, cap);
+}
+
+unsigned long long ganlab_launch_count(void) { return gl_launch_count; }
+
+int ganlab_launch_history(int back, char* name, int cap, unsigned* grid) {
+  if (back < 0 || back >= GL_LAUNCH_RING || (unsigned long long)back >= gl_launch_count) return 0;
+  const unsigned long long i = (gl_launch_count - 1 - (unsigned long long)back) % GL_LAUNCH_RING;
+  if (grid) *grid = gl_ring_grid[i];
+  return gl_symbol_of(gl_ring_fn[i], name, cap);
 }
 
 int ganlab_conv_geom_size(void) { return (int)sizeof(ganlab_conv_geom); }

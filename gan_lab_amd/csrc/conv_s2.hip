@@ -173,6 +173,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // second-level sums of the accumulation chains (conv.hip, GL_ACC_DUMP): a 16-tap output contracts 16 * Cin terms
+  constexpr int DUMP = GL_ACC_DUMP ? GL_ACC_DUMP_TERMS / (16 * CI_T) : 0;
+  [[maybe_unused]] f32x4 acc2[DUMP ? MB : 1][DUMP ? NB : 1];
+  [[maybe_unused]] int since_dump = 0;
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
   float4 xr[XPT], wr[WPT];
   const __amdgpu_buffer_rsrc_t rs_x =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
@@ -234,6 +245,24 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
         }
       }
     }
+    if constexpr (DUMP > 0) {
+      if (++since_dump == DUMP && ci0 + CI_T < p.Cin_p) {
+        since_dump = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc2[mb][nb] += acc[mb][nb];
+            acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+    }
+  }
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
   }
   // epilogue (low-res): + bias, activation
   const long long oplane = (long long)p.Hl * p.Wl;
@@ -288,7 +317,7 @@ struct TCfg {
 
 constexpr int S2_AFF_MAXC = 512;
 template <class Cfg, bool AFF = false>
-__global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel(S2Args p) {
+__global__ __launch_bounds__(256, (Cfg::MB <= 2 && !GL_ACC_DUMP ? 3 : 2)) void conv_s2_up_kernel(S2Args p) {
   constexpr int MB = Cfg::MB, NBL = Cfg::NBL, CI_T = Cfg::CI_T, PLANE = Cfg::PLANE, RP = Cfg::RP, COP = Cfg::COP;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS + (AFF ? 2 * S2_AFF_MAXC : 0)];
@@ -346,6 +375,18 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // second-level sums (conv.hip, GL_ACC_DUMP): an output of one parity contracts 4 taps * Cin terms
+  constexpr int DUMP = GL_ACC_DUMP ? GL_ACC_DUMP_TERMS / (4 * CI_T) : 0;
+  [[maybe_unused]] f32x4 acc2[DUMP ? 4 : 1][DUMP ? MB : 1][DUMP ? NBL : 1];
+  [[maybe_unused]] int since_dump = 0;
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBL; ++nb) acc2[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   float4 xr[XPT], wr[WPT];
   const __amdgpu_buffer_rsrc_t rs_x =
@@ -433,6 +474,28 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 ? 3 : 2)) void conv_s2_up_kernel
         }
       }
     }
+    if constexpr (DUMP > 0) {
+      if (++since_dump == DUMP && has_next) {
+        since_dump = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBL; ++nb) {
+              acc2[ph][mb][nb] += acc[ph][mb][nb];
+              acc[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+      }
+    }
+  }
+  if constexpr (DUMP > 0) {
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] += acc2[ph][mb][nb];
   }
   // epilogue (high-res): lane holds px = 0 and px = 1 of its low-res pixel -> float2 stores
   const int Wo = 2 * p.Wl;

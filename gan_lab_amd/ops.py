@@ -2442,22 +2442,42 @@ class _Mul(Function):
 
 
 class _Tanh(Function):
+    """nn.Tanh: the ResNet generators' output layer, and the hidden activation of ``--nonlinearity tanh``
+    (config.py:208,254; resnetgan/learner.py:180-181).  The backward is a Function of its own so that a gradient penalty
+    differentiates through it (a critic with tanh activations under WGAN-GP / R1)."""
     @staticmethod
     def forward(ctx, x):
         x = _c(x)
         y = torch.empty_like(x)
         check(_lib.lib().ganlab_tanh_fwd_f32(_p(x), _p(y), x.numel(), _st()), 'tanh_fwd')
         ctx.save_for_backward(y)
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
+        if g is None:
+            return None
         y, = ctx.saved_tensors
-        g = _c(g)
+        return _TanhBwd.apply(g, y)
+
+
+class _TanhBwd(Function):
+    """gx = g * (1 - y^2), y = tanh(x): linear in g, and d gx / d y = -2 g y (the second order of tanh)."""
+    @staticmethod
+    def forward(ctx, g, y):
+        g, y = _c(g), _c(y)
         gx = torch.empty_like(g)
         check(_lib.lib().ganlab_tanh_bwd_f32(_p(g), _p(y), _p(gx), g.numel(), _st()), 'tanh_bwd')
+        ctx.save_for_backward(g, y)
         return gx
+
+    @staticmethod
+    def backward(ctx, go):
+        g, y = ctx.saved_tensors
+        gg = _TanhBwd.apply(go, y) if ctx.needs_input_grad[0] else None
+        gy = scale(mul(mul(go, g), y), -2.0) if ctx.needs_input_grad[1] else None
+        return gg, gy
 
 
 def chan_affine(x, scale=None, shift=None):

@@ -21,7 +21,7 @@ from .._int import FMAP_SAMPLES, LearnerConfigCopy, get_current_configuration  #
 from ..optim import ParamArena
 from ..utils import backprop_utils as bp
 from ..utils.backprop_utils import configure_adam_for_gan
-from ..utils.custom_layers import LeakyReLU, make_downsampler, make_upsampler
+from ..utils.custom_layers import LeakyReLU, Tanh, make_downsampler, make_upsampler
 from ..utils.latent_utils import gen_rand_latent_vars
 
 NONREDEFINABLE_ATTRS = ('model', 'res_samples', 'res_dataset', 'len_latent', 'num_classes', 'class_condition',
@@ -72,8 +72,11 @@ class GANLearner(object):
             self.nl = LeakyReLU(negative_slope=config.leakiness)
         elif nl == 'relu':
             self.nl = LeakyReLU(negative_slope=0.)
+        elif nl == 'tanh':
+            self.nl = Tanh()
         else:
-            raise ValueError("config does not support this nonlinearity on the HIP path: [ 'leaky relu', 'relu' ]")
+            raise ValueError("config does not support this nonlinearity.\nSupported nonlinearities are: "
+                             "[ 'leaky relu', 'relu', 'tanh' ]")
 
         self.gen_model = None
         self.disc_model = None

@@ -8,19 +8,13 @@ containers; ``forward`` hands their children to the peephole executor so that
 from torch import nn
 
 from .. import ops
-from ..utils.custom_layers import (AvgPool2x, Conv2dEx, Lambda, LeakyReLU, NormalizeLayer, Upsample2x, own_resampler,
+from ..utils.custom_layers import (AvgPool2x, Conv2dEx, Lambda, LeakyReLU, NormalizeLayer, Upsample2x, own_nl, own_resampler,
                                    fused_sequential, get_blur_op)
 
 
 def _own_nl(nl):
-    """Accept the reference's nn.ReLU()/nn.LeakyReLU() instances as well as the HIP-path module."""
-    if nl is None or isinstance(nl, LeakyReLU):
-        return nl if nl is not None else LeakyReLU(0.)
-    if isinstance(nl, nn.ReLU):
-        return LeakyReLU(0.)
-    if isinstance(nl, nn.LeakyReLU):
-        return LeakyReLU(nl.negative_slope)
-    raise NotImplementedError(f'nonlinearity {nl!r} has no HIP kernel (ReLU / LeakyReLU only)')
+    """Accept the reference's nn.ReLU() / nn.LeakyReLU() / nn.Tanh() instances as well as the HIP-path modules."""
+    return own_nl(nl, default_slope=0.)
 
 
 _own_resampler = own_resampler

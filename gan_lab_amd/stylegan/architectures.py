@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import ops, rng
 from .._int import FMAP_SAMPLES, RES_INIT
-from ..utils.custom_layers import (Blur2d, Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer, Upsample2x,
+from ..utils.custom_layers import (Blur2d, Conv2dBias, Conv2dEx, Lambda, LeakyReLU, LinearEx, NormalizeLayer, Tanh, Upsample2x,
                                    fused_sequential, get_blur_op, own_resampler)
 from ..utils.latent_utils import gen_rand_latent_vars
 from .base import StyleGAN
@@ -241,6 +241,18 @@ class StyleGenerator(StyleGAN):
         act = mods.pop(0) if mods and isinstance(mods[0], LeakyReLU) else None
         bias_t = bias.bias if bias is not None else None
         bias_scale = (bias.lrmul if bias.use_lrmul else 1.0) if bias is not None else 1.0
+        if mods and isinstance(mods[0], Tanh):
+            # --nonlinearity tanh (config.py:254): no fused kernels for it - the layer composed from its parts
+            out = ops.materialize(out)
+            if n:
+                out = fused_sequential(list(layer[0]) if isinstance(layer[0], nn.Sequential) else [layer[0]], out)
+            nz = layer[1].draw(out, noise[n] if noise is not None else None) if self.use_noise else None
+            nw = layer[1].noise_weight if nz is not None else None
+            out = ops.tanh(ops.bias_act(out, bias_t, nz, nw, bias_scale=bias_scale, act=None))
+            if self.use_pixelnorm:
+                out = ops.pixelnorm(out)
+            y = layer[3](w)
+            return ops.instnorm_style(out, y, IN_EPS) if self.use_instancenorm else ops.style_mod(out, y)
         name = 'lrelu' if act is not None else None
         slope = act.negative_slope if act is not None else 0.2
         y = layer[3](w)                                                # (B, 2C) style

@@ -43,6 +43,30 @@ class LeakyReLU(nn.Module):
         return f'negative_slope={self.negative_slope}'
 
 
+class Tanh(nn.Module):
+    """nn.Tanh stand-in: ``--nonlinearity tanh`` as the hidden activation (config.py:208,254, resnetgan/learner.py:180-181).
+    Off the benchmark configurations: it runs as a pass of its own (no fold into the conv / normalisation kernels), first
+    and second order."""
+
+    def forward(self, x):
+        return ops.tanh(x)
+
+
+def own_nl(nl, default_slope=0.2):
+    """The reference's nn.ReLU() / nn.LeakyReLU() / nn.Tanh() instances (or ``None``) as HIP-path modules."""
+    if nl is None:
+        return LeakyReLU(default_slope)
+    if isinstance(nl, (LeakyReLU, Tanh)):
+        return nl
+    if isinstance(nl, nn.ReLU):
+        return LeakyReLU(0.)
+    if isinstance(nl, nn.LeakyReLU):
+        return LeakyReLU(nl.negative_slope)
+    if isinstance(nl, nn.Tanh):
+        return Tanh()
+    raise NotImplementedError(f'nonlinearity {nl!r} has no HIP kernel (ReLU / LeakyReLU / Tanh)')
+
+
 class Upsample2x(nn.Module):
     """nn.Upsample(scale_factor=2, mode='nearest') stand-in (fused into the following conv)."""
 

@@ -43,6 +43,12 @@ int ganlab_abi_version(void);
  * kernel launch made by this library.  Returns the symbol's length (it is truncated to cap-1 characters), 0 when
  * nothing was launched yet.  bench.py uses it to name the kernel its `roofline` prices from what was dispatched. */
 int ganlab_last_launch(char* name, int cap, unsigned* grid);
+/* Diagnostics for tests that assert WHICH kernels a step dispatched (an entry point may launch several: a weight
+ * gradient and its slot reduction): the number of kernels the calling thread has launched through this library so far,
+ * and the launch `back` positions before its most recent one (0 = what ganlab_last_launch reports; the library keeps
+ * the last 16; returns 0 beyond that). */
+unsigned long long ganlab_launch_count(void);
+int ganlab_launch_history(int back, char* name, int cap, unsigned* grid);
 
 /* Geometry of one convolution C(x, w) = scale * conv2d(up2?(x), w, stride 1, padding pad).
  * Replaces Conv2dEx.forward / LinearEx.forward (utils/custom_layers.py:202-211, :282-291) with the

@@ -4,7 +4,9 @@ driven from reference-layout ``state_dict``s; reference paths relative to /root/
 Pinned by tests/golden/resnet{32,64}.npz (made by tests/golden/make_golden.py from the reference).
 
 Only the default configuration of config #5 is restated: equalized_lr False (so no runtime weight
-scale: custom_layers.py:171-195 leaves wscale None), blur_type None, ReLU, no class conditioning.
+scale: custom_layers.py:171-195 leaves wscale None), blur_type None, no class conditioning; the hidden nonlinearity is
+ReLU, or ``nl='tanh'`` / ``('leaky relu', slope)`` (config.py:208, resnetgan/learner.py:176-181; pinned by
+tests/golden/resnet32_tanh.npz).
 """
 import torch
 import torch.nn.functional as F
@@ -43,18 +45,28 @@ def _pool(x):
     return F.avg_pool2d(x, kernel_size=2, stride=2)
 
 
-def _resblock(sd, p, x, norm, mode, pix32=False):
+def _nl(nl):
+    if nl in (None, 'relu'):
+        return F.relu
+    if nl == 'tanh':
+        return torch.tanh
+    if isinstance(nl, (tuple, list)) and nl[0] == 'leaky relu':
+        return lambda t: F.leaky_relu(t, negative_slope=float(nl[1]))
+    raise ValueError(nl)
+
+
+def _resblock(sd, p, x, norm, mode, pix32=False, act=F.relu):
     """ResBlock2d (resnetgan/resblocks.py:15-64; ResBlock2d32Pix :67-80).
     mode 'up':   [norm, relu, up, conv] -> [norm, relu, conv];        skip = [up, conv1x1]
     mode 'pool': [norm, relu, conv]     -> [norm, relu, conv, pool];  skip = [pool, conv1x1]
                  (32Pix: skip = [conv1x1, pool])
     mode None:   [norm, relu, conv]     -> [norm, relu, conv];        skip = conv1x1 if present else x"""
-    h = F.relu(norm(p + 'conv_layer_1.0', x))
+    h = act(norm(p + 'conv_layer_1.0', x))
     if mode == 'up':
         h = _conv(sd, p + 'conv_layer_1.3', _up(h))
     else:
         h = _conv(sd, p + 'conv_layer_1.2', h)
-    h = F.relu(norm(p + 'conv_layer_2.0', h))
+    h = act(norm(p + 'conv_layer_2.0', h))
     h = _conv(sd, p + 'conv_layer_2.2', h)
     if mode == 'pool':
         h = _pool(h)
@@ -69,8 +81,9 @@ def _resblock(sd, p, x, norm, mode, pix32=False):
     return s + h
 
 
-def gen_forward(sd, z, res=64, training=True, buffers=None):
+def gen_forward(sd, z, res=64, training=True, buffers=None, nl=None):
     """Generator32PixResnet / Generator64PixResnet (resnetgan/architectures.py:29-97)."""
+    act = _nl(nl)
     p = 'generator_model.'
     w = sd[p + '1.linear.weight']
     h = F.linear(z.view(-1, w.shape[1]), w, sd[p + '1.linear.bias'])
@@ -78,28 +91,29 @@ def gen_forward(sd, z, res=64, training=True, buffers=None):
     nblk = 4 if res == 64 else 3
     norm = lambda key, t: _bn(sd, key, t, training, buffers)  # noqa: E731
     for i in range(nblk):
-        h = _resblock(sd, f'{p}{3 + i}.', h, norm, 'up', pix32=(res == 32))
-    h = F.relu(norm(f'{p}{3 + nblk}', h))
+        h = _resblock(sd, f'{p}{3 + i}.', h, norm, 'up', pix32=(res == 32), act=act)
+    h = act(norm(f'{p}{3 + nblk}', h))
     return torch.tanh(_conv(sd, f'{p}{5 + nblk}', h))
 
 
-def disc_forward(sd, x, res=64):
+def disc_forward(sd, x, res=64, nl=None):
     """Discriminator32PixResnet / Discriminator64PixResnet (resnetgan/architectures.py:103-187)."""
+    act = _nl(nl)
     norm = lambda key, t: _ln(sd, key, t)  # noqa: E731
     x = x.view(-1, 3, res, res)
     if res == 64:
         h = _conv(sd, 'conv1', x)
         for i in range(4):
-            h = _resblock(sd, f'resblocks.{i}.', h, norm, 'pool')
+            h = _resblock(sd, f'resblocks.{i}.', h, norm, 'pool', act=act)
         h = h.reshape(h.shape[0], -1)
     else:
         # FastResBlock2dDownsample (resblocks.py:83-124): [conv, relu] -> [conv, pool]; skip [pool, conv1x1]
-        h1 = F.relu(_conv(sd, 'conv1.conv_layer_1.0', x))
+        h1 = act(_conv(sd, 'conv1.conv_layer_1.0', x))
         h = _pool(_conv(sd, 'conv1.conv_layer_2.0', h1)) + _conv(sd, 'conv1.skip_connection.1', _pool(x))
-        h = _resblock(sd, 'resblocks.0.', h, norm, 'pool', pix32=True)
-        h = _resblock(sd, 'resblocks.1.', h, norm, None, pix32=True)
-        h = _resblock(sd, 'resblocks.2.', h, norm, None, pix32=True)
-        h = F.relu(h).mean(dim=(2, 3))
+        h = _resblock(sd, 'resblocks.0.', h, norm, 'pool', pix32=True, act=act)
+        h = _resblock(sd, 'resblocks.1.', h, norm, None, pix32=True, act=act)
+        h = _resblock(sd, 'resblocks.2.', h, norm, None, pix32=True, act=act)
+        h = act(h).mean(dim=(2, 3))
     return F.linear(h, sd['linear1.linear.weight'], sd['linear1.linear.bias']).view(-1)
 
 
@@ -113,7 +127,8 @@ class ResnetFunctionalGAN:
     (backprop_utils.py:109-120), every random draw passed in.  No drift term, no EWMA."""
 
     def __init__(self, sd_g, sd_d, res=64, loss='wgan', gp='wgan-gp', lda=10.0, gamma=1.0, lr=1e-4, beta1=0.0,
-                 beta2=0.9, adam_eps=1e-8):
+                 beta2=0.9, adam_eps=1e-8, nl=None):
+        self.nl = nl
         self.g = {k: v.detach().clone().requires_grad_(True) for k, v in sd_g.items() if not _is_buffer(k)}
         self.g_buf = {k: v.detach().clone() for k, v in sd_g.items() if _is_buffer(k)}
         self.d = {k: v.detach().clone().requires_grad_(True) for k, v in sd_d.items()}
@@ -123,10 +138,10 @@ class ResnetFunctionalGAN:
         self.st_d = {k: _step.new_adam_state(v) for k, v in self.d.items()}
 
     def gen(self, z, training=True):
-        return gen_forward(self.g, z, self.res, training, self.g_buf)
+        return gen_forward(self.g, z, self.res, training, self.g_buf, self.nl)
 
     def disc(self, x, sd=None):
-        return disc_forward(self.d if sd is None else sd, x, self.res)
+        return disc_forward(self.d if sd is None else sd, x, self.res, self.nl)
 
     def _apply(self, params, states):
         with torch.no_grad():

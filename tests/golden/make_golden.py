@@ -658,14 +658,17 @@ def golden_schedule():
 RESNET_LATENT = 16
 
 
-def make_resnets(res, fmap_g, fmap_d):
+def make_resnets(res, fmap_g, fmap_d, nl=None):
+    """``nl``: None = the constructors' default nn.ReLU(); 'tanh' = nn.Tanh(), what resnetgan/learner.py:180-181 passes
+    for --nonlinearity tanh."""
     import resnetgan.architectures as ra
+    kw = {} if nl is None else {'nl': {'tanh': torch.nn.Tanh}[nl]()}
     if res == 64:
-        g = ra.Generator64PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g)
-        d = ra.Discriminator64PixResnet(fmap=fmap_d)
+        g = ra.Generator64PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g, **kw)
+        d = ra.Discriminator64PixResnet(fmap=fmap_d, **kw)
     else:
-        g = ra.Generator32PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g)
-        d = ra.Discriminator32PixResnet(fmap=fmap_d)
+        g = ra.Generator32PixResnet(len_latent=RESNET_LATENT, fmap=fmap_g, **kw)
+        d = ra.Discriminator32PixResnet(fmap=fmap_d, **kw)
     return g, d
 
 
@@ -679,13 +682,13 @@ def randomize_resnet(module, gen):
                 p.copy_(1. + torch.randn(p.shape, generator=gen) * 0.2)
 
 
-def golden_resnet(res, tag, fmap_g, fmap_d, b=4, lr=1e-3, n_iters=2, n_disc=2):
+def golden_resnet(res, tag, fmap_g, fmap_d, b=4, lr=1e-3, n_iters=2, n_disc=2, nl=None):
     """Forward / gradient vectors plus `n_iters` main iterations of GANLearner.train's loop body
     (resnetgan/learner.py:538-684: one G iteration with D frozen, then `n_disc` D iterations with
     WGAN + WGAN-GP), torch.optim.Adam(betas=(0,.9)), every random draw explicit."""
     torch.manual_seed(21 + res)
     gen = torch.Generator().manual_seed(2100 + res)
-    g, d = make_resnets(res, fmap_g, fmap_d)
+    g, d = make_resnets(res, fmap_g, fmap_d, nl)
     randomize_resnet(g, gen)
     randomize_resnet(d, gen)
     g.train()
@@ -822,6 +825,8 @@ if __name__ == '__main__':
         'checkpoint_sg': golden_checkpoint_stylegan,
         'resnet64': lambda: golden_resnet(64, 'resnet64', fmap_g=2, fmap_d=2),
         'resnet32': lambda: golden_resnet(32, 'resnet32', fmap_g=8, fmap_d=8),
+        # --nonlinearity tanh as the hidden activation (config.py:208, resnetgan/learner.py:180-181)
+        'resnet32_tanh': lambda: golden_resnet(32, 'resnet32_tanh', fmap_g=8, fmap_d=8, n_iters=1, nl='tanh'),
     }
     for name, fn in jobs.items():
         if a.only is None or a.only == name:

@@ -151,6 +151,8 @@ def _grad_errors(hip, ref, floor_frac=1e-3):
 
 
 MAX_TIE_CHANNELS = 2
+# generator entries of the learner-path case, judged as a set (see the test): median e_hip / e_cpu and worst e_hip
+G_MEDIAN_BAR, G_WORST_BAR = 5.0, 3e-2
 
 
 def _without_tie_channels(k, hip, ex, scale):
@@ -214,10 +216,10 @@ def _assert_ties_are_rare(rep, n_entries):
     assert len(ties) <= max(2, n_entries // 12), (len(ties), n_entries, ties)
 
 
-CASES = [('stylegan', 1024, 4, 'nonsaturating', 'r1'), ('progan', 256, 4, 'wgan', 'wgan-gp')]
+CASES = [('progan', 256, 4, 'wgan', 'wgan-gp')]
 
 
-@pytest.mark.parametrize('kind,res,b,loss,gp', CASES, ids=['stylegan1024-b4-r1', 'progan256-b4-wgangp'])
+@pytest.mark.parametrize('kind,res,b,loss,gp', CASES, ids=['progan256-b4-wgangp'])
 def test_full_width_step_vs_oracle(kind, res, b, loss, gp, capsys):
     g, d, sd_g, sd_d = _build(kind, res)
     gen = torch.Generator().manual_seed(2024)
@@ -301,26 +303,89 @@ def test_stylegan128_bf16_b8_step_vs_oracle(capsys):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# the code path bench.py times: the LEARNER's d_step / g_step at full width, two minibatch-stddev groups
+# the code path bench.py times: the LEARNER's d_step / g_step at the headline geometry, full width
 # ---------------------------------------------------------------------------------------------------------------
-def test_learner_step_full_width_b8_vs_oracle(capsys):
+def _host_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 2)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+class _KernelCensus(object):
+    """Counts the kernel symbols dispatched through the C ABI while active: every entry point of the loaded library is
+    wrapped so that the launches the call made (``ganlab_launch_count`` / ``ganlab_launch_history``: per calling thread -
+    the autograd engine launches the backward from its own thread; an entry point may launch several kernels) are read
+    right after it."""
+
+    def __enter__(self):
+        from gan_lab_amd import _lib
+        self.L, self.saved, self.seen = _lib.lib(), {}, {}
+        self.saved_count = self.L.ganlab_launch_count
+        for name in _lib.SIGNATURES:
+            if name in ('ganlab_last_launch', 'ganlab_launch_count', 'ganlab_launch_history') or name.endswith('_size') or name.endswith('_workspace') or \
+                    name.endswith('_supported') or name.endswith('_plan') or name.endswith('_slots'):
+                continue
+            fn = getattr(self.L, name)
+            self.saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _lib=_lib):
+                before = int(self.saved_count())
+                rc = _fn(*a)
+                for sym, _ in _lib.launches_since(before):
+                    self.seen[sym] = self.seen.get(sym, 0) + 1
+                return rc
+            setattr(self.L, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.L, name, fn)
+        return False
+
+    def count(self, *needles):
+        return sum(n for sym, n in self.seen.items() if all(s in sym for s in needles))
+
+
+LEARNER_CASES = [(1024, 8)]
+
+
+@pytest.mark.parametrize('res,b', LEARNER_CASES, ids=[f'stylegan{r}-b{b}-learner' for r, b in LEARNER_CASES])
+def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
     """``ProGANLearner.d_step(defer_update=True)`` + ``g_step(d_update_pending=True)`` - flat arenas, FusedAdam,
-    ``no_grad_towards``, the shared D(real) forward, the deferred D update, train-mode generator with mixing
-    regularisation, EWMA - on the full-width StyleGAN-128 at batch 8 (TWO minibatch-stddev groups), fp32, against
-    ``oracle/step.py FunctionalGAN`` (gan_lab/progan/learner.py:734-943) driven with the same latents, noise (injected
-    through ``honour_noise_in_training``), mixing cut and real batch: losses, every gradient in both arenas (per-entry
-    float64 rule of this file), the Adam update of every parameter and the EWMA shadow."""
+    ``no_grad_towards``, ``direct_param_grads``, the shared D(real) forward, the deferred D update, train-mode generator
+    with mixing regularisation and injected noise, EWMA - on the full-width StyleGAN-1024 (BASELINE config #3's network,
+    TWO minibatch-stddev groups), fp32, against ``oracle/step.py FunctionalGAN`` (gan_lab/progan/learner.py:734-943,
+    gan_lab/resnetgan/learner.py:780-827) driven with the same latents, noise (``honour_noise_in_training``), mixing cut and
+    real batch: losses, logits, R1 value, every gradient in both arenas (per-entry float64 rule of this file), the Adam
+    update of every parameter and the EWMA shadow.
+
+    This is the code ``bench.py`` times.  The round-3 fused kernels only dispatch at these sizes - the blur-folded
+    rolling-window kernels (<= 16 channels, W % 64 == 0), fromRGB's backward inside the first conv's input gradient
+    (``RB_RGB``, only inside ``direct_param_grads``), the thin modulated layer - and had fused == composed evidence only
+    (VERDICT r03 weak 2): the census below asserts that each of them actually ran in this step.
+    The two oracle evaluations (fp32, float64) run in processes of their own next to the GPU's part
+    (tests/oracle_worker.py)."""
+    import os
+    import subprocess
+    import sys
     from gan_lab_amd import ops
     from gan_lab_amd.config import make_config
     from gan_lab_amd.stylegan.architectures import StyleAddNoise
     from gan_lab_amd.stylegan.learner import StyleGANLearner
-    from oracle import nets, step
-    res, b, lr = 128, 8, 1e-3
+    b = int(os.environ.get('GANLAB_TEST_LEARNER_BATCH', b))
+    lr = 1e-3
     torch.manual_seed(31)
     cfg = make_config('stylegan', dev='cuda', pin_memory=False, res_samples=res, res_dataset=res, init_res=res,
-                      batch_size=b, bs_dict={r: b for r in (4, 8, 16, 32, 64, 128)}, loss='nonsaturating',
-                      gradient_penalty='r1', lda=10., num_iters_save_model=10 ** 9, log_every=0, random_seed=5,
-                      cutoff_trunc_trick=4, lr_base=lr)
+                      batch_size=b, bs_dict={r: b for r in (4, 8, 16, 32, 64, 128, 256, 512, 1024)},
+                      loss='nonsaturating', gradient_penalty='r1', lda=10., num_iters_save_model=10 ** 9, log_every=0,
+                      random_seed=5, cutoff_trunc_trick=4, lr_base=lr)
     L = StyleGANLearner(cfg)
     with torch.no_grad():
         for k, p in list(L.gen_model.named_parameters()) + list(L.disc_model.named_parameters()):
@@ -343,84 +408,102 @@ def test_learner_step_full_width_b8_vs_oracle(capsys):
     nd = [torch.randn(*s, generator=gen) for s in shapes]
     ng = [torch.randn(*s, generator=gen) for s in shapes]
     real = torch.rand(b, 3, res, res, generator=gen) * 2 - 1
-    cut_d, cut_g = 5, 9
-
-    lr_factor = cfg.lr_fctr_dict[res]            # LambdaLR 'resolution dependent' (StyleGAN: 1.5 at 128)
+    cut_d, cut_g = 5, nl - 3
+    lr_factor = cfg.lr_fctr_dict[res]            # LambdaLR 'resolution dependent' (StyleGAN: 3 at 1024)
     for grp in L.opt_gen.param_groups + L.opt_disc.param_groups:
         grp['lr'] = lr * lr_factor
-    StyleAddNoise.honour_noise_in_training = True
+
+    # ---- the oracle, fp32 and float64, side by side in two processes ------------------------------------------------
+    t0 = time.time()
+    torch.save(dict(sd_g=sd_g, sd_d=sd_d, zd=zd, zg=zg, zmix_d=zmix_d, zmix_g=zmix_g, nd=nd, ng=ng, real=real,
+                    cut_d=cut_d, cut_g=cut_g, lr=lr, lr_factor=lr_factor, beta=L.beta, loss='nonsaturating', gp='r1',
+                    lda=10., eps_drift=.001), tmp_path / 'in.pt')
+    threads = max(1, _host_cpus() // 2)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'oracle_worker.py')
+    procs = {dt: subprocess.Popen([sys.executable, worker, str(tmp_path / 'in.pt'), str(tmp_path / f'{dt}.pt'), dt,
+                                   str(threads)]) for dt in ('float32', 'float64')}
     try:
-        L.set_requires_grad_disc(True)
-        ld = L.d_step(real.cuda(), zb=zd.cuda(), defer_update=True,
-                      gen_kwargs=dict(noise=[n.cuda() for n in nd], _mix=(cut_d, zmix_d.cuda())))
-        gd = {k: v.detach().cpu().clone() for k, v in L.arena_d.views_of(L.arena_d.gflat).items()}
-        L.set_requires_grad_disc(False)
-        lg = L.g_step(zb=zg.cuda(), d_update_pending=True,
-                      gen_kwargs=dict(noise=[n.cuda() for n in ng], _mix=(cut_g, zmix_g.cuda())))
-        gg = {k: v.detach().cpu().clone() for k, v in L.arena_g.views_of(L.arena_g.gflat).items()}
-    finally:
-        StyleAddNoise.honour_noise_in_training = False
-    torch.cuda.synchronize()
-    new_g = {k: v.detach().cpu() for k, v in L.gen_model.state_dict().items()}
-    new_d = {k: v.detach().cpu() for k, v in L.disc_model.state_dict().items()}
-    lag = {k: v.detach().cpu() for k, v in L.lagged_params.items()}
+        # ---- the learner's own step ---------------------------------------------------------------------------------
+        StyleAddNoise.honour_noise_in_training = True
+        taken = [0]
+        take = ops._take
 
-    def oracle(dt):
-        gan = step.FunctionalGAN({k: v.to(dt) for k, v in sd_g.items()}, {k: v.to(dt) for k, v in sd_d.items()},
-                                 nets.make_cfg(), model='stylegan', loss='nonsaturating', gp='r1', lda=10.,
-                                 eps_drift=.001, lr=lr)
-        old = torch.get_default_dtype()
-        torch.set_default_dtype(dt)
+        def counting(name, shape, like):
+            out = take(name, shape, like)
+            taken[0] += int(bool(ops._TAKEN.get(name)))
+            return out
+        ops._take = counting
         try:
-            o_ld, _ = gan.d_step(zd.to(dt), real.to(dt), [n.to(dt) for n in nd], lr_factor=lr_factor, cutoff_idx=cut_d,
-                                 z_mix=zmix_d.to(dt))
-            o_gd = {k: v.grad.detach().clone() for k, v in gan.d.items() if v.grad is not None}
-            o_lg = gan.g_step(zg.to(dt), [n.to(dt) for n in ng], lr_factor=lr_factor, beta=L.beta, cutoff_idx=cut_g,
-                              z_mix=zmix_g.to(dt))
+            with _KernelCensus() as census:
+                L.set_requires_grad_disc(True)
+                ld = L.d_step(real.cuda(), zb=zd.cuda(), defer_update=True,
+                              gen_kwargs=dict(noise=[n.cuda() for n in nd], _mix=(cut_d, zmix_d.cuda())))
+                gd = {k: v.detach().cpu().clone() for k, v in L.arena_d.views_of(L.arena_d.gflat).items()}
+                L.set_requires_grad_disc(False)
+                lg = L.g_step(zb=zg.cuda(), d_update_pending=True,
+                              gen_kwargs=dict(noise=[n.cuda() for n in ng], _mix=(cut_g, zmix_g.cuda())))
+                gg = {k: v.detach().cpu().clone() for k, v in L.arena_g.views_of(L.arena_g.gflat).items()}
         finally:
-            torch.set_default_dtype(old)
-        o_gg = {k: v.grad.detach().clone() for k, v in gan.g.items() if v.grad is not None}
-        return dict(ld=o_ld, lg=o_lg, gd=o_gd, gg=o_gg, g={k: v.detach() for k, v in gan.g.items()},
-                    d={k: v.detach() for k, v in gan.d.items()}, lag=gan.lagged)
+            StyleAddNoise.honour_noise_in_training = False
+            ops._take = take
+        torch.cuda.synchronize()
+        t1 = time.time()
+        new_g = {k: v.detach().cpu() for k, v in L.gen_model.state_dict().items()}
+        new_d = {k: v.detach().cpu() for k, v in L.disc_model.state_dict().items()}
+        lag = {k: v.detach().cpu() for k, v in L.lagged_params.items()}
+        ld, lg = ld.cpu(), lg.cpu()
+        n_params = len(L.arena_d.params) + len(L.arena_g.params)
+        del L
+        torch.cuda.empty_cache()
+        for dt, p in procs.items():
+            assert p.wait() == 0, f'the {dt} oracle process failed'
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+    cpu, ex = torch.load(tmp_path / 'float32.pt'), torch.load(tmp_path / 'float64.pt')
+    t2 = time.time()
 
-    cpu = oracle(torch.float32)
-    rep = dict(loss_d=rel_err(ld, cpu['ld']), loss_g=rel_err(lg, cpu['lg']))
+    # ---- which kernels ran (the dispatch the bench times) ---------------------------------------------------------------
+    must = {'fromRGB backward inside the first conv input gradient (RB_RGB)': ('conv_fwd_roll_blur_kernel<2',),
+            'conv + LeakyReLU + blur (critic top, forward)': ('conv_fwd_roll_blur_kernel<1',),
+            'upsample + conv + blur + layer tail (generator top, forward)': ('conv_s2_up_roll_blur_kernel<0',),
+            'pooled conv input gradient + blur^T + LeakyReLU derivative (critic top, backward)':
+                ('conv_s2_up_roll_blur_kernel<1',),
+            'thin modulated layer with its tail (generator top)': ('conv_fwd_rollmod_kernel',),
+            'rolling-window weight gradient': ('conv_wgrad_roll_kernel',),
+            'rolling-window stride-2 weight gradient': ('conv_s2_wgrad_roll_kernel',)}
+    ran = {what: census.count(*needles) for what, needles in must.items()}
+    rep = dict(loss_d=rel_err(ld, cpu['ld']), loss_g=rel_err(lg, cpu['lg']), kernels=ran,
+               direct_gradients=f'{taken[0]} of {n_params} parameters')
     ed, _ = _grad_errors(gd, cpu['gd'])
     eg, _ = _grad_errors(gg, cpu['gg'])
     rep['worst_d_grad'] = max(ed.items(), key=lambda kv: kv[1])
     rep['worst_g_grad'] = max(eg.items(), key=lambda kv: kv[1])
     bad_d, bad_g = [k for k, v in ed.items() if v > TOL], [k for k, v in eg.items() if v > TOL]
     still = {}
-    ex = None
-    if bad_d or bad_g:
-        ex = oracle(torch.float64)
-        if bad_d:        # the critic's own gradients: the strict per-entry rule of this file
-            s_, j, ties = _judge_outliers('d.', bad_d, gd, cpu['gd'], ex['gd'],
-                                          max(v.abs().max().item() for v in ex['gd'].values()))
+    if bad_d:        # the critic's own gradients: the strict per-entry rule of this file
+        s_, j, ties = _judge_outliers('d.', bad_d, gd, cpu['gd'], ex['gd'],
+                                      max(v.abs().max().item() for v in ex['gd'].values()))
+        still.update(s_)
+        rep.setdefault('lrelu_tie_channels', {}).update(ties)
+        rep['judged_d'] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
+    if bad_g:
+        # Every generator gradient of the G step is J_G^T applied to ONE vector, the critic's input gradient
+        # d loss / d image: all ~80 generator entries inherit ONE realisation of its rounding error, on the CPU fp32 path
+        # exactly as on the HIP path, so the generator entries are judged as a set: the strict per-entry rule where it
+        # holds, otherwise the common factor - median e_hip / e_cpu, both against float64 - within G_MEDIAN_BAR and no
+        # entry further than G_WORST_BAR from float64.  (Round 3: 5 and 3e-2, while the thick conv kernels carried ONE
+        # fmaf chain per output and rounded 2-2.5x worse than ATen; the chains are split now - tools/op_error_probe.py.)
+        s_, j, ties = _judge_outliers('g.', bad_g, gg, cpu['gg'], ex['gg'],
+                                      max(v.abs().max().item() for v in ex['gg'].values()))
+        rep.setdefault('lrelu_tie_channels', {}).update(ties)
+        rep['judged_g'] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
+        ratios = sorted(a / max(c, 1e-30) for a, c in j.values())
+        rep['g_common_mode'] = dict(median_ratio=round(ratios[len(ratios) // 2], 2), worst_e_hip='%.2e' % max(
+            a for a, _ in j.values()), entries_beyond_strict_rule=len(s_), entries=len(j))
+        if s_ and not (ratios[len(ratios) // 2] <= G_MEDIAN_BAR and max(a for a, _ in j.values()) <= G_WORST_BAR):
             still.update(s_)
-            rep.setdefault('lrelu_tie_channels', {}).update(ties)
-            rep['judged_d'] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
-        if bad_g:
-            # Every generator gradient of the G step is J_G^T applied to ONE vector, the critic's input gradient
-            # d loss / d image, and that vector is ill-conditioned in fp32 on ANY implementation: a handful of the
-            # critic's ~10^7 LeakyReLU inputs sit within rounding of zero and take the other slope than in float64.
-            # tools/dgrad_chain_probe.py (profiles/r03_dgrad_chain_probe.txt), the same full-width critic, L2 error of
-            # d loss / d image against float64: HIP 1.4e-4 .. 9.4e-4, CPU fp32 3.2e-4 .. 6.6e-4 over four (resolution,
-            # batch) draws, ratio 0.2 .. 2.6.  All ~60 generator entries inherit that ONE realisation, so an
-            # entry-by-entry 1.5x bound compares two random magnitudes on a single draw (see the module docstring); the
-            # generator entries are therefore judged as a set: the strict rule where it holds, otherwise the common
-            # factor - median e_hip / e_cpu - within 5 and no entry further than 3e-2 from float64.
-            # tests/test_gpu_nets.py::test_thin16_network_is_as_accurate_as_the_cpu_path pins the same property
-            # statistically over several draws on a network small enough for that.
-            s_, j, ties = _judge_outliers('g.', bad_g, gg, cpu['gg'], ex['gg'],
-                                          max(v.abs().max().item() for v in ex['gg'].values()))
-            rep.setdefault('lrelu_tie_channels', {}).update(ties)
-            rep['judged_g'] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
-            ratios = sorted(a / max(c, 1e-30) for a, c in j.values())
-            rep['g_common_mode'] = dict(median_ratio=round(ratios[len(ratios) // 2], 2), worst_e_hip='%.2e' % max(
-                a for a, _ in j.values()), entries_beyond_strict_rule=len(s_), entries=len(j))
-            if s_ and not (ratios[len(ratios) // 2] <= 5.0 and max(a for a, _ in j.values()) <= 3e-2):
-                still.update(s_)
     # Adam (beta1 = 0, first step) moves every element by lr * g / (|g| + eps), i.e. by ~lr * sign(g): the update is checked
     # where the SIGN of the gradient is certain - elements above 1e-3 of the tensor's largest and above 8x the largest
     # difference between the two fp32 paths on that tensor (the generator's entries carry the common-mode noise discussed
@@ -446,8 +529,12 @@ def test_learner_step_full_width_b8_vs_oracle(capsys):
     worst_lag = max(((lag[k] - cpu['lag'][k]).abs().max().item() / max(cpu['lag'][k].abs().max().item(), 1e-30), k)
                     for k in lag)
     rep['worst_ewma'] = worst_lag
+    rep['seconds'] = dict(hip=round(t1 - t0, 1), waited_for_oracle=round(t2 - t1, 1), oracle_f32=round(cpu['seconds'], 1),
+                          oracle_f64=round(ex['seconds'], 1), threads_each=threads)
     with capsys.disabled():
         print(f'\nlearner d_step + g_step, StyleGAN-{res} b{b} full width, vs FunctionalGAN:', rep)
+    assert all(n > 0 for n in ran.values()), ran
+    assert taken[0] >= 0.6 * n_params, rep['direct_gradients']
     assert rep['loss_d'] <= TOL and rep['loss_g'] <= TOL, rep
     assert not still, still
     _assert_ties_are_rare(rep, len(ed) + len(eg))

@@ -53,6 +53,14 @@ def test_chan_affine_mul_tanh():
     assert_close(y.cpu(), torch.tanh(a), 1e-6, 'tanh')
     y.backward(b.cuda())
     assert_close(xg.grad.cpu(), b * (1 - torch.tanh(a) ** 2), 1e-5, 'tanh bwd')
+    # second order (a gradient penalty through a tanh critic): L = sum (d<tanh(x), b> / dx)^2 against torch's own tanh
+    xg = a.clone().cuda().requires_grad_(True)
+    xr = a.clone().requires_grad_(True)
+    gg, = torch.autograd.grad((ops.tanh(xg) * b.cuda()).sum(), xg, create_graph=True)
+    gr, = torch.autograd.grad((torch.tanh(xr) * b).sum(), xr, create_graph=True)
+    (gg ** 2).sum().backward()
+    (gr ** 2).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, 1e-5, 'tanh second order')
     g = torch.randn(3, 4, 8, 8)
     assert_close(ops.global_avg_pool(g.cuda()).cpu(), g.mean(dim=(2, 3), keepdim=True), 1e-6, 'global avg pool')
 
@@ -133,24 +141,37 @@ def test_layer_norm_first_and_second_order(shape, fused_slope):
 
 
 # ---------------------------------------------------------------------------------------------- #
-def _nets(G, res):
+RESNET_CASES = [(32, None), (64, None), (32, 'tanh')]      # (resolution, --nonlinearity other than the default ReLU)
+RESNET_IDS = ['32', '64', '32-tanh']
+
+
+def _resnet_golden(res, nl):
+    return load_golden(f'resnet{res}.npz' if nl is None else f'resnet{res}_{nl}.npz')
+
+
+def _nets(G, res, nl=None):
+    from torch import nn
     from gan_lab_amd.resnetgan import architectures as A
+    kw = {} if nl is None else {'nl': {'tanh': nn.Tanh}[nl]()}     # the reference's own module instance is accepted
     if res == 64:
-        g = A.Generator64PixResnet(len_latent=int(G['len_latent']), fmap=int(G['fmap_g']))
-        d = A.Discriminator64PixResnet(fmap=int(G['fmap_d']))
+        g = A.Generator64PixResnet(len_latent=int(G['len_latent']), fmap=int(G['fmap_g']), **kw)
+        d = A.Discriminator64PixResnet(fmap=int(G['fmap_d']), **kw)
     else:
-        g = A.Generator32PixResnet(len_latent=int(G['len_latent']), fmap=int(G['fmap_g']))
-        d = A.Discriminator32PixResnet(fmap=int(G['fmap_d']))
+        g = A.Generator32PixResnet(len_latent=int(G['len_latent']), fmap=int(G['fmap_g']), **kw)
+        d = A.Discriminator32PixResnet(fmap=int(G['fmap_d']), **kw)
     g.load_state_dict(sub(G, 'g0.'))
     d.load_state_dict(sub(G, 'd0.'))
     return g.cuda().train(), d.cuda().train()
 
 
-@pytest.mark.parametrize('res', [32, 64])
-def test_resnet_nets_match_reference(res):
+@pytest.mark.parametrize('res,nl', RESNET_CASES, ids=RESNET_IDS)
+def test_resnet_nets_match_reference(res, nl):
+    """Forward, generator gradients, WGAN-GP value and its double-backward gradients against the reference's fixtures;
+    the tanh case is ``--nonlinearity tanh`` as the hidden activation (resnetgan/learner.py:180-181): first and second
+    order of ``ops.tanh`` inside whole networks."""
     from gan_lab_amd.utils import backprop_utils as bp
-    G = load_golden(f'resnet{res}.npz')
-    g, d = _nets(G, res)
+    G = _resnet_golden(res, nl)
+    g, d = _nets(G, res, nl)
     img = g(t(G['z']).cuda())
     assert_close(img.cpu(), G['img'], TOL, 'img')
     for k, v in sub(G, 'g_after_fwd.').items():
@@ -188,16 +209,17 @@ def make_learner(res, batch=4, **kw):
     return cfg, GANLearner
 
 
-@pytest.mark.parametrize('res', [32, 64])
-def test_resnet_training_iterations_match_reference(res):
+@pytest.mark.parametrize('res,nl', RESNET_CASES, ids=RESNET_IDS)
+def test_resnet_training_iterations_match_reference(res, nl):
     """Two main iterations (G step, then 2 critic steps each) from the reference's fixture.  Losses are
     checked against the reference's own values.  Parameter updates are judged against a float64 replay
     of the oracle: on these narrow nets torch's CPU fp32 BatchNorm backward is itself ~3e-3 away from
     the float64 result for the deep generator parameters (measured; the HIP path is ~1e-6 away), and
     Adam(beta1=0) turns a relative gradient error straight into a relative update error."""
     from oracle import resnet
-    G = load_golden(f'resnet{res}.npz')
-    cfg, Learner = make_learner(res, len_latent=int(G['len_latent']), lr_base=float(G['lr']))
+    G = _resnet_golden(res, nl)
+    cfg, Learner = make_learner(res, len_latent=int(G['len_latent']), lr_base=float(G['lr']),
+                                **({} if nl is None else {'nonlinearity': nl}))
     cfg.fmap_g, cfg.fmap_d = int(G['fmap_g']), int(G['fmap_d'])
     L = Learner(cfg)
     L.gen_model.load_state_dict(sub(G, 'g0.'))
@@ -206,7 +228,7 @@ def test_resnet_training_iterations_match_reference(res):
     L.gen_model.train()
     L.disc_model.train()
     dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}  # noqa: E731
-    gan = resnet.ResnetFunctionalGAN(dbl(sub(G, 'g0.')), dbl(sub(G, 'd0.')), res, lr=float(G['lr']))
+    gan = resnet.ResnetFunctionalGAN(dbl(sub(G, 'g0.')), dbl(sub(G, 'd0.')), res, lr=float(G['lr']), nl=nl)
     ok = {}
 
     def note(tag, params):

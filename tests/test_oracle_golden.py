@@ -253,11 +253,19 @@ def _grad_close(got, ref_by_key, tol, what):
         assert e <= tol, f'{what} {k}: rel err {e:.3e} > {tol:.1e}'
 
 
-@pytest.mark.parametrize('res', [32, 64])
-def test_resnet_nets_forward_backward_gp(res):
+RESNET_CASES = [(32, None), (64, None), (32, 'tanh')]      # (resolution, --nonlinearity other than the default ReLU)
+RESNET_IDS = ['32', '64', '32-tanh']
+
+
+def _resnet_golden(res, nl):
+    return load_golden(f'resnet{res}.npz' if nl is None else f'resnet{res}_{nl}.npz')
+
+
+@pytest.mark.parametrize('res,nl', RESNET_CASES, ids=RESNET_IDS)
+def test_resnet_nets_forward_backward_gp(res, nl):
     from oracle import resnet
-    g = load_golden(f'resnet{res}.npz')
-    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']))
+    g = _resnet_golden(res, nl)
+    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']), nl=nl)
     img = gan.gen(t(g['z']))
     assert_close(img, g['img'], TOL, 'img')
     for k, v in sub(g, 'g_after_fwd.').items():
@@ -279,11 +287,11 @@ def test_resnet_nets_forward_backward_gp(res):
     _grad_close(gan.d, {k[3:]: v for k, v in g.items() if k.startswith('gd.')}, 2e-4, 'D grad')
 
 
-@pytest.mark.parametrize('res', [32, 64])
-def test_resnet_training_iterations(res):
+@pytest.mark.parametrize('res,nl', RESNET_CASES, ids=RESNET_IDS)
+def test_resnet_training_iterations(res, nl):
     from oracle import resnet
-    g = load_golden(f'resnet{res}.npz')
-    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']))
+    g = _resnet_golden(res, nl)
+    gan = resnet.ResnetFunctionalGAN(sub(g, 'g0.'), sub(g, 'd0.'), res, lr=float(g['lr']), nl=nl)
     ok = {}
 
     def note(tag, params):
