@@ -88,7 +88,10 @@ __device__ __forceinline__ double gl_block_sum_256d(double v, double* red) {
 #ifndef GL_ACC_DUMP
 #define GL_ACC_DUMP 1
 #endif
-constexpr int GL_ACC_DUMP_TERMS = 144;
+#ifndef GL_ACC_DUMP_TERMS_V
+#define GL_ACC_DUMP_TERMS_V 144
+#endif
+constexpr int GL_ACC_DUMP_TERMS = GL_ACC_DUMP_TERMS_V;
 
 __device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 

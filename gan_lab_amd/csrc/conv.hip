@@ -385,6 +385,10 @@ struct FwdCfg {
   static constexpr bool STRIP = MB_ == 1 && XMODE_ != XSCALAR;
   // chunks per accumulator dump (0: single chain - the 1x1 / linear layers contract <= 512 terms, split-K'd further)
   static constexpr int DUMP = (GL_ACC_DUMP && KS_ == 3) ? (GL_ACC_DUMP_TERMS / (KK * CI_T) > 0 ? GL_ACC_DUMP_TERMS / (KK * CI_T) : 1) : 0;
+  // operand fragments of the next K-step requested before the MFMAs of this one (conv_fwd_kernel)
+#ifndef GL_FRAG_PREFETCH
+#define GL_FRAG_PREFETCH 1
+#endif
   static_assert(NB >= 1, "pixel tile too small");
 };
 
@@ -1005,45 +1009,16 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       afftab[AFF_MAXC + c] = p.in.aff_t[(long long)n0 * p.in.Cin + c];
     }
   }
-
-  for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    // every staging mode goes through the register prefetch
-    if constexpr (AFF) x_store<G, CI_T, PLANE, true, true>(xr, xst, Xs, tid, afftab, ci0, AFF_MAXC, p.in.Cin - ci0);
-    else x_store<G, CI_T, PLANE, true>(xr, xst, Xs, tid);
+  auto stage = [&](float* xs, float* ws, int ci0) {       // prefetch registers -> LDS
+    if constexpr (AFF) x_store<G, CI_T, PLANE, true, true>(xr, xst, xs, tid, afftab, ci0, AFF_MAXC, p.in.Cin - ci0);
+    else x_store<G, CI_T, PLANE, true>(xr, xst, xs, tid);
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
-      if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
-    __syncthreads();
-    if (ci0 + CI_T < c_end) {  // prefetch the next chunk: in flight during the MFMA phase below
-      load_x(ci0 + CI_T);
-      load_w(ci0 + CI_T);
-    }
-    // taps: ky is a real loop (bounds the compiler's hoisting of LDS reads, i.e. register pressure),
-    // kx and the 4-channel K-steps are unrolled with immediate LDS offsets
-#pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {
-      const float* wrow = Ws + ky * (KS * CI_T * COP) + aoff;
-      const float* xrow = Xs + ky * RP;
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-#pragma unroll
-        for (int c4 = 0; c4 < CI_T / 4; ++c4) {
-          float a[MB], b[NB];
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[(kx * CI_T + c4 * 4) * COP + mb * 16];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) b[nb] = xrow[c4 * 4 * PLANE + boff[nb] + kx];
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nb], a[mb], acc[mb][nb], 0, 0, 0);
-        }
-      }
-    }
-    if constexpr (DUMP > 0) {       // the chain of the last DUMP chunks joins the second-level sum and restarts
-      if (++since_dump == DUMP && ci0 + CI_T < c_end) {
+      if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(ws + wl[i]) = wr[i];
+  };
+  auto dump = [&](bool more) {        // the chain of the last DUMP chunks joins the second-level sum and restarts
+    if constexpr (DUMP > 0) {
+      if (++since_dump == DUMP && more) {
         since_dump = 0;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -1054,6 +1029,73 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
           }
       }
     }
+  };
+  // taps: ky is a real loop (bounds the compiler's hoisting of LDS reads, i.e. register pressure),
+  // kx and the 4-channel K-steps are unrolled with immediate LDS offsets
+  auto mfma_row = [&](const float* xs, const float* ws, int ky) {
+    const float* wrow = ws + ky * (KS * CI_T * COP) + aoff;
+    const float* xrow = xs + ky * RP;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+      for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+        float a[MB], b[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[mb] = wrow[(kx * CI_T + c4 * 4) * COP + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[nb] = xrow[c4 * 4 * PLANE + boff[nb] + kx];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nb], a[mb], acc[mb][nb], 0, 0, 0);
+      }
+    }
+  };
+
+  // The same K-steps with the operand fragments of step k+1 requested BEFORE the MFMAs of step k (two fragment sets, the
+  // chunk fully unrolled, order pinned): left to itself hipcc emits "ds_read, s_waitcnt lgkmcnt(0), 8 MFMAs" groups, one
+  // exposed LDS latency per 256 MFMA cycles that only the other waves of the SIMD cover - which the kernels with a second
+  // accumulator set (two waves per SIMD) have too few of.
+  auto mfma_chunk = [&](const float* xs, const float* ws) {
+    constexpr int NK = KK * (CI_T / 4);
+    float a[2][MB], b[2][NB];
+    auto fetch = [&](int k, int st) {
+      const int tap = k / (CI_T / 4), c4 = k % (CI_T / 4), ky = tap / KS, kx = tap % KS;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[st][mb] = ws[aoff + (tap * CI_T + c4 * 4) * COP + mb * 16];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[st][nb] = xs[ky * RP + c4 * 4 * PLANE + boff[nb] + kx];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if (k + 1 < NK) fetch(k + 1, (k + 1) & 1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[k & 1][nb], a[k & 1][mb], acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  constexpr bool FRAGPF = GL_FRAG_PREFETCH && KS == 3 && MB >= 2 && G::XMODE != XSCALAR;
+
+  for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    stage(Xs, Ws, ci0);   // every staging mode goes through the register prefetch
+    __syncthreads();
+    if (ci0 + CI_T < c_end) {  // prefetch the next chunk: in flight during the MFMA phase below
+      load_x(ci0 + CI_T);
+      load_w(ci0 + CI_T);
+    }
+    if constexpr (FRAGPF) {
+      mfma_chunk(Xs, Ws);
+    } else {
+#pragma unroll 1
+      for (int ky = 0; ky < KS; ++ky) mfma_row(Xs, Ws, ky);
+    }
+    dump(ci0 + CI_T < c_end);
   }
   if constexpr (DUMP > 0) {
 #pragma unroll

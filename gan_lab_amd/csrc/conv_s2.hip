@@ -99,6 +99,9 @@ struct S2Args {
 
 // TWL_ = 5: 32x8 low-res tiles; TWL_ = 4: 16x16 tiles for 16-pixel-wide outputs (a 32-wide tile would be half empty:
 // the 512->512 down layer at 32^2 ran at 63 TFLOP/s executed, its neighbours at 120+)
+#ifndef GL_S2_FRAG_PREFETCH
+#define GL_S2_FRAG_PREFETCH 1
+#endif
 template <int MB_, int TWL_ = 5>
 struct SCfg {
   static constexpr int MB = MB_, NB = 4, TWL = TWL_, TW = 1 << TWL_, TH = 256 / TW;
@@ -222,26 +225,54 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
       if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
     if (ci0 + CI_T < p.Cin_p) load(ci0 + CI_T);   // (issuing it inside the tap loop costs 20 VGPRs = the third workgroup)
-#pragma unroll 1
-    for (int a = 0; a < 4; ++a) {
-      const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
-      const float* wrow = Ws + a * (4 * CI_T * COP) + aoff;
-      const float* xrow = Xs + (py * 2) * CI_T * PL + dy * RPL;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
+    if constexpr (GL_S2_FRAG_PREFETCH) {
+      // operand fragments of K-step k+1 requested before the MFMAs of step k (conv.hip, mfma_chunk): two waves per SIMD do
+      // not cover an exposed LDS latency per group of MFMAs
+      constexpr int NK = 16 * (CI_T / 4);
+      float av[2][MB], bv[2][NB];
+      auto fetch = [&](int k, int st) {
+        const int tap = k / (CI_T / 4), c4 = k % (CI_T / 4), a = tap >> 2, b = tap & 3;
+        const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
         const int dx = cDY(b), px = cPY(b);
 #pragma unroll
-        for (int c4 = 0; c4 < CI_T / 4; ++c4) {
-          float av[MB], bv[NB];
+        for (int mb = 0; mb < MB; ++mb) av[st][mb] = Ws[a * (4 * CI_T * COP) + aoff + (b * CI_T + c4 * 4) * COP + mb * 16];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) av[mb] = wrow[(b * CI_T + c4 * 4) * COP + mb * 16];
+        for (int nb = 0; nb < NB; ++nb)
+          bv[st][nb] = Xs[(py * 2) * CI_T * PL + dy * RPL + (px * CI_T + c4 * 4) * PL + boff[nb] + dx];
+      };
+      fetch(0, 0);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bv[nb] = xrow[(px * CI_T + c4 * 4) * PL + boff[nb] + dx];
+      for (int k = 0; k < NK; ++k) {
+        if (k + 1 < NK) fetch(k + 1, (k + 1) & 1);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k & 1][mb], bv[k & 1][nb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 1
+      for (int a = 0; a < 4; ++a) {
+        const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
+        const float* wrow = Ws + a * (4 * CI_T * COP) + aoff;
+        const float* xrow = Xs + (py * 2) * CI_T * PL + dy * RPL;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int dx = cDY(b), px = cPY(b);
+#pragma unroll
+          for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+            float av[MB], bv[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = wrow[(b * CI_T + c4 * 4) * COP + mb * 16];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = xrow[(px * CI_T + c4 * 4) * PL + boff[nb] + dx];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+          }
         }
       }
     }
@@ -436,39 +467,71 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 && !GL_ACC_DUMP ? 3 : 2)) void c
       if (tid + i * 256 < Cfg::NWI) *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i];
     __syncthreads();
     const bool has_next = ci0 + CI_T < p.Cin_p;
-    // K-steps of 4 channels are a real loop (bounds register pressure); the 16 (phase, tap) combinations
-    // inside are unrolled with immediate LDS offsets and static accumulator indices
+    if constexpr (GL_S2_FRAG_PREFETCH) {
+      // the operand fragments of (K-step, phase, tap) combination i + 2 are requested before the MFMAs of combination i
+      // (conv.hip, mfma_chunk); the next chunk's loads go out behind the first K-step
+      constexpr int NC = 16 * (CI_T / 4), PD = 2;
+      float av[PD + 1][MB], bv[PD + 1][NBL];
+      auto fetch = [&](int i, int st) {
+        const int c4 = i >> 4, py = (i >> 3) & 1, px = (i >> 2) & 1, iy = (i >> 1) & 1, ix = i & 1;
+        const int dy = py == 0 ? (iy == 0 ? -1 : 0) : (iy == 0 ? 0 : 1);
+        const int a = py == 0 ? (iy == 0 ? 3 : 1) : (iy == 0 ? 2 : 0);
+        const int dx = px == 0 ? (ix == 0 ? -1 : 0) : (ix == 0 ? 0 : 1);
+        const int b = px == 0 ? (ix == 0 ? 3 : 1) : (ix == 0 ? 2 : 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[st][mb] = Ws[c4 * 4 * COP + aoff + ((a * 4 + b) * CI_T) * COP + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NBL; ++nb) bv[st][nb] = Xs[c4 * 4 * PLANE + boff[nb] + dy * RP + dx];
+      };
+#pragma unroll
+      for (int i = 0; i < PD; ++i) fetch(i, i % (PD + 1));
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        if (i + PD < NC) fetch(i + PD, (i + PD) % (PD + 1));
+        if (i == 16 && has_next) load(ci0 + CI_T);
+        const int st = i % (PD + 1), ph = (i >> 2) & 3;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NBL; ++nb)
+            acc[ph][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][mb], bv[st][nb], acc[ph][mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // K-steps of 4 channels are a real loop (bounds register pressure); the 16 (phase, tap) combinations
+      // inside are unrolled with immediate LDS offsets and static accumulator indices
 #pragma unroll 1
-    for (int c4 = 0; c4 < CI_T / 4; ++c4) {
-      // the next chunk's loads go out after the first K-step: nothing but LDS reads between the barrier and the
-      // first MFMA, and the address arithmetic runs under queued matrix work (2 workgroups per CU either way)
-      if (c4 == 1 && has_next) load(ci0 + CI_T);
-      const float* wc = Ws + c4 * 4 * COP + aoff;
-      const float* xc = Xs + c4 * 4 * PLANE;
+      for (int c4 = 0; c4 < CI_T / 4; ++c4) {
+        // the next chunk's loads go out after the first K-step: nothing but LDS reads between the barrier and the
+        // first MFMA, and the address arithmetic runs under queued matrix work (2 workgroups per CU either way)
+        if (c4 == 1 && has_next) load(ci0 + CI_T);
+        const float* wc = Ws + c4 * 4 * COP + aoff;
+        const float* xc = Xs + c4 * 4 * PLANE;
 #pragma unroll
-      for (int py = 0; py < 2; ++py) {
+        for (int py = 0; py < 2; ++py) {
 #pragma unroll
-        for (int px = 0; px < 2; ++px) {
+          for (int px = 0; px < 2; ++px) {
 #pragma unroll
-          for (int iy = 0; iy < 2; ++iy) {
-            // taps(0) = {(-1,3), (0,1)} ; taps(1) = {(0,2), (+1,0)}
-            const int dy = py == 0 ? (iy == 0 ? -1 : 0) : (iy == 0 ? 0 : 1);
-            const int a = py == 0 ? (iy == 0 ? 3 : 1) : (iy == 0 ? 2 : 0);
+            for (int iy = 0; iy < 2; ++iy) {
+              // taps(0) = {(-1,3), (0,1)} ; taps(1) = {(0,2), (+1,0)}
+              const int dy = py == 0 ? (iy == 0 ? -1 : 0) : (iy == 0 ? 0 : 1);
+              const int a = py == 0 ? (iy == 0 ? 3 : 1) : (iy == 0 ? 2 : 0);
 #pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
-              const int dx = px == 0 ? (ix == 0 ? -1 : 0) : (ix == 0 ? 0 : 1);
-              const int b = px == 0 ? (ix == 0 ? 3 : 1) : (ix == 0 ? 2 : 0);
-              float av[MB], bv[NBL];
+              for (int ix = 0; ix < 2; ++ix) {
+                const int dx = px == 0 ? (ix == 0 ? -1 : 0) : (ix == 0 ? 0 : 1);
+                const int b = px == 0 ? (ix == 0 ? 3 : 1) : (ix == 0 ? 2 : 0);
+                float av[MB], bv[NBL];
 #pragma unroll
-              for (int mb = 0; mb < MB; ++mb) av[mb] = wc[((a * 4 + b) * CI_T) * COP + mb * 16];
+                for (int mb = 0; mb < MB; ++mb) av[mb] = wc[((a * 4 + b) * CI_T) * COP + mb * 16];
 #pragma unroll
-              for (int nb = 0; nb < NBL; ++nb) bv[nb] = xc[boff[nb] + dy * RP + dx];
+                for (int nb = 0; nb < NBL; ++nb) bv[nb] = xc[boff[nb] + dy * RP + dx];
 #pragma unroll
-              for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NBL; ++nb)
-                  acc[py * 2 + px][mb][nb] =
-                      __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[py * 2 + px][mb][nb], 0, 0, 0);
+                  for (int nb = 0; nb < NBL; ++nb)
+                    acc[py * 2 + px][mb][nb] =
+                        __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[py * 2 + px][mb][nb], 0, 0, 0);
+              }
             }
           }
         }
@@ -772,7 +835,10 @@ int run_S(S2Args a, hipStream_t st) {
                              a.act, a.slope, st);
   if (a.Wl <= 16 && a.Cout > 32) return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
   if (a.Cout <= 16) return launch_s2<SCfg<1>>(conv_s2_down_kernel<SCfg<1>>, a, st);
-  if (a.Cout <= 32) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
+#ifndef GL_S2_DOWN_MB2_CIN
+#define GL_S2_DOWN_MB2_CIN 0
+#endif
+  if (a.Cout <= 32 || (GL_ACC_DUMP && a.Cin <= GL_S2_DOWN_MB2_CIN)) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
   return launch_s2<SCfg<4>>(conv_s2_down_kernel<SCfg<4>>, a, st);
 }
 

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256, (SR_NSLOTS == 6 ? 4 : 3)) void conv_s2_down_ro
     }
   };
 
+  // two accumulation chains of 128 products per output (tap rows 0-1, tap rows 2-3), added at the end: a single chain
+  // of 256 rounds 1.3x worse than ATen's blocked sums (tools/op_error_probe.py; common.h GL_ACC_DUMP)
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  [[maybe_unused]] f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   load_rows(0, 4);
   store_rows(0, 4);
   load_rows(4, 2);
@@ -165,8 +168,12 @@ __global__ __launch_bounds__(256, (SR_NSLOTS == 6 ? 4 : 3)) void conv_s2_down_ro
       for (int b = 0; b < 4; ++b) {
         const int v = b == 0 ? 2 : (b == 1 ? 0 : (b == 2 ? 3 : 1));     // b=0: O'[x], 1: E[x], 2: O'[x+1], 3: E[x+1]
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-          acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[s][blk][v], wreg[(a * 4 + b) * 4 + c4], acc[blk], 0, 0, 0);
+        for (int blk = 0; blk < 2; ++blk) {
+          if (GL_ACC_DUMP && g >= NG / 2)
+            accb[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[s][blk][v], wreg[(a * 4 + b) * 4 + c4], accb[blk], 0, 0, 0);
+          else
+            acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[s][blk][v], wreg[(a * 4 + b) * 4 + c4], acc[blk], 0, 0, 0);
+        }
       }
       // the next step's four high rows: issued a few groups INTO the loop (behind queued MFMAs, see conv_fwd_roll_kernel)
       if (g == 1) load_rows(4 * t + 6, t + 1 < nsteps ? 4 : 0);
@@ -180,13 +187,14 @@ __global__ __launch_bounds__(256, (SR_NSLOTS == 6 ? 4 : 3)) void conv_s2_down_ro
       u32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[blk][r] + bv;
+        float v = (GL_ACC_DUMP ? acc[blk][r] + accb[blk][r] : acc[blk][r]) + bv;
         if (p.act == GANLAB_ACT_LRELU) v = gl_lrelu(v, p.slope);
         o[r] = __float_as_uint(v);
       }
       // offset in the VGPR, soffset 0 (store-data hazard with an SGPR soffset: conv.hip, conv_fwd_strip2_kernel)
       __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo[blk] == SR_OOB ? vo[blk] : vo[blk] + orow, 0, 0);
       acc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accb[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                   // rows 4t .. 4t+3 are free for the next step's prefetch; 4t+6 .. 4t+9 complete
     if constexpr (SR_SLOTS == 6) {
