@@ -351,7 +351,18 @@ def host_cpu():
         pass
     usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     n_phys = len(cores) or max(1, logical // 2)
-    return model or 'unknown', min(n_phys, usable), usable
+    # the container's CPU quota (cgroup v2 cpu.max): a one-GPU box of the pool shows all 256 logical CPUs of the host but
+    # is granted 16 CPUs' worth of time - 128 threads on that only take turns.  `cores` of the record is what the
+    # baseline can actually use.
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    n = min(n_phys, usable)
+    return model or 'unknown', (min(n, quota) if quota else n), usable
 
 
 def cpu_baseline(torch, res, batch, steps=3):
@@ -388,7 +399,8 @@ def cpu_baseline(torch, res, batch, steps=3):
             'cpu_model': model, 'logical_cpus': usable, 'torch_threads': torch.get_num_threads(),
             'step_seconds': [round(t, 2) for t in times],
             'sample': f'G+D step of StyleGAN {res}^2 at batch {batch} (oracle/step.py FunctionalGAN, torch CPU fp32, '
-                      f'{n_phys} threads = physical cores of {model}): 1 warm-up + {steps} timed steps, median '
+                      f'{n_phys} threads = the physical cores of {model} this container may use [cgroup cpu.max]): 1 warm-up + '
+                      f'{steps} timed steps, median '
                       f'{med:.1f} s'}
 
 
@@ -397,7 +409,7 @@ def _baseline_record(torch, batch, images_per_step, times, what, model, n_phys, 
     return {'value': round(images_per_step / med, 5), 'unit': 'images/sec', 'cores': n_phys, 'kind': 'port',
             'cpu_model': model, 'logical_cpus': usable, 'torch_threads': torch.get_num_threads(),
             'step_seconds': [round(t, 2) for t in times],
-            'sample': f'{what} at batch {batch} (torch CPU fp32, {n_phys} threads = physical cores of {model}): '
+            'sample': f'{what} at batch {batch} (torch CPU fp32, {n_phys} threads = the usable physical cores of {model}): '
                       f'1 warm-up + {len(times) - 1} timed steps, median {med:.1f} s'}
 
 

@@ -54,6 +54,18 @@ enum { RB_PLAIN = 0, RB_BLUR = 1, RB_RGB = 2 };
 
 __device__ __forceinline__ float rb_act(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+#ifdef GL_PHASES   // tools/phase_probe_rb.py (debug builds only): accumulated time of the step's phases, wave 0 of each workgroup
+__device__ unsigned long long* rb_phase_buf;
+#define RB_PH_DECL unsigned long long rb_t = wall_clock64(), rb_ph[6] = {0, 0, 0, 0, 0, 0};
+#define RB_PH(i) { const unsigned long long rb_n = wall_clock64(); rb_ph[i] += rb_n - rb_t; rb_t = rb_n; }
+#define RB_PH_FLUSH(nsteps) if (threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) rb_phase_buf[(long long)blockIdx.x * 8 + i_] = rb_ph[i_]; \
+    rb_phase_buf[(long long)blockIdx.x * 8 + 6] = (nsteps); rb_phase_buf[(long long)blockIdx.x * 8 + 7] = wall_clock64(); }
+#else
+#define RB_PH_DECL
+#define RB_PH(i)
+#define RB_PH_FLUSH(nsteps)
+#endif
+
 // BLUR = false: the same wave-owns-a-column-block MFMA phase with a plain epilogue (+bias, activation, store) - the rolling
 // 3x3 kernel with half the LDS operand reads of conv.hip's conv_fwd_roll_kernel (wave owns a row).
 template <int MODE>
@@ -146,11 +158,13 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
   const int e_row = lane & 3, e_side = (lane >> 2) & 1;
   const int e_lane = (w * 4 + kk) * RB_RP + (e_side ? 64 : -1) + 3;
 
+  RB_PH_DECL
   load_rows(0, 4);
   store_rows(0, 4);
   load_rows(4, 2);
   store_rows(4, 2);
   __syncthreads();
+  RB_PH(0)
 
   for (int s = 0; s < nrun; ++s) {
     [[maybe_unused]] unsigned mb[4] = {0xffu, 0xffu, 0xffu, 0xffu};
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       if (f == 8) load_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    RB_PH(1)
     if constexpr (RGB) {
       __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the previous step's image rows neither
       store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
@@ -248,9 +263,13 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
         __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, 0);
         acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      RB_PH(2)
       __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read
+      RB_PH(3)
       store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
+      RB_PH(4)
       __syncthreads();
+      RB_PH(5)
       continue;
     }
     // ---- activation; publish what the neighbours need ----
@@ -268,7 +287,9 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
     if (kk < 2)   // lanes kk = 0: column -1, rows r; kk = 1: column 64
       *reinterpret_cast<float4*>(xe + ((kk * 4 + w) * 16 + co) * 4) = float4{acce[0], acce[1], acce[2], acce[3]};
     acce = f32x4{0.f, 0.f, 0.f, 0.f};
+    RB_PH(2)
     __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the exchange buffers are complete
+    RB_PH(3)
     store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);       // into the slots of rows 4s .. 4s+3
     // ---- horizontal blur (unnormalised [1 2 1]) ----
     float4 nl = float4{0.f, 0.f, 0.f, 0.f}, nr = nl;      // left neighbour of pixel 0 / right neighbour of pixel 15 (by row)
@@ -346,8 +367,11 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
           p.bits[(((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0 + w * 16) >> 4] = (unsigned short)nib;
       }
     }
+    RB_PH(4)
     __syncthreads();   // the ring holds rows 4s+4 .. 4s+9; the exchange buffers may be rewritten
+    RB_PH(5)
   }
+  RB_PH_FLUSH(nrun)
   if constexpr (RGB) {        // this workgroup's partial sums: lane groups, then waves (fixed order)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -422,6 +446,12 @@ int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, floa
   else GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_PLAIN>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
+
+#ifdef GL_PHASES
+extern "C" int ganlab_dbg_set_phase_buf_rb(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rb_phase_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 

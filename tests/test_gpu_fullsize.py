@@ -152,7 +152,7 @@ def _grad_errors(hip, ref, floor_frac=1e-3):
 
 MAX_TIE_CHANNELS = 2
 # generator entries of the learner-path case, judged as a set (see the test): median e_hip / e_cpu and worst e_hip
-G_MEDIAN_BAR, G_WORST_BAR = 5.0, 3e-2
+G_MEDIAN_BAR, G_WORST_BAR = 2.0, 1e-2
 
 
 def _without_tie_channels(k, hip, ex, scale):
@@ -171,7 +171,13 @@ def _without_tie_channels(k, hip, ex, scale):
         return None, []
     if per.numel() < 16:
         return None, []
-    limit = MAX_TIE_CHANNELS if per.numel() > 16 else 1        # a 16-channel layer: ONE channel at most
+    # How many flips to expect: two correct fp32 evaluations of a pre-activation differ by ~2e-7 of its scale (tools/
+    # flip_probe.py: 2.2e-7 .. 3.4e-7 on both paths), so ~1.6e-7 of a layer's activations sit on the other side of zero - one
+    # flip per ~6 M activations, on the CPU fp32 path as on this one (the probe counts 1 - 3 flipped bits per pass through
+    # the full-width 128^2 critic on either).  A layer's B * C * H * W activations spread their flips over C channels: up
+    # to MAX_TIE_CHANNELS channels per tensor, one more per 128 channels beyond 256 (a 512-channel layer: 4), ONE for a
+    # 16-channel layer.
+    limit = max(MAX_TIE_CHANNELS, per.numel() // 128) if per.numel() > 16 else 1
     order = per.argsort(descending=True)
     drop = [int(i) for i in order[:limit] if per[i] / scale > TOL]
     keep = torch.ones_like(per, dtype=torch.bool)
@@ -504,12 +510,14 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
             a for a, _ in j.values()), entries_beyond_strict_rule=len(s_), entries=len(j))
         if s_ and not (ratios[len(ratios) // 2] <= G_MEDIAN_BAR and max(a for a, _ in j.values()) <= G_WORST_BAR):
             still.update(s_)
-    # Adam (beta1 = 0, first step) moves every element by lr * g / (|g| + eps), i.e. by ~lr * sign(g): the update is checked
-    # where the SIGN of the gradient is certain - elements above 1e-3 of the tensor's largest and above 8x the largest
-    # difference between the two fp32 paths on that tensor (the generator's entries carry the common-mode noise discussed
-    # above; below that threshold a flipped sign is a full 2 * lr, on either path) - and must agree to 2 % of the step size;
-    # prev_torgb / prev_fromrgb are outside the optimiser in the stabilised phase and must not move
-    n_upd, worst_upd = 0, (0.0, None)
+    # Adam (beta1 = 0, first step): every element moves by lr * g / (|g| + eps).  Two checks.  (i) The optimiser's own
+    # arithmetic: the update the fused kernel made against that formula evaluated in float64 on the gradient IT was given
+    # (the arena's) - every element of every parameter, to 1e-3 of the step size (the parameter's own fp32 rounding).
+    # (ii) Against the oracle's update where the gradient's sign and size are certain on both paths - elements above 1e-3
+    # of the tensor's largest, above 8x the largest difference between the two fp32 paths on that tensor and above 100 eps
+    # (below that the step is not saturated at lr and follows the gradient's rounding) - to 2 % of the step size;
+    # prev_torgb / prev_fromrgb are outside the optimiser in the stabilised phase and must not move.
+    n_upd, worst_upd, worst_arith = 0, (0.0, None), (0.0, None)
     for tag, new, old, ref, grads, mine in (('g.', new_g, sd_g, cpu['g'], cpu['gg'], gg),
                                             ('d.', new_d, sd_d, cpu['d'], cpu['gd'], gd)):
         for k, v0 in old.items():
@@ -517,14 +525,20 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
             if du_ref.abs().max() == 0:
                 assert du.abs().max() == 0, tag + k
                 continue
+            gm = mine[k].double()
+            want = -(lr * lr_factor) * gm / (gm.abs() + 1e-8)
+            ea = ((du.double() - want).abs().max() / (lr * lr_factor)).item()
+            if ea > worst_arith[0]:
+                worst_arith = (ea, tag + k)
             g = grads[k]
-            m = g.abs() > max(1e-3 * g.abs().max().item(), 8.0 * (mine[k] - g).abs().max().item())
+            m = g.abs() > max(1e-3 * g.abs().max().item(), 8.0 * (mine[k] - g).abs().max().item(), 1e-6)
             if not bool(m.any()):
                 continue
             e = ((du - du_ref)[m].abs().max() / du_ref[m].abs().max()).item()
             n_upd += int(m.sum())
             if e > worst_upd[0]:
                 worst_upd = (e, tag + k)
+    rep['worst_update_arithmetic'] = worst_arith
     rep['worst_update'] = worst_upd
     worst_lag = max(((lag[k] - cpu['lag'][k]).abs().max().item() / max(cpu['lag'][k].abs().max().item(), 1e-30), k)
                     for k in lag)
@@ -539,5 +553,6 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
     assert not still, still
     _assert_ties_are_rare(rep, len(ed) + len(eg))
     assert len(ed) >= 20 and len(eg) >= 20 and n_upd > 10 ** 6
+    assert worst_arith[0] <= 1e-3, rep
     assert worst_upd[0] <= 2e-2, rep
     assert worst_lag[0] <= 1e-4, rep

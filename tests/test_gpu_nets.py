@@ -252,14 +252,12 @@ def test_thin16_network_is_as_accurate_as_the_cpu_path(capsys, monkeypatch):
     entries), for the CPU fp32 path exactly as for the HIP path, so a single draw compares two random numbers.  The test
     therefore looks at THREE independent draws (weights and data reseeded) and at float64 as the truth: per draw the
     median over the noisy entries (error > 1e-4 on either side, D and G) of e_hip / e_cpu.
-    What is asserted is the MEASURED property, tied to the per-op bound: against float64 the thin kernels' error EQUALS the
-    ATen CPU conv's (tools/op_error_probe.py: rms 2.14e-7 both for 16->16 - the same fmaf order), but this network's
-    body is 64-channel layers, whose 576 products are ONE fmaf chain in a single MFMA accumulator where the CPU library
-    keeps blocked partial sums: 1.96x the CPU error per op at 64 channels (2.5x at 512; a second accumulator set does
-    not fit the 168-VGPR budget of the three-workgroups-per-CU kernels).  Measured over four draws: 2.4, 3.0, 0.55, 4.8 - median
-    2.7.  The test fails if the median of the three ratios exceeds 3.5 or any entry of any draw is further than 1e-2 from
-    float64; the full-width networks (tests/test_gpu_fullsize.py, full-width-64 / thin-top-256 above) pass the strict
-    per-entry rule without any such factor."""
+    What is asserted: the median over the three draws of that per-draw ratio is <= 2.0 and no entry of any draw is further
+    than 1e-2 from float64.  The per-op basis (tools/op_error_probe.py, profiles/r04_op_error_probe.txt): against float64 every
+    conv kernel now rounds like the ATen CPU conv (rms ratio 0.94 .. 1.01 at 16, 32, 64 and 512 channels) - the thin kernels
+    always did (same fmaf order), the 32+-channel kernels since round 4 (second accumulator set: chains of <= 144 products,
+    csrc/common.h GL_ACC_DUMP; rounds 2-3 measured 1.4x / 1.96x / 2.5x at 32 / 64 / 512 channels, per-draw medians 2.4, 3.0,
+    0.55, 4.8 here and a bar of 3.5).  Measured with the split chains: 0.8, 1.35, 0.55."""
     import os
     import test_gpu_fullsize as FS
     from gan_lab_amd import _lib, progressive as P
@@ -305,5 +303,5 @@ def test_thin16_network_is_as_accurate_as_the_cpu_path(capsys, monkeypatch):
         print('\nthin 16-channel network, median e_hip / e_cpu (vs float64) per draw:', reps, 'worst |e_hip|', worst_abs)
     assert calls['mod'] >= 3 or os.environ.get('GANLAB_DEFER') == '0', calls     # the modulated 3x3 layer ran in every draw
     ratios.sort()
-    assert ratios[1] <= 3.5, reps
+    assert ratios[1] <= 2.0, reps
     assert worst_abs <= 1e-2, worst_abs
