@@ -30,6 +30,14 @@ constexpr int RB_TW = 64, RB_SLOTS = 6, RB_RP = 80, RB_SLOT = 16 * RB_RP, RB_Q =
 constexpr int RB_ITEMS = 4 * 16 * RB_Q;             // float4 items of one 4-row prefetch: 1152
 constexpr int RB_PT = (RB_ITEMS + 255) / 256;       // 5
 constexpr int RB_OOB = (int)0x80000000;
+// cache policy of the output stores / input loads (aux 2 = nt): measured in round 4 on 16 -> 16 at 1024^2 x 32 - nt stores
+// 1.318 against 1.31 ms, nt loads 1.44 ms (the column-halo re-reads then miss the L2): both stay at the default policy
+#ifndef RB_STORE_AUX
+#define RB_STORE_AUX 0
+#endif
+#ifndef RB_LOAD_AUX
+#define RB_LOAD_AUX 0
+#endif
 
 struct RBArgs {
   const float* x;
@@ -56,10 +64,10 @@ __device__ __forceinline__ float rb_act(float v, float slope) { return v > 0.f ?
 
 #ifdef GL_PHASES   // tools/phase_probe_rb.py (debug builds only): accumulated time of the step's phases, wave 0 of each workgroup
 __device__ unsigned long long* rb_phase_buf;
-#define RB_PH_DECL unsigned long long rb_t = wall_clock64(), rb_ph[6] = {0, 0, 0, 0, 0, 0};
+#define RB_PH_DECL unsigned long long rb_t = wall_clock64(), rb_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RB_PH(i) { const unsigned long long rb_n = wall_clock64(); rb_ph[i] += rb_n - rb_t; rb_t = rb_n; }
-#define RB_PH_FLUSH(nsteps) if (threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) rb_phase_buf[(long long)blockIdx.x * 8 + i_] = rb_ph[i_]; \
-    rb_phase_buf[(long long)blockIdx.x * 8 + 6] = (nsteps); rb_phase_buf[(long long)blockIdx.x * 8 + 7] = wall_clock64(); }
+#define RB_PH_FLUSH(nsteps) if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) rb_phase_buf[(long long)blockIdx.x * 12 + i_] = rb_ph[i_]; \
+    rb_phase_buf[(long long)blockIdx.x * 12 + 10] = (nsteps); rb_phase_buf[(long long)blockIdx.x * 12 + 11] = wall_clock64(); }
 #else
 #define RB_PH_DECL
 #define RB_PH(i)
@@ -77,6 +85,10 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
   __shared__ __attribute__((aligned(16))) float ring[RB_SLOTS * RB_SLOT];       // 30720 B
   __shared__ __attribute__((aligned(16))) float xn[2 * 4 * 16 * 4];             // [side][wave][co][row]: own edge pixels
   __shared__ __attribute__((aligned(16))) float xe[2 * 4 * 16 * 4];             // [side][wave][co][row]: outside columns, partial
+  // sign bits of a step, [row of the step][co][8 bytes = the strip's 64 pixels]: the waves drop their bytes here and wave 0
+  // writes the step's 64 x 8 bytes with ONE store at the top of the next step (four 2-byte stores per wave and step before:
+  // 2.1 of the 10.5 us of a step, tools/phase_probe_rb.py)
+  __shared__ __attribute__((aligned(8))) unsigned char bits_s[BLUR ? 4 * 16 * 8 : 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int co = lane & 15, kk = lane >> 4;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       const int vy = Y0 - RO - 1 + rel0 + lo_k[i];
       const bool ok = gbase[i] != RB_OOB && lo_k[i] < nrows && (unsigned)vy < (unsigned)p.H;
       const int off = ok ? gbase[i] + (int)((unsigned)vy * (unsigned)(p.W * 4)) : RB_OOB;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, RB_LOAD_AUX);
       xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
   };
@@ -158,6 +170,17 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
   const int e_row = lane & 3, e_side = (lane >> 2) & 1;
   const int e_lane = (w * 4 + kk) * RB_RP + (e_side ? 64 : -1) + 3;
 
+  [[maybe_unused]] auto flush_bits = [&](int sp) {       // wave 0: lane = (row of step sp) * 16 + co
+    if constexpr (BLUR) {
+      if (p.bits != nullptr && w == 0) {
+        const int r4 = lane >> 4, row = Y0 - 1 + 4 * sp + r4;
+        if (co_ok && row >= Y0 && row < Y0 + 4 * ns) {
+          const uint2 v = *reinterpret_cast<const uint2*>(bits_s + (r4 * 16 + co) * 8);
+          *reinterpret_cast<uint2*>(p.bits + ((((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0) >> 4)) = v;
+        }
+      }
+    }
+  };
   RB_PH_DECL
   load_rows(0, 4);
   store_rows(0, 4);
@@ -167,6 +190,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
   RB_PH(0)
 
   for (int s = 0; s < nrun; ++s) {
+    if (s > 0) flush_bits(s - 1);
     [[maybe_unused]] unsigned mb[4] = {0xffu, 0xffu, 0xffu, 0xffu};
     if constexpr (RGB) {      // the tail's memory operands, requested before the MFMA phase
       if (img_item >= 0)
@@ -250,6 +274,9 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
     }
     if constexpr (!BLUR) {
       // ---- plain epilogue: +bias, activation, 16-byte stores of the four rows ----
+      // (tried in round 4: the rows through an LDS tile, leaving as 256-byte runs from inside the next step's MFMA loop -
+      // +1 %; a build WITHOUT the stores runs 1.13 instead of 1.35 ms: what the kernel pays is the 2 GiB of write traffic
+      // next to its 2 GiB of reads, not the shape of the store instructions)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int row = Y0 + 4 * s + r4;
@@ -260,7 +287,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
           if (p.act == GANLAB_ACT_LRELU) t = gl_lrelu(t, p.slope);
           o[r] = __float_as_uint(t);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, RB_STORE_AUX);
         acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       RB_PH(2)
@@ -291,6 +318,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
     __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the exchange buffers are complete
     RB_PH(3)
     store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);       // into the slots of rows 4s .. 4s+3
+    RB_PH(6)
     // ---- horizontal blur (unnormalised [1 2 1]) ----
     float4 nl = float4{0.f, 0.f, 0.f, 0.f}, nr = nl;      // left neighbour of pixel 0 / right neighbour of pixel 15 (by row)
     if (kk == 0) {
@@ -337,6 +365,7 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       hb[r4][2] = v[r4][1] + 2.f * v[r4][2] + v[r4][3];
       hb[r4][3] = v[r4][2] + 2.f * v[r4][3] + r;
     }
+    RB_PH(7)
     // ---- vertical blur, one row behind: output rows Y0 - 2 + 4s + i from (c0, c1, hb[0..3]) ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -348,29 +377,27 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
         u32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = __float_as_uint((a[r] + 2.f * b[r] + c[r]) * 0.0625f);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, RB_STORE_AUX);
       }
     }
     c0 = hb[2];
     c1 = hb[3];
-    // ---- sign bits of the activation rows this strip owns ----
+    RB_PH(8)
+    // ---- sign bits of the activation rows of this step: one byte per lane pair (8 pixels) into bits_s ----
     if (p.bits != nullptr) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = Y0 - 1 + 4 * s + r4;
         unsigned nib = (v[r4][0] > 0.f ? 1u : 0u) | (v[r4][1] > 0.f ? 2u : 0u) | (v[r4][2] > 0.f ? 4u : 0u) |
                        (v[r4][3] > 0.f ? 8u : 0u);
-        nib <<= 4 * kk;
-        nib |= __shfl_xor(nib, 16, 64);
-        nib |= __shfl_xor(nib, 32, 64);
-        if (kk == 0 && co_ok && row >= Y0 && row < Y0 + 4 * ns)
-          p.bits[(((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0 + w * 16) >> 4] = (unsigned short)nib;
+        const unsigned hi = __shfl_down(nib, 16, 64);          // lane group kk + 1: the next four pixels
+        if ((kk & 1) == 0) bits_s[(r4 * 16 + co) * 8 + w * 2 + (kk >> 1)] = (unsigned char)(nib | (hi << 4));
       }
     }
-    RB_PH(4)
+    RB_PH(9)
     __syncthreads();   // the ring holds rows 4s+4 .. 4s+9; the exchange buffers may be rewritten
     RB_PH(5)
   }
+  if (nrun > 0) flush_bits(nrun - 1);
   RB_PH_FLUSH(nrun)
   if constexpr (RGB) {        // this workgroup's partial sums: lane groups, then waves (fixed order)
 #pragma unroll
