@@ -376,7 +376,10 @@ struct FwdCfg {
   static constexpr int CO_T = 16 * MB_;
   // scalar staging keeps 3 registers per patch element in flight (global offset, LDS offset, value): 8-channel
   // chunks bound that at ~55 registers for the 4x4x16-image geometry
-  static constexpr int CI_T = (KS_ == 1) ? 32 : ((MB_ == 1 && XMODE_ != XSCALAR) ? 16 : 8);
+#ifndef GL_THICK_CI_T       // 16-channel chunks for the two-workgroups-per-CU thick kernel (half the barriers, 72 KB of LDS):
+#define GL_THICK_CI_T 8     // measured slower in round 4 (plain 64..512-channel layers: 5.90 against 5.79 ms), stays 8
+#endif
+  static constexpr int CI_T = (KS_ == 1) ? 32 : ((MB_ == 1 && XMODE_ != XSCALAR) ? 16 : ((MB_ == 4 && XMODE_ == XVEC && GL_ACC_DUMP) ? GL_THICK_CI_T : 8));
   static constexpr int PLANE = pad_mod32(G::NI * G::IMG, 16);
   static constexpr int COP = pad_mod32(CO_T, 16);
   static constexpr int XS = CI_T * PLANE, WS = KK * CI_T * COP;
@@ -937,13 +940,18 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
   // ---- staging descriptors (independent of the K-chunk) ----
   XS_t xst;
   xst.init(p.in, tid, n0, oy0, ox0);
-  int wg[WPT], wl[WPT];
+  // (one tap per 256 threads when a tap's slab is exactly 256 float4 items: the descriptors are affine in i and need no
+  // registers of their own)
+  constexpr bool WAFF = CI_T * (CO_T / 4) == 256;
+  int wg[WAFF ? 1 : WPT], wl[WAFF ? 1 : WPT];
+  [[maybe_unused]] const int wg_step = p.Cin_p * p.Cout_p;
 #pragma unroll
   for (int i = 0; i < WPT; ++i) {
     const int e = tid + i * 256;
     const int c4 = e % (CO_T / 4);
     const int t = e / (CO_T / 4);
     const int ci = t % CI_T, tap = t / CI_T;
+    if (WAFF && i > 0) break;
     wl[i] = (tap * CI_T + ci) * COP + 4 * c4;
     wg[i] = e < NWI ? (tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4 : -1;
   }
@@ -987,11 +995,13 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       if constexpr (DESC) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wg[i] >= 0 ? wg[i] * 4 : (int)0x80000000,
+        const int wgi = WAFF ? wg[0] + i * wg_step : wg[i];
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wgi >= 0 ? wgi * 4 : (int)0x80000000,
                                                               ci0 * p.Cout_p * 4, 0);
         wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
       } else {
-        wr[i] = wg[i] >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wg[i])
+        const int wgi = WAFF ? wg[0] + i * wg_step : wg[i];
+        wr[i] = wgi >= 0 ? *reinterpret_cast<const float4*>(p.wp + (long long)ci0 * p.Cout_p + wgi)
                            : float4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
     else x_store<G, CI_T, PLANE, true>(xr, xst, xs, tid);
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
-      if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(ws + wl[i]) = wr[i];
+      if (tid + i * 256 < NWI) *reinterpret_cast<float4*>(ws + (WAFF ? wl[0] + i * CI_T * COP : wl[i])) = wr[i];
   };
   auto dump = [&](bool more) {        // the chain of the last DUMP chunks joins the second-level sum and restarts
     if constexpr (DUMP > 0) {
