@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // second-level sums of the accumulation chains (conv.hip, GL_ACC_DUMP): a 16-tap output contracts 16 * Cin terms
-  constexpr int DUMP = GL_ACC_DUMP ? GL_ACC_DUMP_TERMS / (16 * CI_T) : 0;
+  // (three 64-term chunks per dump: chains of 192 + 16 Cin / 192 second-level terms stay within 1.25x of a 144-term chain's
+  // rounding error for every Cin <= 512, with a third fewer passes over the accumulators)
+  constexpr int DUMP = GL_ACC_DUMP ? (GL_ACC_DUMP_TERMS + 48) / (16 * CI_T) : 0;
   [[maybe_unused]] f32x4 acc2[DUMP ? MB : 1][DUMP ? NB : 1];
   [[maybe_unused]] int since_dump = 0;
   if constexpr (DUMP > 0) {
@@ -833,7 +835,16 @@ int run_S(S2Args a, hipStream_t st) {
   if (gl_s2_roll_supported(0, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.x, a.y))
     return gl_s2_roll_launch(0, a.x, a.wp, a.bias, a.y, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.Cin_p, a.Cout_p, a.bias_scale,
                              a.act, a.slope, st);
-  if (a.Wl <= 16 && a.Cout > 32) return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
+  if (a.Wl <= 16 && a.Cout > 32) {
+    // 16-wide outputs: one 16x16 tile per image.  With 64-channel tiles 512 -> 512 at batch 32 is 256 workgroups - one per
+    // CU, nothing to cover its stalls (0.67 of the peak); 32-channel tiles make it 512, two per CU (GL_S2_DOWN_W16_MB2=0: A/B)
+#ifndef GL_S2_DOWN_W16_MB2
+#define GL_S2_DOWN_W16_MB2 1
+#endif
+    const long long wg64 = (long long)ceil_div(a.Wl, 16) * ceil_div(a.Hl, 16) * a.N * ceil_div(a.Cout, 64);
+    if (GL_S2_DOWN_W16_MB2 && wg64 < 512) return launch_s2<SCfg<2, 4>>(conv_s2_down_kernel<SCfg<2, 4>>, a, st);
+    return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
+  }
   if (a.Cout <= 16) return launch_s2<SCfg<1>>(conv_s2_down_kernel<SCfg<1>>, a, st);
 #ifndef GL_S2_DOWN_MB2_CIN
 #define GL_S2_DOWN_MB2_CIN 0
