@@ -102,6 +102,9 @@ struct S2Args {
 #ifndef GL_S2_FRAG_PREFETCH
 #define GL_S2_FRAG_PREFETCH 1
 #endif
+#ifndef GL_S2_UP_NBL1
+#define GL_S2_UP_NBL1 0
+#endif
 template <int MB_, int TWL_ = 5>
 struct SCfg {
   static constexpr int MB = MB_, NB = 4, TWL = TWL_, TW = 1 << TWL_, TH = 256 / TW;
@@ -862,6 +865,9 @@ int run_T(S2Args a, hipStream_t st) {
     return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>, true>, a, st);
   }
   if (a.Cout <= 16) return launch_s2<TCfg<1, 4>>(conv_s2_up_kernel<TCfg<1, 4>>, a, st);
+#if GL_S2_UP_NBL1
+  return launch_s2<TCfg<2, 1>>(conv_s2_up_kernel<TCfg<2, 1>>, a, st);
+#endif
   if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
   // 32 output channels per workgroup for the thick layers as well: the 64-channel tile keeps 128 accumulator registers
   // (219 VGPRs, two workgroups per CU) and measured 3-4 % slower on every layer than this one (123 VGPRs, four per CU)
