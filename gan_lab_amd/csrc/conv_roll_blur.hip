@@ -38,6 +38,9 @@ constexpr int RB_OOB = (int)0x80000000;
 #ifndef RB_LOAD_AUX
 #define RB_LOAD_AUX 0
 #endif
+#ifndef RB_SETPRIO
+#define RB_SETPRIO 0
+#endif
 
 struct RBArgs {
   const float* x;
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
   // sign bits of a step, [row of the step][co][8 bytes = the strip's 64 pixels]: the waves drop their bytes here and wave 0
   // writes the step's 64 x 8 bytes with ONE store at the top of the next step (four 2-byte stores per wave and step before:
   // 2.1 of the 10.5 us of a step, tools/phase_probe_rb.py)
-  __shared__ __attribute__((aligned(8))) unsigned char bits_s[BLUR ? 4 * 16 * 8 : 8];
+  __shared__ __attribute__((aligned(16))) unsigned bits_s[BLUR ? 16 * 8 : 4];      // [co][8 byte positions of the strip] x 4 row bytes
+  __shared__ __attribute__((aligned(16))) float scratch_s[BLUR ? 256 * 4 : 4];     // one 16-byte slot per thread for writes that do not apply
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int co = lane & 15, kk = lane >> 4;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
@@ -174,10 +178,13 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
     if constexpr (BLUR) {
       if (p.bits != nullptr && w == 0) {
         const int r4 = lane >> 4, row = Y0 - 1 + 4 * sp + r4;
-        if (co_ok && row >= Y0 && row < Y0 + 4 * ns) {
-          const uint2 v = *reinterpret_cast<const uint2*>(bits_s + (r4 * 16 + co) * 8);
-          *reinterpret_cast<uint2*>(p.bits + ((((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0) >> 4)) = v;
-        }
+        const uint4 lo = *reinterpret_cast<const uint4*>(bits_s + co * 8), hi = *reinterpret_cast<const uint4*>(bits_s + co * 8 + 4);
+        const int sh = 8 * r4;
+        uint2 o;
+        o.x = ((lo.x >> sh) & 0xffu) | (((lo.y >> sh) & 0xffu) << 8) | (((lo.z >> sh) & 0xffu) << 16) | (((lo.w >> sh) & 0xffu) << 24);
+        o.y = ((hi.x >> sh) & 0xffu) | (((hi.y >> sh) & 0xffu) << 8) | (((hi.z >> sh) & 0xffu) << 16) | (((hi.w >> sh) & 0xffu) << 24);
+        if (co_ok && row >= Y0 && row < Y0 + 4 * ns)
+          *reinterpret_cast<uint2*>(p.bits + ((((long long)(n0 * p.Cout + co) * p.H + row) * p.W + ox0) >> 4)) = o;
       }
     }
   };
@@ -227,6 +234,9 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       const int kx = i12 >> 2, c4 = i12 & 3;
       rb[slot] = ring[sb[j] + c4 * 4 * RB_RP + kx + a_lane];
     };
+#if RB_SETPRIO
+    __builtin_amdgcn_s_setprio(RB_SETPRIO);     // the MFMA phase issues ahead of the other workgroups' epilogues on this SIMD
+#endif
 #pragma unroll
     for (int f = 0; f < PD; ++f) fetch(f, f % (PD + 1));
 #pragma unroll
@@ -250,6 +260,9 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       if (f == 8) load_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if RB_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     RB_PH(1)
     if constexpr (RGB) {
       __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the previous step's image rows neither
@@ -309,45 +322,48 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       for (int r = 0; r < 4; ++r) v[r4][r] = in ? rb_act(acc[r4][r] + bv, p.slope) : 0.f;
       acc[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (kk == 0) *reinterpret_cast<float4*>(xn + ((0 * 4 + w) * 16 + co) * 4) = float4{v[0][0], v[1][0], v[2][0], v[3][0]};
-    if (kk == 3) *reinterpret_cast<float4*>(xn + ((1 * 4 + w) * 16 + co) * 4) = float4{v[0][3], v[1][3], v[2][3], v[3][3]};
-    if (kk < 2)   // lanes kk = 0: column -1, rows r; kk = 1: column 64
-      *reinterpret_cast<float4*>(xe + ((kk * 4 + w) * 16 + co) * 4) = float4{acce[0], acce[1], acce[2], acce[3]};
+    // The epilogue is written WITHOUT lane-dependent branches (round 4: the first version's 19 exec-mask regions, four
+    // serialised shuffle -> wait -> byte-store rounds and per-item guards made it a ~600-instruction dependent chain of ~5 us per
+    // step, tools/phase_probe_rb.py): lanes that have nothing to publish write to a scratch slot of their own, every lane
+    // reads the neighbour values it may need, selections are v_cndmask.
+    {
+      const bool k0 = kk == 0, k3 = kk == 3;
+      const float4 e1 = k0 ? float4{v[0][0], v[1][0], v[2][0], v[3][0]} : float4{v[0][3], v[1][3], v[2][3], v[3][3]};
+      float* d1 = k0 ? xn + ((0 * 4 + w) * 16 + co) * 4 : (k3 ? xn + ((1 * 4 + w) * 16 + co) * 4 : scratch_s + tid * 4);
+      *reinterpret_cast<float4*>(d1) = e1;
+      float* d2 = kk < 2 ? xe + ((kk * 4 + w) * 16 + co) * 4 : scratch_s + tid * 4;   // kk = 0: column -1, kk = 1: column 64
+      *reinterpret_cast<float4*>(d2) = float4{acce[0], acce[1], acce[2], acce[3]};
+    }
     acce = f32x4{0.f, 0.f, 0.f, 0.f};
     RB_PH(2)
     __syncthreads();          // rows 4s .. 4s+3 of the ring are no longer read; the exchange buffers are complete
     RB_PH(3)
-    store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);       // into the slots of rows 4s .. 4s+3
+    store_rows(4 * s + 6, s + 1 < nrun ? 4 : 0);       // into the slots of rows 4s .. 4s+3 (an unguarded form of this
+                                                       // staging spilled 48 registers: it keeps its per-item guards)
     RB_PH(6)
-    // ---- horizontal blur (unnormalised [1 2 1]) ----
+    // ---- horizontal blur (unnormalised [1 2 1]); w and txi are wave-uniform: scalar branches, every lane reads ----
     float4 nl = float4{0.f, 0.f, 0.f, 0.f}, nr = nl;      // left neighbour of pixel 0 / right neighbour of pixel 15 (by row)
-    if (kk == 0) {
-      if (w > 0) {
-        nl = *reinterpret_cast<const float4*>(xn + ((1 * 4 + (w - 1)) * 16 + co) * 4);
-      } else if (txi > 0) {
-        float4 t = *reinterpret_cast<const float4*>(xe + ((0 * 4 + 0) * 16 + co) * 4);
+    if (w > 0) {
+      nl = *reinterpret_cast<const float4*>(xn + ((1 * 4 + (w - 1)) * 16 + co) * 4);
+    } else if (txi > 0) {
+      float4 t = *reinterpret_cast<const float4*>(xe + ((0 * 4 + 0) * 16 + co) * 4);
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-          const float4 u = *reinterpret_cast<const float4*>(xe + ((0 * 4 + ww) * 16 + co) * 4);
-          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        nl = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope),
-                    rb_act(t.w + bv, p.slope)};
+      for (int ww = 1; ww < 4; ++ww) {
+        const float4 u = *reinterpret_cast<const float4*>(xe + ((0 * 4 + ww) * 16 + co) * 4);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
+      nl = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope), rb_act(t.w + bv, p.slope)};
     }
-    if (kk == 3) {
-      if (w < 3) {
-        nr = *reinterpret_cast<const float4*>(xn + ((0 * 4 + (w + 1)) * 16 + co) * 4);
-      } else if (txi + 1 < p.cols) {
-        float4 t = *reinterpret_cast<const float4*>(xe + ((1 * 4 + 0) * 16 + co) * 4);
+    if (w < 3) {
+      nr = *reinterpret_cast<const float4*>(xn + ((0 * 4 + (w + 1)) * 16 + co) * 4);
+    } else if (txi + 1 < p.cols) {
+      float4 t = *reinterpret_cast<const float4*>(xe + ((1 * 4 + 0) * 16 + co) * 4);
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-          const float4 u = *reinterpret_cast<const float4*>(xe + ((1 * 4 + ww) * 16 + co) * 4);
-          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        nr = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope),
-                    rb_act(t.w + bv, p.slope)};
+      for (int ww = 1; ww < 4; ++ww) {
+        const float4 u = *reinterpret_cast<const float4*>(xe + ((1 * 4 + ww) * 16 + co) * 4);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
+      nr = float4{rb_act(t.x + bv, p.slope), rb_act(t.y + bv, p.slope), rb_act(t.z + bv, p.slope), rb_act(t.w + bv, p.slope)};
     }
     f32x4 hb[4];
 #pragma unroll
@@ -358,40 +374,46 @@ __global__ __launch_bounds__(256, MODE == RB_PLAIN ? 4 : 3) void conv_fwd_roll_b
       float r = __shfl_down(v[r4][0], 16, 64);    // lane + 16: pixel 4kk + 4
       const float nlv = r4 == 0 ? nl.x : r4 == 1 ? nl.y : r4 == 2 ? nl.z : nl.w;
       const float nrv = r4 == 0 ? nr.x : r4 == 1 ? nr.y : r4 == 2 ? nr.z : nr.w;
-      if (kk == 0) l = in ? nlv : 0.f;
-      if (kk == 3) r = in ? nrv : 0.f;
+      l = kk == 0 ? (in ? nlv : 0.f) : l;
+      r = kk == 3 ? (in ? nrv : 0.f) : r;
       hb[r4][0] = l + 2.f * v[r4][0] + v[r4][1];
       hb[r4][1] = v[r4][0] + 2.f * v[r4][1] + v[r4][2];
       hb[r4][2] = v[r4][1] + 2.f * v[r4][2] + v[r4][3];
       hb[r4][3] = v[r4][2] + 2.f * v[r4][3] + r;
     }
     RB_PH(7)
-    // ---- vertical blur, one row behind: output rows Y0 - 2 + 4s + i from (c0, c1, hb[0..3]) ----
+    // ---- vertical blur, one row behind: output rows Y0 - 2 + 4s + i from (c0, c1, hb[0..3]); rows this strip does not own
+    //      get an out-of-range offset (dropped by the descriptor's bounds check) ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = Y0 - 2 + 4 * s + i;
       const f32x4 a = i == 0 ? c0 : i == 1 ? c1 : hb[i - 2];
       const f32x4 b = i == 0 ? c1 : hb[i - 1];
       const f32x4 c = hb[i];
-      if (row >= Y0 && row < Y0 + 4 * ns) {
-        u32x4 o;
+      u32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = __float_as_uint((a[r] + 2.f * b[r] + c[r]) * 0.0625f);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * p.W * 4, 0, RB_STORE_AUX);
-      }
+      for (int r = 0; r < 4; ++r) o[r] = __float_as_uint((a[r] + 2.f * b[r] + c[r]) * 0.0625f);
+      const bool own = row >= Y0 && row < Y0 + 4 * ns;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (own && vo_lane != RB_OOB) ? vo_lane + row * p.W * 4 : RB_OOB, 0, RB_STORE_AUX);
     }
     c0 = hb[2];
     c1 = hb[3];
     RB_PH(8)
-    // ---- sign bits of the activation rows of this step: one byte per lane pair (8 pixels) into bits_s ----
+    // ---- sign bits of the step's four activation rows: ONE shuffle and ONE 4-byte LDS store per lane pair (8 pixels x 4
+    //      rows), bits_s[co][w * 2 + kk / 2] = {row 0, row 1, row 2, row 3} bytes ----
     if (p.bits != nullptr) {
+      unsigned n16 = 0;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        unsigned nib = (v[r4][0] > 0.f ? 1u : 0u) | (v[r4][1] > 0.f ? 2u : 0u) | (v[r4][2] > 0.f ? 4u : 0u) |
-                       (v[r4][3] > 0.f ? 8u : 0u);
-        const unsigned hi = __shfl_down(nib, 16, 64);          // lane group kk + 1: the next four pixels
-        if ((kk & 1) == 0) bits_s[(r4 * 16 + co) * 8 + w * 2 + (kk >> 1)] = (unsigned char)(nib | (hi << 4));
-      }
+      for (int r4 = 0; r4 < 4; ++r4)
+        n16 |= ((v[r4][0] > 0.f ? 1u : 0u) | (v[r4][1] > 0.f ? 2u : 0u) | (v[r4][2] > 0.f ? 4u : 0u) | (v[r4][3] > 0.f ? 8u : 0u))
+               << (4 * r4);
+      const unsigned h16 = __shfl_down(n16, 16, 64);           // lane group kk + 1: the next four pixels of every row
+      auto spread = [](unsigned x) {                            // nibble r -> low nibble of byte r
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        return (x | (x << 4)) & 0x0f0f0f0fu;
+      };
+      unsigned* dst = (kk & 1) == 0 ? bits_s + co * 8 + w * 2 + (kk >> 1) : reinterpret_cast<unsigned*>(scratch_s) + tid * 4;
+      *dst = spread(n16) | (spread(h16) << 4);
     }
     RB_PH(9)
     __syncthreads();   // the ring holds rows 4s+4 .. 4s+9; the exchange buffers may be rewritten

@@ -512,7 +512,7 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
             still.update(s_)
     # Adam (beta1 = 0, first step): every element moves by lr * g / (|g| + eps).  Two checks.  (i) The optimiser's own
     # arithmetic: the update the fused kernel made against that formula evaluated in float64 on the gradient IT was given
-    # (the arena's) - every element of every parameter, to 1e-3 of the step size (the parameter's own fp32 rounding).
+    # (the arena's) - every element of every parameter, to 1e-3 of the step size plus the parameter's own fp32 spacing.
     # (ii) Against the oracle's update where the gradient's sign and size are certain on both paths - elements above 1e-3
     # of the tensor's largest, above 8x the largest difference between the two fp32 paths on that tensor and above 100 eps
     # (below that the step is not saturated at lr and follows the gradient's rounding) - to 2 % of the step size;
@@ -527,7 +527,9 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
                 continue
             gm = mine[k].double()
             want = -(lr * lr_factor) * gm / (gm.abs() + 1e-8)
-            ea = ((du.double() - want).abs().max() / (lr * lr_factor)).item()
+            # (allowance: 1e-3 of the step + the parameter's own fp32 spacing - the mapping network's weights are ~100)
+            allow = 1e-3 * (lr * lr_factor) + 2.4e-7 * v0.double().abs()
+            ea = ((du.double() - want).abs() / allow).max().item()
             if ea > worst_arith[0]:
                 worst_arith = (ea, tag + k)
             g = grads[k]
@@ -553,6 +555,6 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
     assert not still, still
     _assert_ties_are_rare(rep, len(ed) + len(eg))
     assert len(ed) >= 20 and len(eg) >= 20 and n_upd > 10 ** 6
-    assert worst_arith[0] <= 1e-3, rep
+    assert worst_arith[0] <= 1.0, rep
     assert worst_upd[0] <= 2e-2, rep
     assert worst_lag[0] <= 1e-4, rep

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 RES=$OUT/${TAG}_blur_fold_pmc.txt
 : > "$RES"
 cd /tmp && export TMPDIR=/tmp
-for ctr in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS"; do
+for ctr in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS" "SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   D=$OUT/${TAG}_pmc_tmp
   rm -rf "$D"; mkdir -p "$D"
   rocprofv3 --pmc $ctr --kernel-trace -d "$D" -- python3 "$ROOT/tools/blur_fold_bench.py" 32 1024 short > /dev/null 2>> "$OUT/${TAG}_pmc.err" || true
