@@ -141,12 +141,16 @@ class _StepGraphs(object):
         rng.begin_device_offsets(self.block)
         L.opt_disc.dev_scalars, L.opt_gen.dev_scalars = base + 16, base + 28
         graph = torch.cuda.CUDAGraph()
+        import warnings
         try:
-            with torch.cuda.graph(graph, pool=self.pool):
-                self.losses[key[0]].copy_(fn())
+            with warnings.catch_warnings():
+                # (a capture that an exception - or Ctrl-C - cuts short ends empty: torch says so in a warning of its own; the
+                # graph object is dropped below, nothing is left behind)
+                warnings.filterwarnings('ignore', message='The CUDA Graph is empty')
+                with torch.cuda.graph(graph, pool=self.pool):
+                    self.losses[key[0]].copy_(fn())
         except Exception as exc:      # an op that cannot be captured (a host sync, an allocation outside the pool): no retry
             self.failed = exc
-            import warnings
             warnings.warn(f'step-graph capture of {key} failed ({type(exc).__name__}: {exc}); stepping eagerly', RuntimeWarning)
             raise
         finally:
