@@ -1089,7 +1089,12 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  constexpr bool FRAGPF = GL_FRAG_PREFETCH && KS == 3 && MB >= 2 && G::XMODE != XSCALAR;
+  // (every 3x3 instantiation: the element-wise staged small-map tiles gain the most - 512 -> 512 at 8^2 87 -> 96 TFLOP/s, at 4^2
+  // 52 -> 59, at 16^2 and batch 8 91 -> 101; GL_FRAG_PREFETCH_K1 extends it to the 1x1 / linear instantiations)
+#ifndef GL_FRAG_PREFETCH_K1
+#define GL_FRAG_PREFETCH_K1 0
+#endif
+  constexpr bool FRAGPF = GL_FRAG_PREFETCH && (KS == 3 || GL_FRAG_PREFETCH_K1);
 
   for (int ci0 = c_begin; ci0 < c_end; ci0 += CI_T) {
     __syncthreads();  // every wave is done reading the previous chunk

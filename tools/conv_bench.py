@@ -19,6 +19,8 @@ THICK = [('32->32 @512', 32, 32, 512, 0, 0), ('64->64 @256', 64, 64, 256, 0, 0),
          ('512->512 pool @32', 512, 512, 32, 0, 1),
          ('64->32 up @256', 64, 32, 256, 1, 0), ('128->64 up @128', 128, 64, 128, 1, 0), ('256->128 up @64', 256, 128, 64, 1, 0),
          ('512->256 up @32', 512, 256, 32, 1, 0), ('512->512 up @16', 512, 512, 16, 1, 0)]
+SMALL = [('512->512 @16', 512, 512, 16, 0, 0), ('512->512 @8', 512, 512, 8, 0, 0), ('512->512 @4', 512, 512, 4, 0, 0),
+         ('16->16 @512 (w%64)', 16, 16, 512, 0, 0), ('16->16 @96', 16, 16, 96, 0, 0)]
 THIN = [('16->16 @1024', 16, 16, 1024, 0, 0), ('16->32 pool @1024', 16, 32, 1024, 0, 1), ('32->16 up @512', 32, 16, 512, 1, 0)]
 
 
@@ -45,7 +47,7 @@ def main():
     p.add_argument('--batch', type=int, default=32)
     p.add_argument('--reps', type=int, default=10)
     a = p.parse_args()
-    layers = {'thick': THICK, 'thin': THIN, 'all': THICK + THIN, 'plain': THICK[:5], 's2': THICK[6:]}[a.layers]
+    layers = {'thick': THICK, 'thin': THIN, 'all': THICK + THIN, 'plain': THICK[:5], 's2': THICK[6:], 'small': SMALL}[a.layers]
     print('library:', os.path.basename(_lib.SO_PATH))
     tot = {}
     for name, cin, cout, hin, up, pool in layers:
