@@ -1315,8 +1315,11 @@ struct WgCfg {
   static_assert(G::PX_T % (4 * WK_) == 0, "K-steps must split evenly over waves");
 };
 
+#ifndef GL_WGRAD_MINW
+#define GL_WGRAD_MINW 1
+#endif
 template <class Cfg, bool AFF = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, NBC = Cfg::NBC, WK = Cfg::WK;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, GP = Cfg::GP;
