@@ -153,6 +153,12 @@ SIGNATURES = {
     'ganlab_instnorm_bwd_act_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
     'ganlab_instnorm_style_bwd_act_f32': (_c_int, [_c_p] * 11 + [_c_int, _c_int, _c_ll, _c_int, _c_f, _c_f, _c_p, _c_sz,
                                                                  _c_p]),
+    'ganlab_instnorm_bwd_rgb_supported': (_c_int, [_c_int, _c_int, _c_int, _c_ll]),
+    'ganlab_instnorm_bwd_reduce_rgb_workspace': (_c_sz, [_c_int, _c_int, _c_ll]),
+    'ganlab_instnorm_style_bwd_reduce_rgb_f32': (_c_int, [_c_p, _c_p, _c_int] + [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_p,
+                                                                                            _c_sz, _c_p]),
+    'ganlab_instnorm_style_bwd_act_rgb_f32': (_c_int, [_c_p, _c_p, _c_int] + [_c_p] * 10 + [_c_int, _c_int, _c_ll, _c_int,
+                                                                                         _c_f, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_instnorm_style_bwd_act_blur_f32': (_c_int, [_c_p] * 11 + [_c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_f,
                                                                       _c_p, _c_sz, _c_p]),
     'ganlab_u8_box_decode_f32': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p, _c_p, _c_p, _c_p]),

@@ -95,6 +95,21 @@ constexpr int GL_ACC_DUMP_TERMS = GL_ACC_DUMP_TERMS_V;
 
 __device__ __forceinline__ float gl_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// One output channel `co` of a 1x1 convolution with <= 4 input channels (fromRGB forward / toRGB input gradient), 4 pixels
+// at a time: start + sum_ci wp[ci * Cout_p + co] * xv[ci], channels in order.  Shared by pw_few_to_many_kernel (conv.hip)
+// and the InstanceNorm backward kernels that recompute toRGB's input gradient instead of reading it (pointwise.hip), so
+// both produce the same bits.
+__device__ __forceinline__ float4 gl_few_dot(const float4 (&xv)[4], const float* __restrict__ wp, int Cin, int Cout_p, int co,
+                                             float start) {
+  float4 a = float4{start, start, start, start};
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) {
+    const float w = ci < Cin ? wp[(long long)ci * Cout_p + co] : 0.f;
+    a.x += w * xv[ci].x; a.y += w * xv[ci].y; a.z += w * xv[ci].z; a.w += w * xv[ci].w;
+  }
+  return a;
+}
+
 // ---- wgrad_roll.hip: rolling-window weight gradient of the thin 3x3 layers (used by ganlab_conv_wgrad_f32) ----------
 bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int pad, int up, const void* x,
                              const void* gy);

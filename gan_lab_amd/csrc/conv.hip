@@ -1688,12 +1688,7 @@ __global__ __launch_bounds__(256) void pw_few_to_many_kernel(PwArgs p) {
     float4* yb = reinterpret_cast<float4*>(p.y) + n * p.Cout * p.hw4 + q;
     for (int co = 0; co < p.Cout; ++co) {
       const float b = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
-      float4 a = float4{b, b, b, b};
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci) {
-        const float w = ci < p.Cin ? p.wp[(long long)ci * p.Cout_p + co] : 0.f;
-        a.x += w * xv[ci].x; a.y += w * xv[ci].y; a.z += w * xv[ci].z; a.w += w * xv[ci].w;
-      }
+      float4 a = gl_few_dot(xv, p.wp, p.Cin, p.Cout_p, co, b);
       if (p.act == GANLAB_ACT_LRELU) {
         a.x = gl_lrelu(a.x, p.slope); a.y = gl_lrelu(a.y, p.slope); a.z = gl_lrelu(a.z, p.slope); a.w = gl_lrelu(a.w, p.slope);
       }

@@ -844,6 +844,171 @@ __global__ __launch_bounds__(256) void instnorm_style_fwd_chunk_kernel(const flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------- //
+// The same two passes for the generator's LAST layer, whose only reader is toRGB (stylegan/architectures.py torgb, a 1x1
+// conv to <= 4 channels): its incoming gradient  gy[n, c] = sum_k wp[k][c] * grgb[n, k]  is cheaper to recompute from the
+// image gradient (3 planes per image) than to write as C planes and read back twice.  A workgroup owns a pixel range of ONE
+// image and walks the C <= 16 channels itself, so the image gradient is read once (a plane-per-workgroup grid re-reads it
+// through eight L2s: measured slower than reading gy).  gy's bits are pw_few_to_many_kernel's (gl_few_dot).
+// ---------------------------------------------------------------------------------------------- //
+constexpr int RGB_MAXC = 16;
+struct RgbSrc {
+  const float* grgb;   // (N, crgb, HW)
+  const float* wp;     // toRGB's input-gradient pack: wp[k * cout_p + c]
+  int crgb, cout_p;
+};
+__device__ __forceinline__ void rgb_src_load(const RgbSrc& r, long long n, long long hw4, long long i, float4 (&xv)[4]) {
+  const float4* gb = reinterpret_cast<const float4*>(r.grgb) + n * r.crgb * hw4 + i;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xv[k] = k < r.crgb ? gb[(long long)k * hw4] : float4{0.f, 0.f, 0.f, 0.f};
+}
+
+// grid (chunks, N); part[((n*C + c)*chunks + chunk)*2 + {0, 1}] = this chunk's share of sum gy, sum gy * xhat
+// EXACT: C == 16, crgb == 3 (the shape toRGB has on the timed path) as compile-time constants - with run-time bounds every
+// channel and every image plane is a branch
+template <bool EXACT>
+__global__ __launch_bounds__(256) void instnorm_bwd_reduce_rgb_kernel(RgbSrc rgb, const float* __restrict__ x,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ rstd,
+                                                                      double* __restrict__ part, int C_, long long hw4,
+                                                                      int chunks, int contig) {
+  __shared__ double red[4];
+  const int C = EXACT ? RGB_MAXC : C_;
+  if (EXACT) rgb.crgb = 3;
+  const long long n = blockIdx.y;
+  const float4* xb = reinterpret_cast<const float4*>(x) + n * C * hw4;      // (offsets inside one image fit 32 bits)
+  double a[RGB_MAXC], b[RGB_MAXC];
+#pragma unroll
+  for (int c = 0; c < RGB_MAXC; ++c) a[c] = b[c] = 0.0;
+  const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
+  for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
+    float4 xv[4];
+    rgb_src_load(rgb, n, hw4, i, xv);
+#pragma unroll
+    for (int c = 0; c < RGB_MAXC; ++c) {
+      if (c < C) {
+        const long long pl = n * C + c;
+        const float m = mean[pl], r = rstd[pl];
+        const float4 g = gl_few_dot(xv, rgb.wp, rgb.crgb, rgb.cout_p, c, 0.f);
+        const float4 v = xb[(unsigned)(c * hw4 + i)];
+        a[c] += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+        b[c] += ((double)g.x * ((v.x - m) * r) + (double)g.y * ((v.y - m) * r)) +
+                ((double)g.z * ((v.z - m) * r) + (double)g.w * ((v.w - m) * r));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < RGB_MAXC; ++c) {
+    if (c < C) {
+      const double sa = gl_block_sum_256d(a[c], red);
+      __syncthreads();
+      const double sb = gl_block_sum_256d(b[c], red);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double* dst = part + (((n * C + c) * chunks) + blockIdx.x) * 2;
+        dst[0] = sa;
+        dst[1] = sb;
+      }
+    }
+  }
+}
+
+__global__ void instnorm_bwd_reduce_rgb_finish_kernel(const double* __restrict__ part, float* __restrict__ s1,
+                                                      float* __restrict__ s2, long long planes, int chunks) {
+  const long long pl = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pl >= planes) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < chunks; ++k) {       // fixed order
+    a += part[(pl * chunks + k) * 2];
+    b += part[(pl * chunks + k) * 2 + 1];
+  }
+  s1[pl] = (float)a;
+  s2[pl] = (float)b;
+}
+
+// instnorm_bwd_apply_act_kernel with the channel loop inside; grid (chunks, N), the same partial-sum slots
+template <bool EXACT>
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_act_rgb_kernel(
+    RgbSrc rgb, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ style, const float* __restrict__ s1, const float* __restrict__ s2,
+    const float* __restrict__ noise, float* __restrict__ gz, double* __restrict__ part, int N, int C_, long long hw4,
+    int chunks, int act_, float slope, int want_b, int want_nw, int contig) {
+  __shared__ double red[4];
+  __shared__ double cst[RGB_MAXC][5];          // k, a1, a2, mean, rstd of this image's planes
+  const int C = EXACT ? RGB_MAXC : C_;
+  const int act = EXACT ? GANLAB_ACT_LRELU : act_;
+  if (EXACT) rgb.crgb = 3;
+  const long long n = blockIdx.y;
+  const float4* xb = reinterpret_cast<const float4*>(x) + n * C * hw4;
+  float4* zb = reinterpret_cast<float4*>(gz) + n * C * hw4;
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const long long pl = n * C + c;
+    const float r = rstd[pl];
+    const float ys = style ? style[(n * 2 + 0) * C + c] + 1.f : 1.f;
+    const double inv = 1.0 / (double)(hw4 * 4);
+    cst[c][0] = (double)r * (double)ys;
+    cst[c][1] = (double)s1[pl] * inv;
+    cst[c][2] = (double)s2[pl] * inv;
+    cst[c][3] = (double)mean[pl];
+    cst[c][4] = (double)r;
+  }
+  __syncthreads();
+  const float4* pn = (want_nw && noise) ? reinterpret_cast<const float4*>(noise) + n * hw4 : nullptr;
+  double sb[RGB_MAXC], snw[RGB_MAXC];
+#pragma unroll
+  for (int c = 0; c < RGB_MAXC; ++c) sb[c] = snw[c] = 0.0;
+  const ChunkRange cr = chunk_range(hw4, chunks, blockIdx.x, contig);
+  for (long long i = cr.begin + threadIdx.x; i < cr.end; i += cr.stride) {
+    float4 xv[4];
+    rgb_src_load(rgb, n, hw4, i, xv);
+    float4 z = float4{0.f, 0.f, 0.f, 0.f};
+    if (pn) z = pn[i];
+    // (an offset the compiler cannot see through: hoisted out of this loop the 80 constants would sit in 160 registers)
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const double* cp = &cst[0][0] + opaque;
+#pragma unroll
+    for (int c = 0; c < RGB_MAXC; ++c) {
+      if (c < C) {
+        const double k = cp[c * 5], a1 = cp[c * 5 + 1], a2 = cp[c * 5 + 2], md = cp[c * 5 + 3], rd = cp[c * 5 + 4];
+        float g[4], v[4], o[4];
+        double td[4];
+        *reinterpret_cast<float4*>(g) = gl_few_dot(xv, rgb.wp, rgb.crgb, rgb.cout_p, c, 0.f);
+        *reinterpret_cast<float4*>(v) = xb[(unsigned)(c * hw4 + i)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double t = k * ((double)g[j] - a1 - ((double)v[j] - md) * rd * a2);
+          if (act == GANLAB_ACT_LRELU && !(v[j] > 0.f)) t *= (double)slope;
+          td[j] = t;
+          o[j] = (float)t;
+        }
+        zb[(unsigned)(c * hw4 + i)] = *reinterpret_cast<float4*>(o);
+        sb[c] += (td[0] + td[1]) + (td[2] + td[3]);
+        if (pn) snw[c] += (td[0] * z.x + td[1] * z.y) + (td[2] * z.z + td[3] * z.w);
+      }
+      // four channels' loads in flight at a time: unbounded, the scheduler hoists all 16 and the kernel needs 360 registers
+      if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < RGB_MAXC; ++c) {
+    if (c < C) {
+      const long long slot = ((long long)c * N + n) * chunks + blockIdx.x;
+      if (want_b) {
+        const double v = gl_block_sum_256d(sb[c], red);
+        __syncthreads();
+        if (threadIdx.x == 0) part[slot] = v;
+      }
+      if (want_nw) {
+        const double v = gl_block_sum_256d(snw[c], red);
+        __syncthreads();
+        if (threadIdx.x == 0) part[(long long)C * N * chunks + slot] = v;
+      }
+    }
+  }
+}
+
 template <int T>
 __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ gy,
                                                                   const float* __restrict__ x,
@@ -1632,6 +1797,73 @@ int ganlab_instnorm_style_bwd_act_f32(const float* gy, const float* x, const flo
   double* part = reinterpret_cast<double*>(workspace);
   GL_LAUNCH(instnorm_bwd_apply_act_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, ST, gy, x, mean,
             rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope, gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
+  if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part, gb, C, N * chunks, bias_scale);
+  if (gnw)
+    GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part + (size_t)C * N * chunks, gnw, C,
+              N * chunks, 1.f);
+  return GL_CHECK_LAUNCH();
+}
+
+/* The two InstanceNorm backward passes of a generator layer whose ONLY reader is toRGB, fed with the image gradient instead
+ * of the layer's incoming gradient  gy[n, c] = sum_k wp[k * round_up(C, 64) + c] * grgb[n, k]  (wp: toRGB's input-gradient
+ * pack, scale included) - toRGB's backward then writes nothing and these passes read crgb planes per image instead of C.
+ * gz / gb / gnw: the bits of ganlab_conv_dgrad_f32 followed by the plain entry points given the same s1 / s2; s1 / s2 themselves
+ * are fp64 sums in another order (equal after rounding to fp32 up to ties).  C <= 16, crgb <= 4, HW % 4 == 0. */
+int ganlab_instnorm_bwd_rgb_supported(int N, int C, int crgb, long long HW) {
+  return (N > 0 && N <= 65535 && C > 0 && C <= 16 && crgb > 0 && crgb <= 4 && HW >= 1024 && (HW & 3) == 0) ? 1 : 0;
+}
+
+static RgbSrc make_rgb_src(const float* grgb, const float* wp, int crgb, int C) {
+  RgbSrc r;
+  r.grgb = grgb; r.wp = wp; r.crgb = crgb; r.cout_p = (C + 63) / 64 * 64;
+  return r;
+}
+
+size_t ganlab_instnorm_bwd_reduce_rgb_workspace(int N, int C, long long HW) {
+  if (!ganlab_instnorm_bwd_rgb_supported(N, C, 3, HW)) return 0;
+  return (size_t)N * C * act_stats_chunks(HW / 4) * 2 * sizeof(double);
+}
+
+int ganlab_instnorm_style_bwd_reduce_rgb_f32(const float* grgb, const float* wp, int crgb, const float* x,
+                                             const float* mean, const float* rstd, float* s1, float* s2, int N, int C,
+                                             long long HW, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grgb || !wp || !x || !mean || !rstd || !s1 || !s2) return GANLAB_EINVAL;
+  if (!ganlab_instnorm_bwd_rgb_supported(N, C, crgb, HW)) return GANLAB_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < ganlab_instnorm_bwd_reduce_rgb_workspace(N, C, HW)) return GANLAB_EWORKSPACE;
+  const long long hw4 = HW / 4, planes = (long long)N * C;
+  const int chunks = act_stats_chunks(hw4);
+  double* part = reinterpret_cast<double*>(workspace);
+  if (C == RGB_MAXC && crgb == 3)
+    GL_LAUNCH(instnorm_bwd_reduce_rgb_kernel<true>, dim3((unsigned)chunks, (unsigned)N), dim3(256), 0, ST,
+              make_rgb_src(grgb, wp, crgb, C), x, mean, rstd, part, C, hw4, chunks, pw_contig());
+  else
+    GL_LAUNCH(instnorm_bwd_reduce_rgb_kernel<false>, dim3((unsigned)chunks, (unsigned)N), dim3(256), 0, ST,
+              make_rgb_src(grgb, wp, crgb, C), x, mean, rstd, part, C, hw4, chunks, pw_contig());
+  GL_LAUNCH(instnorm_bwd_reduce_rgb_finish_kernel, dim3((unsigned)((planes + 63) / 64)), dim3(64), 0, ST,
+            (const double*)part, s1, s2, planes, chunks);
+  return GL_CHECK_LAUNCH();
+}
+
+int ganlab_instnorm_style_bwd_act_rgb_f32(const float* grgb, const float* wp, int crgb, const float* x, const float* mean,
+                                          const float* rstd, const float* style, const float* s1, const float* s2,
+                                          const float* noise, float* gz, float* gb, float* gnw, int N, int C, long long HW,
+                                          int act, float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  if (!grgb || !wp || !x || !mean || !rstd || !s1 || !s2 || !gz || (gnw && !noise)) return GANLAB_EINVAL;
+  if (!ganlab_instnorm_bwd_rgb_supported(N, C, crgb, HW)) return GANLAB_EUNSUPPORTED;
+  if ((gb || gnw) && (!workspace || workspace_bytes < ganlab_instnorm_bwd_act_workspace(N, C, HW)))
+    return GANLAB_EWORKSPACE;
+  const long long hw4 = HW / 4;
+  const int chunks = act_stats_chunks(hw4);
+  double* part = reinterpret_cast<double*>(workspace);
+  if (C == RGB_MAXC && crgb == 3 && act == GANLAB_ACT_LRELU)
+    GL_LAUNCH(instnorm_bwd_apply_act_rgb_kernel<true>, dim3((unsigned)chunks, (unsigned)N), dim3(256), 0, ST,
+              make_rgb_src(grgb, wp, crgb, C), x, mean, rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope,
+              gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
+  else
+    GL_LAUNCH(instnorm_bwd_apply_act_rgb_kernel<false>, dim3((unsigned)chunks, (unsigned)N), dim3(256), 0, ST,
+              make_rgb_src(grgb, wp, crgb, C), x, mean, rstd, style, s1, s2, noise, gz, part, N, C, hw4, chunks, act, slope,
+              gb ? 1 : 0, gnw ? 1 : 0, pw_contig());
   if (gb) GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part, gb, C, N * chunks, bias_scale);
   if (gnw)
     GL_LAUNCH(channel_sum_stage2, dim3(C), dim3(64), 0, ST, (const double*)part + (size_t)C * N * chunks, gnw, C,

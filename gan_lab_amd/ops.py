@@ -1924,10 +1924,35 @@ class Deferred(object):
     Gradient contract: whoever consumes ``a`` sends back d loss / d (a*s + t) - the gradient with respect to the
     NORMALISED tensor - as the gradient of ``a``; ``_LayerTailDeferred.backward`` is the InstanceNorm backward of that
     (exactly what the materialised path feeds it), so ``s`` / ``t`` carry no gradient of their own."""
-    __slots__ = ('a', 's', 't', 'mean', 'rstd', 'style')
+    __slots__ = ('a', 's', 't', 'mean', 'rstd', 'style', 'link')
 
-    def __init__(self, a, s, t, mean, rstd, style):
-        self.a, self.s, self.t, self.mean, self.rstd, self.style = a, s, t, mean, rstd, style
+    def __init__(self, a, s, t, mean, rstd, style, link=None):
+        self.a, self.s, self.t, self.mean, self.rstd, self.style, self.link = a, s, t, mean, rstd, style, link
+
+    def read(self):
+        """Called by every consumer of ``a`` (see ``RgbGradLink``); returns self."""
+        if self.link is not None:
+            self.link.readers += 1
+        return self
+
+
+class RgbGradLink(object):
+    """Link between a generator layer's tail (the producer of a ``Deferred``) and toRGB where toRGB is its ONLY reader (the
+    last layer outside the fade-in, stylegan/architectures.py:398-402): toRGB's input gradient is a 1x1 conv of the <= 4-plane
+    image gradient, cheaper to recompute inside the tail's two InstanceNorm backward passes than to write as C planes and
+    read back twice (csrc/pointwise.hip, RgbSrc).  toRGB's backward fills ``grgb`` / ``wp`` / ``crgb`` and returns a
+    placeholder for the gradient of ``a``; the tail's backward - which always runs after it - reads them instead."""
+    __slots__ = ('readers', 'grgb', 'wp', 'crgb')
+
+    def __init__(self):
+        self.readers, self.grgb, self.wp, self.crgb = 0, None, None, 0
+
+
+def _rgb_link_ok(link, n, c, crgb, hw):
+    import os
+    return link is not None and link.readers == 1 and get_compute_dtype() == 'f32' and \
+        os.environ.get('GANLAB_TORGB_FOLD') != '0' and \
+        bool(_lib.lib().ganlab_instnorm_bwd_rgb_supported(n, c, crgb, hw))
 
     @property
     def shape(self):
@@ -1947,15 +1972,28 @@ def _layer_tail_backward(ctx, saved_tail, gout, blur=False):
     ``blur``: the tail sits behind a blur - the (self-adjoint) blur of gz runs in the SAME pass and gz is never written.
     Returns (gz or blur(gz), gb, gnw, gstyle)."""
     y, mean, rstd, style, noise = saved_tail
-    gout = _c(gout)
     n, c, hw = _nchw(y)
     L = _lib.lib()
+    rgb = getattr(ctx, 'link', None)
+    if rgb is not None and rgb.grgb is None:
+        rgb = None
     params = _want_param_grads()
     want_b = ctx.bias_shape is not None and ctx.want_bias_grad and params
     want_nw = ctx.nw_shape is not None and ctx.want_nw_grad and params
     s1, s2 = _new((n, c), y), _new((n, c), y)
-    check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
-                                                 _st()), 'instnorm_bwd_reduce')
+    if rgb is not None:            # ``gout`` is toRGB's placeholder: the gradient is recomputed from the image gradient
+        assert not blur
+        grgb, wp_rgb, crgb = rgb.grgb, rgb.wp, rgb.crgb
+        rgb.grgb = rgb.wp = None
+        wsr = torch.empty((L.ganlab_instnorm_bwd_reduce_rgb_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
+                          device=y.device)
+        check(L.ganlab_instnorm_style_bwd_reduce_rgb_f32(_p(grgb), _p(wp_rgb), crgb, _p(y), _p(mean), _p(rstd), _p(s1),
+                                                         _p(s2), n, c, hw, _p(wsr), wsr.numel() * 4, _st()),
+              'instnorm_bwd_reduce_rgb')
+    else:
+        gout = _c(gout)
+        check(L.ganlab_instnorm_style_bwd_reduce_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(s1), _p(s2), n * c, hw,
+                                                     _st()), 'instnorm_bwd_reduce')
     gz = gb = gnw = None
     if ctx.want_x_grad or want_b or want_nw:
         gz = torch.empty_like(y)
@@ -1965,7 +2003,13 @@ def _layer_tail_backward(ctx, saved_tail, gout, blur=False):
         gnw = _take('gnw', (c,), y) if want_nw else None
         ws = torch.empty((L.ganlab_instnorm_bwd_act_workspace(n, c, hw) + 3) // 4, dtype=torch.float32,
                          device=y.device) if (want_b or want_nw) else None
-        if blur and blur_fusable(y):
+        if rgb is not None:
+            check(L.ganlab_instnorm_style_bwd_act_rgb_f32(_p(grgb), _p(wp_rgb), crgb, _p(y), _p(mean), _p(rstd), _p(style),
+                                                          _p(s1), _p(s2), _p(noise) if want_nw else None, _p(gz), _p(gb),
+                                                          _p(gnw), n, c, hw, ctx.act, ctx.slope, ctx.bias_scale, _p(ws),
+                                                          ws.numel() * 4 if ws is not None else 0, _st()),
+                  'instnorm_bwd_act_rgb')
+        elif blur and blur_fusable(y):
             check(L.ganlab_instnorm_style_bwd_act_blur_f32(_p(gout), _p(y), _p(mean), _p(rstd), _p(style), _p(s1), _p(s2),
                                                            _p(noise) if want_nw else None, _p(gz), _p(gb), _p(gnw), n, c,
                                                            int(y.shape[2]), int(y.shape[3]), ctx.act, ctx.slope,
@@ -1995,9 +2039,10 @@ class _LayerTailDeferred(Function):
     per-(n, c) scale / shift of InstanceNorm + style - see ``Deferred`` for the gradient contract."""
 
     @staticmethod
-    def forward(ctx, x, bias, noise, noise_w, style, bias_scale, act, slope, blur, eps):
+    def forward(ctx, x, bias, noise, noise_w, style, bias_scale, act, slope, blur, eps, link=None):
         kern = k_blur_bias_act_stats if blur else k_bias_act_stats
         noise = _c(noise) if noise is not None else None
+        ctx.link = link
         y, mean, rstd = kern(x, bias, noise, noise_w, bias_scale, act, slope, eps)
         n, c, _ = _nchw(y)
         style_c = _c(style) if style is not None else None
@@ -2020,7 +2065,7 @@ class _LayerTailDeferred(Function):
     def backward(ctx, g_b, *_):
         gz, gb, gnw, gstyle = _layer_tail_backward(ctx, ctx.saved_tensors, g_b, blur=ctx.blur)
         gx = gz if ctx.want_x_grad else None
-        return gx, gb, None, gnw, gstyle, None, None, None, None, None
+        return gx, gb, None, gnw, gstyle, None, None, None, None, None, None
 
 
 class _Materialize(Function):
@@ -2044,6 +2089,7 @@ class _Materialize(Function):
 def materialize(x):
     """Tensor for a plain consumer: a ``Deferred`` is normalised + styled now, a tensor is returned as is."""
     if isinstance(x, Deferred):
+        x.read()
         return _Materialize.apply(x.a, x.mean, x.rstd, x.style)
     return x
 
@@ -2182,7 +2228,7 @@ class _ConvAff(Function):
 
 def conv_aff(d, weight, scale, up=False):
     """3x3 'same' conv (behind a nearest 2x upsample when ``up``) of a ``Deferred`` tensor; see ``conv_aff_ok``."""
-    n, cin, h, w = d.a.shape
+    n, cin, h, w = d.read().a.shape
     g = Geom(n, cin, h, w, weight.shape[0], 3, 1, 1 if up else 0, 0)
     return _ConvAff.apply(d.a, d.s, d.t, weight, g, float(scale))
 
@@ -2195,11 +2241,12 @@ class _ConvModTail(Function):
     kernel with the affine on its x operand."""
 
     @staticmethod
-    def forward(ctx, a_in, s_in, t_in, w, bias, noise, noise_w, style, scale, bias_scale, act, slope, eps):
+    def forward(ctx, a_in, s_in, t_in, w, bias, noise, noise_w, style, scale, bias_scale, act, slope, eps, link=None):
         a_in, w = _c(a_in), _c(w)
         n, cin, h, wd = a_in.shape
         cout = w.shape[0]
         L = _lib.lib()
+        ctx.link = link
         g = Geom(n, cin, h, wd, cout, 3, 1, 0)
         _note('fwd', g)
         wp = _packed(w, PACK_FWD, scale)
@@ -2247,7 +2294,7 @@ class _ConvModTail(Function):
             gw = k_conv_wgrad_aff(gz, a_in, s_in, t_in, g, ctx.scale)
             if _sunk('gw'):
                 gw = None
-        return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None
+        return ga, None, None, gw, gb, None, gnw, gstyle, None, None, None, None, None, None
 
 
 class _UpConvBlurTail(Function):
@@ -2314,6 +2361,8 @@ def upconv_blur_tail(x, weight, scale, bias=None, noise=None, noise_w=None, styl
                      eps=1e-8):
     """``x``: a tensor or a ``Deferred``; returns the layer's output as a ``Deferred`` (see ``upconv_blur_tail_ok``)."""
     a_in, s_in, t_in = (x.a, x.s, x.t) if isinstance(x, Deferred) else (x, None, None)
+    if isinstance(x, Deferred):
+        x.read()
     n, cin, h, w = a_in.shape
     g = Geom(n, cin, h, w, weight.shape[0], 3, 1, 1, 0)
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
@@ -2327,11 +2376,12 @@ class _ToRGBMod(Function):
     and folded back by two small kernels (csrc/mod.hip)."""
 
     @staticmethod
-    def forward(ctx, a, s_, t_, w, bias, scale, bias_scale):
+    def forward(ctx, a, s_, t_, w, bias, scale, bias_scale, link=None):
         a, w = _c(a), _c(w)
         n, cin, h, wd = a.shape
         cout = w.shape[0]
         L = _lib.lib()
+        ctx.link = link
         weff, beff = _new((n, cin, 4), a), _new((n, 4), a)
         check(L.ganlab_mod_torgb_prep_f32(_p(w), _p(bias), _p(s_), _p(t_), _p(weff), _p(beff), n, cin, cout, scale,
                                           bias_scale, _st()), 'mod_torgb_prep')
@@ -2352,7 +2402,15 @@ class _ToRGBMod(Function):
         cout = w.shape[0]
         L = _lib.lib()
         g = Geom(n, cin, h, wd, cout, 1, 0, 0)
-        ga = k_conv_dgrad(gy, w, g, ctx.scale) if ctx.needs_input_grad[0] else None      # d/d(a*s + t)
+        ga = None
+        if ctx.needs_input_grad[0]:                      # d/d(a*s + t)
+            link = ctx.link
+            if _rgb_link_ok(link, n, cin, cout, h * wd):
+                # the producer's InstanceNorm backward recomputes it from gy (RgbGradLink); the engine only needs the shape
+                link.grgb, link.wp, link.crgb = gy, _packed(w, PACK_DGRAD, ctx.scale), cout
+                ga = torch.empty((1,), dtype=a.dtype, device=a.device).expand(a.shape)
+            else:
+                ga = k_conv_dgrad(gy, w, g, ctx.scale)
         gw = gb = None
         want_w = ctx.needs_input_grad[3]
         want_b = ctx.bias_shape is not None and ctx.needs_input_grad[4]
@@ -2371,7 +2429,7 @@ class _ToRGBMod(Function):
                 gw = None
             if _sunk('gb'):
                 gb = None
-        return ga, None, None, gw, gb, None, None
+        return ga, None, None, gw, gb, None, None, None
 
 
 class _PixelNorm(Function):
@@ -3061,22 +3119,26 @@ def layer_tail_deferred(x, bias=None, noise=None, noise_w=None, style=None, bias
                         blur=False, eps=1e-8):
     """ops.layer_tail without the normalisation pass: returns a ``Deferred`` (see there) for a modulated consumer."""
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    link = RgbGradLink() if not blur else None
     y, s_, t_, mean, rstd = _LayerTailDeferred.apply(x, bias, noise, noise_w, style, float(bias_scale), a, float(slope),
-                                                     bool(blur), float(eps))
-    return Deferred(y, s_, t_, mean, rstd, style)
+                                                     bool(blur), float(eps), link)
+    return Deferred(y, s_, t_, mean, rstd, style, link)
 
 
 def conv_mod_tail(d, weight, scale, bias=None, noise=None, noise_w=None, style=None, bias_scale=1.0, act=None, slope=0.2,
                   eps=1e-8):
     """3x3 layer + its tail on a deferred input, deferred output (``_ConvModTail``)."""
     a = ACT_LRELU if act == 'lrelu' else ACT_NONE
+    d.read()
+    link = RgbGradLink()
     y, s_, t_, mean, rstd = _ConvModTail.apply(d.a, d.s, d.t, weight, bias, noise, noise_w, style, float(scale),
-                                               float(bias_scale), a, float(slope), float(eps))
-    return Deferred(y, s_, t_, mean, rstd, style)
+                                               float(bias_scale), a, float(slope), float(eps), link)
+    return Deferred(y, s_, t_, mean, rstd, style, link)
 
 
 def torgb_mod(d, weight, bias, scale, bias_scale=1.0):
-    return _ToRGBMod.apply(d.a, d.s, d.t, weight, bias, float(scale), float(bias_scale))
+    d.read()
+    return _ToRGBMod.apply(d.a, d.s, d.t, weight, bias, float(scale), float(bias_scale), d.link)
 
 
 def torgb_mod_ok(d, weight):

@@ -251,6 +251,22 @@ int ganlab_instnorm_style_bwd_act_blur_f32(const float* gy, const float* x, cons
                                            float* out, float* gb, float* gnw, int N, int C, int H, int W, int act,
                                            float slope, float bias_scale, void* workspace, size_t workspace_bytes,
                                            void* stream);
+/* The same two passes (ganlab_instnorm_style_bwd_reduce_f32, ganlab_instnorm_style_bwd_act_f32) for the generator's LAST
+ * layer, whose only reader is toRGB (stylegan/architectures.py:170-172, :398-402 - a 1x1 conv to crgb <= 4 channels): the
+ * incoming gradient  gy[n, c] = sum_k wp[k * round_up(C, 64) + c] * grgb[n, k]  is recomputed from the image gradient grgb
+ * (N, crgb, HW) and toRGB's input-gradient pack wp (scale included) instead of being written by ganlab_conv_dgrad_f32 and
+ * read back twice.  gz / gb / gnw carry the bits of that sequence given the same s1 / s2; s1 / s2 are fp64 sums in another
+ * order (equal after rounding to fp32 up to ties).  C <= 16, HW % 4 == 0, HW >= 1024. */
+int ganlab_instnorm_bwd_rgb_supported(int N, int C, int crgb, long long HW);
+size_t ganlab_instnorm_bwd_reduce_rgb_workspace(int N, int C, long long HW);
+int ganlab_instnorm_style_bwd_reduce_rgb_f32(const float* grgb, const float* wp, int crgb, const float* x,
+                                             const float* mean, const float* rstd, float* s1, float* s2, int N, int C,
+                                             long long HW, void* workspace, size_t workspace_bytes, void* stream);
+int ganlab_instnorm_style_bwd_act_rgb_f32(const float* grgb, const float* wp, int crgb, const float* x, const float* mean,
+                                          const float* rstd, const float* style, const float* s1, const float* s2,
+                                          const float* noise, float* gz, float* gb, float* gnw, int N, int C, long long HW,
+                                          int act, float slope, float bias_scale, void* workspace, size_t workspace_bytes,
+                                          void* stream);
 /* out[c] = scale * sum_{n,hw} a[n,c,hw] * (b ? b[n,hw] : 1)   (bias / noise-weight gradients) */
 int ganlab_channel_sum_f32(const float* a, const float* b_n1hw, float* out, int N, int C, long long HW,
                            float scale, void* workspace, size_t workspace_bytes, void* stream);

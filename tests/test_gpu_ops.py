@@ -920,7 +920,7 @@ def test_integration_snippet_forward_vs_oracle(ops):
 
 @pytest.mark.parametrize('shape', [(2, 16, 16, 64, 16), (3, 12, 24, 128, 10), (2, 16, 8, 64, 16)],
                          ids=['16->16@64x64', '12->10 ragged 24x128', 'two steps'])
-def test_deferred_instancenorm_chain_equals_composed(ops, shape):
+def test_deferred_instancenorm_chain_equals_composed(ops, shape, monkeypatch):
     """csrc/mod.hip: a generator block's tail with the InstanceNorm + style left to its consumers - blurred layer ->
     (deferred) -> thin plain 3x3 layer that applies the affine while staging its input and has noise + bias + LeakyReLU +
     statistics in its epilogue -> (deferred) -> toRGB with per-sample weights - against the SAME chain composed from the round-1 ops
@@ -964,6 +964,23 @@ def test_deferred_instancenorm_chain_equals_composed(ops, shape):
     names = ['x0', 'bias0', 'noise_w0', 'style0', 'w1', 'bias1', 'noise_w1', 'style1', 'w_rgb', 'b_rgb']
     for name, a, b in zip(names, grads[1], grads[0]):
         assert_close(a, b, 2e-4, 'grad ' + name)
+    # toRGB as the last layer's only reader: its input gradient is recomputed inside that layer's InstanceNorm backward
+    # (ops.RgbGradLink, csrc/pointwise.hip RgbSrc) instead of written and read back twice
+    from gan_lab_amd import _lib
+    folds = bool(_lib.lib().ganlab_instnorm_bwd_rgb_supported(n, c1, 3, h * w))
+    assert folds == (h * w >= 1024)
+    pw_dgrads = []
+    plain_dgrad = ops.k_conv_dgrad
+    monkeypatch.setattr(ops, 'k_conv_dgrad', lambda gy, w_, g, sc: (pw_dgrads.append(g.ks) if g.ks == 1 else None,
+                                                                     plain_dgrad(gy, w_, g, sc))[1])
+    monkeypatch.setenv('GANLAB_TORGB_FOLD', '0')
+    unfolded = [t_.detach() for t_ in torch.autograd.grad((deferred() * cot).sum(), params)]
+    assert len(pw_dgrads) == 1
+    monkeypatch.delenv('GANLAB_TORGB_FOLD')
+    folded = [t_.detach() for t_ in torch.autograd.grad((deferred() * cot).sum(), params)]
+    assert len(pw_dgrads) == (1 if folds else 2), 'toRGB input gradient written although the fold is supported'
+    for name, a, b in zip(names, folded, unfolded):     # (the per-plane fp64 sums are taken in another order)
+        assert_close(a, b, 1e-6, 'toRGB fold: grad ' + name)
     # a deferred tensor handed to a plain consumer is materialised - same numbers, same gradients
     d = ops.layer_tail_deferred(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
     ref = ops.layer_tail(x0, b0, nz0, nw0, st0, act='lrelu', slope=0.2, blur=True, eps=1e-8)
