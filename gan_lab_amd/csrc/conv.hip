@@ -395,6 +395,16 @@ struct FwdCfg {
   static_assert(NB >= 1, "pixel tile too small");
 };
 
+// The 64-channel tile of the vector-staged 3x3 layers (64 .. 512 channels at >= 16^2).  With the second accumulator set
+// (GL_ACC_DUMP) a 64-channel x 256-pixel workgroup tile needs ~205 registers: two waves per SIMD.  Over 128 pixels (16 x 8,
+// two accumulator tiles per channel block and wave) it needs 125 and four workgroups share a CU: measured in round 4 on the
+// plain layers at batch 32, 64 -> 64 @256^2 1.184 -> 1.152 ms, 128 @128^2 1.136 -> 1.113, 256 @64^2 1.115 -> 1.099,
+// 512 @32^2 1.115 -> 1.105 (-DGL_THICK_NB2=0 builds the 256-pixel tiles).
+#ifndef GL_THICK_NB2
+#define GL_THICK_NB2 1
+#endif
+using ThickCfg = FwdCfg<3, 4, GL_THICK_NB2 ? 4 : 5, 3, 0, XVEC>;
+
 #ifdef GL_PHASES  // tools/phase_probe.py: per-workgroup phase timestamps (debug builds only)
 __device__ unsigned long long* gl_phase_buf;
 #define GL_T(i) \
@@ -906,7 +916,7 @@ __global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_k
 // has no room for the strip bookkeeping).
 constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the AFF kernels keep in LDS
 template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
-__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4) ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4 && Cfg::NB >= 4) ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
@@ -1602,6 +1612,15 @@ template <int KS, int MB>
 int dispatch_geom(const ConvArgs& a, hipStream_t st) {
   if (a.Ho == 1 && a.Wo == 1) return launch_fwd<FwdCfg<KS, MB, 0, 0, 6, XSCALAR>>(a, st);
   const int mode = (aligned16(a.wp)) ? pick_xmode(a.in, KS, a.Wo) : XSCALAR;
+  if constexpr (GL_THICK_NB2 && KS == 3 && MB == 4) {
+    if (a.Wo >= 16 && mode == XVEC) return launch_fwd<ThickCfg>(a, st);
+  }
+#ifndef GL_MB2_NB2          // the same halving for the 32-channel tile (79 registers): measured slower, 32 -> 32 @512^2 1.237 -> 1.286 ms
+#define GL_MB2_NB2 0
+#endif
+  if constexpr (GL_MB2_NB2 && KS == 3 && MB == 2) {
+    if (a.Wo >= 16 && mode == XVEC) return launch_fwd<FwdCfg<3, 2, 4, 3, 0, XVEC>>(a, st);
+  }
   if (a.Wo >= 32) {
     if (mode == XVEC) return launch_fwd<FwdCfg<KS, MB, 5, 3, 0, XVEC>>(a, st);
     if (KS == 3 && mode == XVECUP) return launch_fwd<FwdCfg<3, MB, 5, 3, 0, XVECUP>>(a, st);
@@ -1619,6 +1638,12 @@ int dispatch_geom(const ConvArgs& a, hipStream_t st) {
   return launch_fwd<FwdCfg<KS, MBS, 2, 2, 4, XSCALAR>>(a, st);
 }
 
+// pixel tiles of the 64-channel-tile kernel where they differ from the narrower kernels' (ThickCfg: 16 x 8 pixels)
+inline long long px_tiles_mb4(long long px_tiles, int N, int Ho, int Wo, int ks) {
+  if (GL_THICK_NB2 && ks == 3 && Wo >= 16) return (long long)ceil_div(Wo, 16) * ceil_div(Ho, 8) * N;
+  return px_tiles;
+}
+
 template <int KS>
 int dispatch_co(const ConvArgs& a, hipStream_t st) {
   if (a.Cout <= 16) return dispatch_geom<KS, 1>(a, st);
@@ -1631,7 +1656,7 @@ int dispatch_co(const ConvArgs& a, hipStream_t st) {
   else if (a.Wo >= 16) px_tiles = (long long)ceil_div(a.Wo, 16) * ceil_div(a.Ho, 16) * a.in.N;
   else if (a.Wo >= 8) px_tiles = (long long)ceil_div(a.Wo, 8) * ceil_div(a.Ho, 8) * ceil_div(a.in.N, 4);
   else px_tiles = (long long)ceil_div(a.Wo, 4) * ceil_div(a.Ho, 4) * ceil_div(a.in.N, 16);
-  if (px_tiles * ceil_div(a.Cout, 64) >= 256) return dispatch_geom<KS, 4>(a, st);
+  if (px_tiles_mb4(px_tiles, a.in.N, a.Ho, a.Wo, KS) * ceil_div(a.Cout, 64) >= 256) return dispatch_geom<KS, 4>(a, st);
   if (px_tiles * ceil_div(a.Cout, 32) >= 256) return dispatch_geom<KS, 2>(a, st);
   return dispatch_geom<KS, 1>(a, st);
 }
@@ -1874,15 +1899,19 @@ int splitk_plan(int N, int Cin, int Cout, int Ho, int Wo, int ks) {
   int mb = 1;
   if (Cout <= 16) mb = 1;
   else if (Cout <= 32) mb = 2;
-  else if (px_tiles * ceil_div(Cout, 64) >= 256) mb = 4;
+  else if (px_tiles_mb4(px_tiles, N, Ho, Wo, ks) * ceil_div(Cout, 64) >= 256) mb = 4;
   else if (px_tiles * ceil_div(Cout, 32) >= 256) mb = 2;
   if (GL_ACC_DUMP && ks == 3 && mb == 4 && Wo < 16) mb = 2;      // as dispatch_geom does
+  if (mb == 4) px_tiles = px_tiles_mb4(px_tiles, N, Ho, Wo, ks);
   const long long wgs = px_tiles * ceil_div(Cout, 16 * mb);
   // K-chunk of the kernel that will run: 32 (1x1), 16 (vector-staged 16x16 tiles with <= 32 output channels per
   // workgroup), else 8; a scalar-staged fallback for unaligned pointers halves it, which keeps every split non-empty
   const int ci_t = ks == 1 ? 32 : ((Wo >= 16 && mb == 1) ? 16 : 8);
   const int chunks = round_up_c(Cin, cin_pad(ks)) / ci_t;
-  long long S = (512 + wgs - 1) / wgs;
+#ifndef GL_SPLITK_TARGET
+#define GL_SPLITK_TARGET 512
+#endif
+  long long S = (GL_SPLITK_TARGET + wgs - 1) / wgs;
   const int cap = (Ho == 1 && Wo == 1) ? 8 : 4;
   if (S > cap) S = cap;
   if (S > chunks / 4) S = chunks / 4;      // at least four K-chunks per workgroup
@@ -1976,7 +2005,12 @@ template <int KS, int NBC, int XM> using WgThinB = WgCfg<KS, NBC, 1, 4, 4, 4, 0,
 template <int KS, int NBC> using WgThinC = WgCfg<KS, NBC, 1, 4, 3, 3, 2, XSCALAR>;       // 8x8 x4 images
 template <int KS, int NBC> using WgThinD = WgCfg<KS, NBC, 1, 4, 2, 2, 4, XSCALAR>;       // 4x4 x16 images
 template <int KS, int NBC> using WgThinE = WgCfg<KS, NBC, 1, 4, 0, 0, 6, XSCALAR>;       // 1x1 x64 samples
-template <int KS, int XM> using WgThickA = WgCfg<KS, 2, 4, 1, 3, 3, 0, XM>;              // 8x8
+#ifndef GL_WGRAD_THICK_NBC
+#define GL_WGRAD_THICK_NBC 2
+#endif
+// (16 input channels per workgroup - 158 registers, three workgroups per CU instead of two - measured slower in round 4:
+// 64 -> 64 @256^2 1.227 -> 1.345 ms, 128 .. 512 channels 1.21 -> 1.29)
+template <int KS, int XM> using WgThickA = WgCfg<KS, (KS == 3 && XM == XVEC) ? GL_WGRAD_THICK_NBC : 2, 4, 1, 3, 3, 0, XM>;   // 8x8
 template <int KS> using WgThickD = WgCfg<KS, 2, 4, 1, 2, 2, 2, XSCALAR>;                 // 4x4 x4 images
 template <int KS> using WgThickE = WgCfg<KS, 2, 4, 1, 0, 0, 6, XSCALAR>;                 // 1x1 x64 samples
 
@@ -2335,7 +2369,8 @@ int ganlab_conv_fwd_aff_f32(const float* x, const float* wp, const float* aff_s,
     if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
     GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
   } else {
-    using Cfg = FwdCfg<3, 4, 5, 3, 0, XVEC>;
+    using Cfg = ThickCfg;
+    a.tiles_x = ceil_div(a.Wo, Cfg::G::TW);
     a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
@@ -2367,7 +2402,7 @@ int ganlab_conv_fwd_aff_tail_chunks(const ganlab_conv_geom* g) {
   if (!(ganlab_conv_aff_supported(g) & 1) || (g->Win % 32) != 0 || (g->Hin % 8) != 0) return 0;
   const char* e = getenv("GANLAB_CONV_TAIL");
   if (e != nullptr && e[0] == '0') return 0;
-  return (g->Win / 32) * (g->Hin / 8);
+  return (g->Win / (g->Cout <= 32 ? 32 : ThickCfg::G::TW)) * (g->Hin / 8);
 }
 
 /* A plain 3x3 generator layer with a deferred-InstanceNorm input in ONE pass over the activations, thicker than the rolling
@@ -2402,7 +2437,8 @@ int ganlab_conv_fwd_aff_tail_f32(const float* x, const float* wp, const float* a
     if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;
     GL_LAUNCH((conv_fwd_kernel<Cfg, false, false, true, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
   } else {
-    using Cfg = FwdCfg<3, 4, 5, 3, 0, XVEC>;
+    using Cfg = ThickCfg;
+    a.tiles_x = a.Wo / Cfg::G::TW;
     a.tiles_co = ceil_div(a.Cout, Cfg::CO_T);
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.tiles_n * a.tiles_co;
     if (tiles <= 0 || tiles > 0x7fffffffLL) return GANLAB_EINVAL;

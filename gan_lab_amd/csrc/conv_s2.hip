@@ -105,9 +105,9 @@ struct S2Args {
 #ifndef GL_S2_UP_NBL1
 #define GL_S2_UP_NBL1 0
 #endif
-template <int MB_, int TWL_ = 5>
+template <int MB_, int TWL_ = 5, int NB_ = 4>
 struct SCfg {
-  static constexpr int MB = MB_, NB = 4, TWL = TWL_, TW = 1 << TWL_, TH = 256 / TW;
+  static constexpr int MB = MB_, NB = NB_, TWL = TWL_, TW = 1 << TWL_, TH = 64 * NB_ / TW;
   static constexpr int CO_T = 16 * MB_;
   static constexpr int CI_T = 4;
   static constexpr int RPL = TW + 4, RL = TH + 2;             // parity-plane geometry (low-res units)
@@ -120,7 +120,7 @@ struct SCfg {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(256, 2) void conv_s2_down_kernel(S2Args p) {
+__global__ __launch_bounds__(256, Cfg::NB >= 4 ? 2 : 3) void conv_s2_down_kernel(S2Args p) {
   constexpr int MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T, PL = Cfg::PL, RPL = Cfg::RPL, COP = Cfg::COP;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
@@ -845,6 +845,11 @@ int run_S(S2Args a, hipStream_t st) {
 #define GL_S2_DOWN_W16_MB2 1
 #endif
     const long long wg64 = (long long)ceil_div(a.Wl, 16) * ceil_div(a.Hl, 16) * a.N * ceil_div(a.Cout, 64);
+#ifndef GL_S2_DOWN_W16
+#define GL_S2_DOWN_W16 0
+#endif
+    if (GL_S2_DOWN_W16 == 1) return launch_s2<SCfg<4, 4, 2>>(conv_s2_down_kernel<SCfg<4, 4, 2>>, a, st);
+    if (GL_S2_DOWN_W16 == 2) return launch_s2<SCfg<2, 4, 2>>(conv_s2_down_kernel<SCfg<2, 4, 2>>, a, st);
     if (GL_S2_DOWN_W16_MB2 && wg64 < 512) return launch_s2<SCfg<2, 4>>(conv_s2_down_kernel<SCfg<2, 4>>, a, st);
     return launch_s2<SCfg<4, 4>>(conv_s2_down_kernel<SCfg<4, 4>>, a, st);
   }
@@ -853,21 +858,34 @@ int run_S(S2Args a, hipStream_t st) {
 #define GL_S2_DOWN_MB2_CIN 0
 #endif
   if (a.Cout <= 32 || (GL_ACC_DUMP && a.Cin <= GL_S2_DOWN_MB2_CIN)) return launch_s2<SCfg<2>>(conv_s2_down_kernel<SCfg<2>>, a, st);
+#ifndef GL_S2_DOWN_NB2      // the 64-channel tile over 128 low-resolution pixels (16 x 8): half the accumulators, see conv.hip ThickCfg
+#define GL_S2_DOWN_NB2 1
+#endif
+  if (GL_S2_DOWN_NB2 && GL_ACC_DUMP) return launch_s2<SCfg<4, 4, 2>>(conv_s2_down_kernel<SCfg<4, 4, 2>>, a, st);
   return launch_s2<SCfg<4>>(conv_s2_down_kernel<SCfg<4>>, a, st);
 }
 
+#ifndef GL_S2_UP_MB1_CIN
+#define GL_S2_UP_MB1_CIN 128
+#endif
 int run_T(S2Args a, hipStream_t st) {
   if (gl_s2_roll_supported(1, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.x, a.y))
     return gl_s2_roll_launch(1, a.x, a.wp, a.bias, a.y, a.N, a.Cin, a.Cout, a.Hl, a.Wl, a.Cin_p, a.Cout_p, a.bias_scale,
                              a.act, a.slope, st, a.aff_s, a.aff_t);
   if (a.aff_s != nullptr) {       // deferred-InstanceNorm input: the 32-channel-tile kernel only (ganlab_conv_s2_aff_supported)
     if (a.Cout <= 16 || a.Cin > S2_AFF_MAXC) return GANLAB_EUNSUPPORTED;
+    if (GL_ACC_DUMP && a.Cin >= GL_S2_UP_MB1_CIN) return launch_s2<TCfg<1, 2>>(conv_s2_up_kernel<TCfg<1, 2>, true>, a, st);
     return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>, true>, a, st);
   }
   if (a.Cout <= 16) return launch_s2<TCfg<1, 4>>(conv_s2_up_kernel<TCfg<1, 4>>, a, st);
 #if GL_S2_UP_NBL1
   return launch_s2<TCfg<2, 1>>(conv_s2_up_kernel<TCfg<2, 1>>, a, st);
 #endif
+  // 16 output channels per workgroup where the contraction is long (>= 128 channels): 113 registers with the second
+  // accumulator set against 208 for the 32-channel tile, four workgroups per CU against two - measured in round 4 at batch 32,
+  // input gradient of 128 -> 256 pool @128^2 1.035 -> 0.998 ms, 256 -> 512 @64^2 1.027 -> 0.990, forward of 256 -> 128 up @64^2
+  // 1.035 -> 0.998, 512 -> 256 @32^2 1.025 -> 0.989; with 64 contracted channels the extra patch staging loses 1 %
+  if (GL_ACC_DUMP && a.Cin >= GL_S2_UP_MB1_CIN) return launch_s2<TCfg<1, 2>>(conv_s2_up_kernel<TCfg<1, 2>>, a, st);
   if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
   // 32 output channels per workgroup for the thick layers as well: the 64-channel tile keeps 128 accumulator registers
   // (219 VGPRs, two workgroups per CU) and measured 3-4 % slower on every layer than this one (123 VGPRs, four per CU)
