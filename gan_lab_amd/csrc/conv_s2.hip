@@ -886,6 +886,8 @@ int run_T(S2Args a, hipStream_t st) {
   // input gradient of 128 -> 256 pool @128^2 1.035 -> 0.998 ms, 256 -> 512 @64^2 1.027 -> 0.990, forward of 256 -> 128 up @64^2
   // 1.035 -> 0.998, 512 -> 256 @32^2 1.025 -> 0.989; with 64 contracted channels the extra patch staging loses 1 %
   if (GL_ACC_DUMP && a.Cin >= GL_S2_UP_MB1_CIN) return launch_s2<TCfg<1, 2>>(conv_s2_up_kernel<TCfg<1, 2>>, a, st);
+  // (short contractions, measured in round 4 on 32 -> 64 pool @512^2 input gradient / 64 -> 32 up @256^2 forward: the 16-channel
+  // tile 1.131 -> 1.113..1.137 / 1.131 -> 1.121..1.137 ms = noise; 32 channels x 64 low-res pixels 1.170 / 1.169: slower)
   if (a.Cout <= 32) return launch_s2<TCfg<2, 2>>(conv_s2_up_kernel<TCfg<2, 2>>, a, st);
   // 32 output channels per workgroup for the thick layers as well: the 64-channel tile keeps 128 accumulator registers
   // (219 VGPRs, two workgroups per CU) and measured 3-4 % slower on every layer than this one (123 VGPRs, four per CU)
