@@ -1328,8 +1328,11 @@ struct WgCfg {
 #ifndef GL_WGRAD_MINW
 #define GL_WGRAD_MINW 1
 #endif
+#ifndef GL_WGRAD_THICK_MINW
+#define GL_WGRAD_THICK_MINW 1
+#endif
 template <class Cfg, bool AFF = false>
-__global__ __launch_bounds__(256, GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, (GL_WGRAD_THICK_MINW > 1 && Cfg::WM == 4 && Cfg::G::XMODE == XVEC && Cfg::KS == 3 && !AFF) ? GL_WGRAD_THICK_MINW : GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, NBC = Cfg::NBC, WK = Cfg::WK;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, GP = Cfg::GP;
@@ -1390,10 +1393,77 @@ __global__ __launch_bounds__(256, GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArg
   float gs[Cfg::GVEC ? 1 : GPT];
 
   const int n_tiles = p.tiles_n * p.tiles_y * p.tiles_x;
+#ifndef GL_WGRAD_DESC
+#define GL_WGRAD_DESC 1
+#endif
+  // Vector staging, one image per tile (the >= 8-wide maps): loads through buffer descriptors over this image's planes - no
+  // 64-bit addresses, no exec-mask branches - with everything that does not depend on the tile hoisted out of the tile loop
+  // (the kernel is bound by what a wave issues per 64-pixel tile NEXT TO its 288 MFMAs, at two workgroups per CU: descriptor
+  // loads alone took 64 -> 64 @256^2 x32 from 1.238 to 1.193 ms, round 4).
+  constexpr bool DESCW = GL_WGRAD_DESC && G::XMODE == XVEC && G::NI == 1 && Cfg::GVEC;
+  constexpr int XPT = XS_t::PT;
+  [[maybe_unused]] int xrel[DESCW ? XPT : 1], xyx[DESCW ? XPT : 1];      // ci*plane + (r-1)*Wi + 4q - LP (or INT_MIN) ; (r-1) | (4q-LP) << 16
+  [[maybe_unused]] int grel[DESCW ? GPT : 1], gyx[DESCW ? GPT : 1];      // co*oplane + ty*Wo + tx (or INT_MIN) ; ty | tx << 16
+  constexpr int NOITEM = (int)0x80000000;
+  if constexpr (DESCW) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int e = tid + i * 256;
+      const int q = e % G::ROW4;
+      const int t = e / G::ROW4;
+      const int r = t % G::R, ci = t / G::R;
+      xst.loff[i] = (ci * PLANE + r * G::RP + 4 * q) | (ci << 20);
+      const int dy = r - G::PADC, dx = 4 * q - G::LP;
+      xrel[i] = (e < XS_t::NITEMS && ci0 + ci < p.in.Cin) ? ci * plane + dy * p.in.Wi + dx : NOITEM;
+      xyx[i] = (dy & 0xffff) | (dx << 16);
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const int j = gj[i];
+      const int ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1), cog = co0 + gco[i];
+      grel[i] = (j >= 0 && cog < p.Cout) ? cog * oplane + ty * p.Wo + tx : NOITEM;
+      gyx[i] = ty | (tx << 16);
+    }
+  }
+  auto load_tile_at = [&](int txi, int tyi, int tni) {
+    if constexpr (DESCW) {
+    const int ox0 = txi * TW, oy0 = tyi * TH, n0 = tni;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in.x + (long long)n0 * p.in.Cin * plane), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.gy + (long long)n0 * p.Cout * oplane), 0, (unsigned)(p.Cout * oplane * 4), 0x00020000);
+    const int xbase = oy0 * p.in.Wi + ox0, gbase = oy0 * p.Wo + ox0, soff = ci0 * plane * 4;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int vy = oy0 + (int)(short)(xyx[i] & 0xffff), vx = ox0 + (xyx[i] >> 16);
+      const bool ok = xrel[i] != NOITEM && (unsigned)vy < (unsigned)p.in.Hi && (unsigned)vx < (unsigned)p.in.Wi;
+      xst.goff[i] = ok ? xrel[i] + xbase : -1;        // (x_store's affine form asks "inside the image?")
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (xrel[i] + xbase) * 4 : NOITEM, soff, 0);
+      xr.v[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+    if constexpr (AFF) {
+      if (tid < 2 * CI_T) {
+        const int c = ci0 + (tid % CI_T);
+        const float* src = tid < CI_T ? p.in.aff_s : p.in.aff_t;
+        aff_reg = c < p.in.Cin ? src[(long long)n0 * p.in.Cin + c] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GPT; ++i) {
+      const bool ok = grel[i] != NOITEM && oy0 + (gyx[i] & 0xffff) < p.Ho && ox0 + (gyx[i] >> 16) < p.Wo;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? (grel[i] + gbase) * 4 : NOITEM, 0, 0);
+      gv[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    }
+    }
+  };
   auto load_tile = [&](int tile) {
     const int txi = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
     const int tyi = t2 % p.tiles_y, tni = t2 / p.tiles_y;
+    if constexpr (DESCW) {
+      load_tile_at(txi, tyi, tni);
+      return;
+    }
     const int ox0 = txi * TW, oy0 = tyi * TH, n0 = tni * NI;
     xst.init(p.in, tid, n0, oy0, ox0);
     if constexpr (G::XMODE != XSCALAR)
@@ -1419,6 +1489,9 @@ __global__ __launch_bounds__(256, GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArg
   };
 
   int tile = split;
+  // (DESCW) the tile coordinates advance by S's own (x, y, image) digits with carries instead of two divisions per tile
+  [[maybe_unused]] int txi = tile % p.tiles_x, tyi = (tile / p.tiles_x) % p.tiles_y, tni = tile / (p.tiles_x * p.tiles_y);
+  [[maybe_unused]] const int sdx = p.S % p.tiles_x, sdy = (p.S / p.tiles_x) % p.tiles_y, sdn = p.S / (p.tiles_x * p.tiles_y);
   if (tile < n_tiles) load_tile(tile);
   while (tile < n_tiles) {
     if constexpr (AFF) {      // nobody reads the table between the previous tile's second barrier and this one
@@ -1444,7 +1517,18 @@ __global__ __launch_bounds__(256, GL_WGRAD_MINW) void conv_wgrad_kernel(WgradArg
     }
     __syncthreads();
     const int next = tile + p.S;
-    if (next < n_tiles) load_tile(next);  // in flight during the MFMA phase
+    if constexpr (DESCW) {
+      txi += sdx;
+      int carry = txi >= p.tiles_x ? 1 : 0;
+      txi -= carry * p.tiles_x;
+      tyi += sdy + carry;
+      carry = tyi >= p.tiles_y ? 1 : 0;
+      tyi -= carry * p.tiles_y;
+      tni += sdn + carry;
+      if (next < n_tiles) load_tile_at(txi, tyi, tni);  // in flight during the MFMA phase
+    } else {
+      if (next < n_tiles) load_tile(next);
+    }
     for (int q = wk; q < PX_T / 4; q += WK) {
       const int j = 4 * q + (lane >> 4);
       const int ni = j >> (G::TWL + G::THL), ty = (j >> G::TWL) & (TH - 1), tx = j & (TW - 1);
@@ -2454,6 +2538,7 @@ int ganlab_conv_wgrad_aff_f32(const float* gy, const float* x, const float* aff_
                               void* stream) {
   if (!(ganlab_conv_aff_supported(g) & 2)) return GANLAB_EUNSUPPORTED;
   if (!gy || !x || !gw || !aff_s || !aff_t || !aligned16(x) || !aligned16(gy)) return GANLAB_EINVAL;
+  if ((long long)g->Cout * g->Hin * g->Win * 4 >= 0x7fffffffLL) return GANLAB_EINVAL;
   PatchArgs in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, 0);
   in.aff_s = aff_s; in.aff_t = aff_t;
   const int ho = g->Hin, wo = g->Win;
@@ -2509,6 +2594,8 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   int ho, wo;
   if (ganlab_conv_out_hw(g, &ho, &wo) != GANLAB_OK || !gy || !x || !gw) return GANLAB_EINVAL;
   if ((long long)g->Cin * g->Hin * g->Win * 64 >= 0x7fffffffLL && g->Hin * g->Win < 64) return GANLAB_EINVAL;
+  // (byte offsets inside one image are 32-bit: buffer-descriptor loads of the vector-staged kernels)
+  if ((long long)g->Cin * g->Hin * g->Win * 4 >= 0x7fffffffLL || (long long)g->Cout * ho * wo * 4 >= 0x7fffffffLL) return GANLAB_EINVAL;
   const PatchArgs in = make_patch(x, g->N, g->Cin, g->Hin, g->Win, g->pad, g->up);
   const WgPlan pl = plan_wgrad(in, gy, g->ks, g->Cout, ho, wo);
   const long long nw = (long long)g->Cout * g->Cin * g->ks * g->ks;

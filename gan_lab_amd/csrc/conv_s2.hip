@@ -658,8 +658,11 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_kernel(W2Args p) {
   const int a_py = (wk == 0 || wk == 2) ? 1 : 0, a_dy = wk == 0 ? -1 : (wk == 3 ? 1 : 0);
   const int tap_base = (a_py * 2 * 16) * PL + a_dy * RPL;
 
-  // tile-independent descriptor parts
-  int xrel[XPT], xl[XPT];   // (hr, q) packed ; LDS offset | ch<<20
+  // Tile-independent parts of the staging descriptors; loads go through buffer descriptors over this image's planes (no 64-bit
+  // addresses, no exec-mask branches) and the tile coordinates advance by S's own digits with carries: the kernel is bound by
+  // what a wave issues per tile next to its MFMAs (conv.hip, conv_wgrad_kernel DESCW).
+  constexpr int NOITEM = (int)0x80000000;
+  int xrel[XPT], xyx[XPT], xl[XPT];   // ch*hplane + dy*W + dx (or NOITEM) ; dy | dx << 16 ; LDS offset (or -1)
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int e = tid + i * 256;
@@ -667,66 +670,77 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_kernel(W2Args p) {
     const int t = e / Cfg::HROW4;
     const int hr = t % Cfg::HROWS, ch = t / Cfg::HROWS;
     const int ly = hr >> 1, py = hr & 1;
-    xl[i] = e < Cfg::NXI ? ((((py * 2) * 16 + ch) * PL + ly * RPL + 2 * q) | (ch << 20)) : -1;
-    xrel[i] = (hr << 8) | q;
+    xl[i] = e < Cfg::NXI ? (((py * 2) * 16 + ch) * PL + ly * RPL + 2 * q) : -1;
+    const int dy = hr - 2, dx = 4 * q - 4;
+    xrel[i] = (e < Cfg::NXI && ch0 + ch < p.Ch) ? (ch0 + ch) * hplane + dy * W + dx : NOITEM;
+    xyx[i] = (dy & 0xffff) | (dx << 16);
   }
-  int gl_[GPT], gj[GPT], gc[GPT];
+  int gl_[GPT], grel[GPT], gyx[GPT];
 #pragma unroll
   for (int i = 0; i < GPT; ++i) {
     const int e = tid + i * 256;
     const int j = (e % (PX_T / 4)) * 4, c = e / (PX_T / 4);
-    gj[i] = e < Cfg::NGI ? j : -1;
-    gc[i] = c;
-    gl_[i] = c * GP + j;
+    const int ty = j >> Cfg::TWL, tx = j & (TW - 1);
+    gl_[i] = e < Cfg::NGI ? c * GP + j : -1;
+    grel[i] = (e < Cfg::NGI && cl0 + c < p.Cl) ? (cl0 + c) * lplane + ty * p.Wl + tx : NOITEM;
+    gyx[i] = ty | (tx << 16);
   }
   float4 xr[XPT], gr[GPT];
   const int tiles_img = p.tiles_x * p.tiles_y, n_tiles = p.N * tiles_img;
-  auto load_tile = [&](int tile) {
-    const int n = tile / tiles_img, t2 = tile % tiles_img;
-    const int tyi = t2 / p.tiles_x, txi = t2 % p.tiles_x;
+  auto load_tile_at = [&](int txi, int tyi, int n) {
     const int ox0 = txi * TW, oy0 = tyi * TH;
-    const float* hb = p.high + ((long long)n * p.Ch + ch0) * hplane;
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.high + (long long)n * p.Ch * hplane), 0, (unsigned)(p.Ch * hplane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.low + (long long)n * p.Cl * lplane), 0, (unsigned)(p.Cl * lplane * 4), 0x00020000);
+    const int hbase = 2 * oy0 * W + 2 * ox0, lbase = oy0 * p.Wl + ox0;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      const int hr = xrel[i] >> 8, q = xrel[i] & 0xff;
-      const int ch = (xl[i] >> 20) & 0x3ff;
-      const int gy_ = 2 * oy0 - 2 + hr, gx_ = 2 * ox0 - 4 + 4 * q;
-      const bool ok = xl[i] != -1 && ch0 + ch < p.Ch && (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W;
-      xr[i] = ok ? *reinterpret_cast<const float4*>(hb + (long long)ch * hplane + gy_ * W + gx_)
-                 : float4{0.f, 0.f, 0.f, 0.f};
+      const int vy = 2 * oy0 + (int)(short)(xyx[i] & 0xffff), vx = 2 * ox0 + (xyx[i] >> 16);
+      const bool ok = xrel[i] != NOITEM && (unsigned)vy < (unsigned)H && (unsigned)vx < (unsigned)W;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, ok ? (xrel[i] + hbase) * 4 : NOITEM, 0, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
-    const float* lb = p.low + ((long long)n * p.Cl + cl0) * lplane;
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
-      const int j = gj[i];
-      const int oy = oy0 + (j >> Cfg::TWL), ox = ox0 + (j & (TW - 1));
-      const bool ok = j >= 0 && cl0 + gc[i] < p.Cl && oy < p.Hl && ox < p.Wl;
-      gr[i] = ok ? *reinterpret_cast<const float4*>(lb + (long long)gc[i] * lplane + oy * p.Wl + ox)
-                 : float4{0.f, 0.f, 0.f, 0.f};
+      const bool ok = grel[i] != NOITEM && oy0 + (gyx[i] & 0xffff) < p.Hl && ox0 + (gyx[i] >> 16) < p.Wl;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_l, ok ? (grel[i] + lbase) * 4 : NOITEM, 0, 0);
+      gr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
   };
   int tile = split;
-  if (tile < n_tiles) load_tile(tile);
+  int txi = tile % p.tiles_x, tyi = (tile / p.tiles_x) % p.tiles_y, tni = tile / tiles_img;
+  const int sdx = p.S % p.tiles_x, sdy = (p.S / p.tiles_x) % p.tiles_y, sdn = p.S / tiles_img;
+  if (tile < n_tiles) load_tile_at(txi, tyi, tni);
   while (tile < n_tiles) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       if (xl[i] != -1) {
-        const int l = xl[i] & 0xfffff;
+        const int l = xl[i];
         *reinterpret_cast<float2*>(Xs + l) = float2{xr[i].x, xr[i].z};
         *reinterpret_cast<float2*>(Xs + l + 16 * PL) = float2{xr[i].y, xr[i].w};
       }
     }
 #pragma unroll
     for (int i = 0; i < GPT; ++i) {
-      if (gj[i] >= 0) {
+      if (gl_[i] >= 0) {
         *reinterpret_cast<float2*>(Gs + gl_[i]) = float2{gr[i].x, gr[i].y};
         *reinterpret_cast<float2*>(Gs + gl_[i] + 2) = float2{gr[i].z, gr[i].w};
       }
     }
     __syncthreads();
     const int next = tile + p.S;
-    if (next < n_tiles) load_tile(next);   // (issued inside the K loop instead: same-box A/B 288.4 vs 287.6 ms/step - no gain)
+    {
+      txi += sdx;
+      int carry = txi >= p.tiles_x ? 1 : 0;
+      txi -= carry * p.tiles_x;
+      tyi += sdy + carry;
+      carry = tyi >= p.tiles_y ? 1 : 0;
+      tyi -= carry * p.tiles_y;
+      tni += sdn + carry;
+    }
+    if (next < n_tiles) load_tile_at(txi, tyi, tni);   // (issued inside the K loop instead: same-box A/B 288.4 vs 287.6 ms/step - no gain)
 #pragma unroll 4
     for (int q = 0; q < PX_T / 4; ++q) {
       const int j = 4 * q + (lane >> 4);
@@ -816,7 +830,8 @@ bool s2_ok(const ganlab_conv_geom* g, int* Hl, int* Wl) {
   }
   // vector staging: rows of the low tensor must be float4-aligned, and the tiles are 16/32 wide
   if (hl < 4 || wl < 16 || (wl & 3)) return false;
-  if ((long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * hl * wl * 4 >= 0x7fffffffLL) return false;
+  // (byte offsets inside one image's HIGH-resolution planes - 4 hl wl floats per channel - are 32-bit)
+  if ((long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * hl * wl * 16 >= 0x7fffffffLL) return false;
   *Hl = hl; *Wl = wl;
   return true;
 }
