@@ -455,6 +455,204 @@ __global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll_kernel(W2RArgs p) {
       }
 }
 
+// The same kernel stepping by HALF steps (one low row = two new high rows per barrier).  In the kernel above a step is
+// [128 MFMAs per wave][barrier][LDS stores of the prefetched rows][barrier]: the stores cannot start earlier because the four new
+// high rows overwrite slots the step is still reading, and they cost 10 % of the kernel (a build without them: 1.105 -> 0.946 ms
+// on 128 -> 256 pool @128^2 x32; without the loads as well: the loads are 4 %).  A half step h reads high rel rows 2h .. 2h+3
+// and low row h; the rows the NEXT half step adds (2h+4, 2h+5; low row h+1) go to the two ring slots / the low slot that died
+// at the previous barrier, so their LDS stores are issued at the top of half step h, in front of its 64 MFMAs, and ONE barrier
+// per half step publishes them.  Loads are issued one half step before their stores.  Everything that does not depend on the
+// half step is hoisted to the unit (column offset and its bounds test) or to the workgroup.
+template <int NBA, bool AFF>
+__global__ __launch_bounds__(256, 3) void conv_s2_wgrad_roll2_kernel(W2RArgs p) {
+  constexpr int CL_T = 16 * NBA, LROW = CL_T * W2_LP;
+  constexpr int HITEMS = 2 * 16 * WR_XQ, HPT = (HITEMS + 255) / 256;      // two high rows: 576 float4, 3 per thread
+  constexpr int LITEMS = CL_T * W2_LQ;                                    // one low row: 256 / 128 float4
+  static_assert(LITEMS <= 256, "one low item per thread");
+  __shared__ __attribute__((aligned(16))) float smem[WR_SLOTS * W2_HSLOT + W2_RL * LROW];
+  __shared__ float afftab[AFF ? 2 * CL_T : 1];
+  // writes that do not apply (the third item of threads >= 64, the left-halo float4's E pair, a step past the unit's end) go
+  // to the thread's own 16-byte slot here instead of being branched around: the half step stays ONE basic block, which is
+  // what lets the staging instructions be scheduled between its MFMAs
+  __shared__ __attribute__((aligned(16))) float sink_s[256 * 4];
+  float* ring = smem;
+  float* lbuf = smem + WR_SLOTS * W2_HSLOT;
+  const int tid = threadIdx.x, lane = tid & 63, wa = tid >> 6;          // wa = tap row a of this wave
+  float* sink = sink_s + 4 * tid;
+  int bid = p.xcd ? gl_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int split = bid % p.S;
+  bid /= p.S;
+  const int ch_t = bid % p.tiles_ch, cl_t = bid / p.tiles_ch;
+  const int ch0 = ch_t * 16, cl0 = cl_t * CL_T;
+  const int H = 2 * p.Hl, W = 2 * p.Wl, hplane = H * W, lplane = p.Hl * p.Wl;
+
+  // workgroup-level item descriptors: channel byte offset (or OOB), LDS offset | row of the pair << 16 | (q > 0) << 17 (or -1)
+  int hlo[HPT];
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % WR_XQ, t = e / WR_XQ;
+    const int ch = t & 15, k = t >> 4;
+    hlo[i] = e < HITEMS ? ((ch * W2_HP + 2 * q) | (k << 16) | ((q > 0 ? 1 : 0) << 17)) : -1;
+  }
+  const int lq_ = tid % W2_LQ, lcl = tid / W2_LQ;
+  const bool lvalid = tid < LITEMS;
+  const int lch = (lvalid && cl0 + lcl < p.Cl) ? (cl0 + lcl) * lplane * 4 : WR_OOB;
+  const int llo = lcl * W2_LP + 4 * lq_;
+
+  f32x4 acc[4][NBA];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m) acc[b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = (lane & 15) * W2_LP + 4 * (lane >> 4);
+  const int b_off = (lane & 15) * W2_HP + 4 * (lane >> 4);
+  float4 xr[2][HPT], lr[2];
+
+  for (int u = split; u < p.units; u += p.S) {
+    const int col = u % p.cols;
+    const int t2 = u / p.cols;
+    const int strip = t2 % p.strips, n = t2 / p.strips;
+    const int X0 = col * W2_TWL, Y0 = strip * p.spu * W2_RL;
+    const int nh = W2_RL * min(p.spu, p.Hl / W2_RL - strip * p.spu);     // half steps = low rows of this unit
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.high + (long long)n * p.Ch * hplane), 0, (unsigned)(p.Ch * hplane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.low + (long long)n * p.Cl * lplane), 0, (unsigned)(p.Cl * lplane * 4), 0x00020000);
+    // unit-level: column offset folded in, its bounds test done
+    int hu[HPT];      // (channel offset recomputed per unit: three registers less across the half-step loop)
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int e = tid + i * 256;
+      const int ch = (e / WR_XQ) & 15, vx = 2 * X0 - 4 + 4 * (e % WR_XQ);
+      hu[i] = (e < HITEMS && ch0 + ch < p.Ch && (unsigned)vx < (unsigned)W) ? (ch0 + ch) * hplane * 4 + vx * 4 : WR_OOB;
+    }
+    const int lu = lch != WR_OOB ? lch + (Y0 * p.Wl + X0 + 4 * lq_) * 4 : WR_OOB;
+    const int vy0 = 2 * Y0 - 1, W4 = W * 4, Wl4 = p.Wl * 4;
+
+    // two register sets: a half step stores set h & 1 (loaded TWO half steps ago: ~4000 MFMA cycles of cover for the loads;
+    // with one set and one half step of distance the first store piece waited for HBM) and refills it for half step h + 2
+    auto load_h2_item = [&](int r0, bool on, int set, int i) {   // item i of high rel rows r0, r0 + 1 (rel row r = high row 2 Y0 - 1 + r)
+      const int vy = vy0 + r0 + ((hlo[i] >> 16) & 1);
+      const int off = (on && hu[i] != WR_OOB && (unsigned)vy < (unsigned)H) ? hu[i] + vy * W4 : WR_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, off, 0, 0);
+      xr[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto load_h2 = [&](int r0, bool on, int set) {
+#pragma unroll
+      for (int i = 0; i < HPT; ++i) load_h2_item(r0, on, set, i);
+    };
+    auto store_h2_item = [&](int r0, int set, int i) {         // r0 even: slots r0 % 6 and r0 % 6 + 1
+      const int s0 = (r0 % WR_SLOTS) * W2_HSLOT;
+      const bool valid = hlo[i] != -1, inner = valid && (hlo[i] & (1 << 17));
+      float* d = ring + s0 + ((hlo[i] >> 16) & 1) * W2_HSLOT + (hlo[i] & 0xffff);
+      *reinterpret_cast<float2*>(inner ? d - 2 : sink) = float2{xr[set][i].x, xr[set][i].z};      // E[2q-2], E[2q-1]
+      *(inner ? d + 35 : sink + 2) = xr[set][i].y;                                                // O'[2q-1]
+      *(valid ? d + 36 : sink + 3) = xr[set][i].w;                                                // O'[2q]
+    };
+    auto store_h2 = [&](int r0, int set) {
+#pragma unroll
+      for (int i = 0; i < HPT; ++i) store_h2_item(r0, set, i);
+    };
+    auto load_l1 = [&](int row, bool on, int set) {     // low row Y0 + row
+      const int off = (on && lu != WR_OOB) ? lu + row * Wl4 : WR_OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_l, off, 0, 0);
+      lr[set] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto store_l1 = [&](int slot, int set) {
+      float4 v = lr[set];
+      if constexpr (AFF) {
+        const bool ok = lch != WR_OOB;
+        const float sv = ok ? afftab[ok ? lcl : 0] : 0.f, tv = ok ? afftab[ok ? CL_T + lcl : 0] : 0.f;
+        v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+      }
+      *reinterpret_cast<float4*>(lvalid ? lbuf + slot * LROW + llo : sink) = v;
+    };
+
+    if constexpr (AFF) {
+      if (tid < 2 * CL_T) {
+        const int c = cl0 + (tid % CL_T);
+        afftab[tid] = c < p.Cl ? (tid < CL_T ? p.aff_s : p.aff_t)[(long long)n * p.Cl + c] : 0.f;
+      }
+      __syncthreads();
+    }
+    load_h2(0, true, 0);
+    load_l1(0, true, 0);
+    load_h2(2, true, 1);
+    store_h2(0, 0);
+    store_l1(0, 0);
+    store_h2(2, 1);
+    load_h2(4, true, 0);           // stored in half step 0
+    load_l1(1, true, 0);
+    load_h2(6, nh > 2, 1);         // stored in half step 1
+    load_l1(2, nh > 2, 1);
+    __syncthreads();
+    // one half step; `par` = h & 1 is a literal at both call sites (register-set index, low slot)
+    auto half_step = [&](int h, int par) {
+      const int sbase = ((2 * h + wa) % WR_SLOTS) * W2_HSLOT + b_off;
+      const float* lrow_s = lbuf + par * LROW + a_off;
+      float4 av[2][NBA], e4[2], o4[2];
+      float2 e2[2], o2[2];
+      auto fetch = [&](int g, int buf) {
+        const float* src = ring + sbase + 16 * g;
+        e4[buf] = *reinterpret_cast<const float4*>(src);
+        e2[buf] = *reinterpret_cast<const float2*>(src + 4);
+        o4[buf] = *reinterpret_cast<const float4*>(src + 36);
+        o2[buf] = *reinterpret_cast<const float2*>(src + 40);
+#pragma unroll
+        for (int m = 0; m < NBA; ++m) av[buf][m] = *reinterpret_cast<const float4*>(lrow_s + m * 16 * W2_LP + 16 * g);
+      };
+      fetch(0, 0);
+      fetch(1, 1);
+      // The staging work of the half step in eight pieces, one behind each group of 4 NBA MFMAs (order pinned): what the next
+      // half step adds goes to LDS (past the unit's end: zeros into slots nobody reads again), then the same register set is
+      // refilled for half step h + 2.  Issued in front of the MFMAs none of it is covered by this wave's own matrix work.
+      static_assert(HPT == 3, "eight staging pieces");
+      auto piece = [&](int k) {
+        if (k < 3) store_h2_item(2 * h + 4, par, k);
+        else if (k == 3) store_l1(par ^ 1, par);
+        else if (k < 7) load_h2_item(2 * h + 8, h + 3 < nh, par, k - 4);
+        else load_l1(h + 3, h + 3 < nh, par);
+      };
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float eE[5] = {e4[g].x, e4[g].y, e4[g].z, e4[g].w, e2[g].x};
+        const float eO[5] = {o4[g].x, o4[g].y, o4[g].z, o4[g].w, o2[g].x};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bv[4] = {eO[q], eE[q], eO[q + 1], eE[q + 1]};
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int m = 0; m < NBA; ++m) {
+              const float a = q == 0 ? av[g][m].x : (q == 1 ? av[g][m].y : (q == 2 ? av[g][m].z : av[g][m].w));
+              acc[b][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[b], acc[b][m], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          piece(g * 4 + q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    };
+    for (int h = 0; h < nh; h += 2) {      // nh is even (two low rows per step of the plan)
+      half_step(h, 0);
+      half_step(h + 1, 1);
+    }
+  }
+  float* dst = p.part + (long long)split * 16 * p.Cl * p.Ch;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int m = 0; m < NBA; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cl = cl0 + m * 16 + (lane >> 4) * 4 + r, ch = ch0 + (lane & 15);
+        if (cl < p.Cl && ch < p.Ch) dst[((long long)(wa * 4 + b) * p.Cl + cl) * p.Ch + ch] = acc[b][m][r];
+      }
+}
+
 inline bool wr_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -576,6 +774,17 @@ int gl_wgrad_s2_roll_launch(const float* low, const float* high, float* part, in
   w2r_plan(a);
   const long long grid = (long long)a.tiles_cl * a.tiles_ch * a.S;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  static const int half = [] { const char* e = getenv("GANLAB_W2R_HALF"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (half) {            // half-step kernel (default; GANLAB_W2R_HALF=0: the whole-step kernel, same-process A/B)
+    if (aff_s != nullptr) {
+      if (a.Cl > 16) GL_LAUNCH((conv_s2_wgrad_roll2_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      else GL_LAUNCH((conv_s2_wgrad_roll2_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    } else {
+      if (a.Cl > 16) GL_LAUNCH((conv_s2_wgrad_roll2_kernel<2, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      else GL_LAUNCH((conv_s2_wgrad_roll2_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
+    return GL_CHECK_LAUNCH();
+  }
   if (aff_s != nullptr) {
     if (a.Cl > 16) GL_LAUNCH((conv_s2_wgrad_roll_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
     else GL_LAUNCH((conv_s2_wgrad_roll_kernel<1, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
