@@ -1366,7 +1366,10 @@ __global__ __launch_bounds__(256, (GL_WGRAD_THICK_MINW > 1 && Cfg::WM == 4 && Cf
     ci_t = bid % p.tiles_ci;
     co_t = bid / p.tiles_ci;
   }
-  const int co0 = co_t * CO_T, ci0 = ci_t * CI_T;
+  // (workgroup-uniform; said explicitly so that buffer descriptors and scalar offsets built from them stay in SGPRs - without it
+  // every descriptor load of the tile sits in a waterfall loop over the "divergent" channel offset)
+  const int co0 = __builtin_amdgcn_readfirstlane(co_t) * CO_T, ci0 = __builtin_amdgcn_readfirstlane(ci_t) * CI_T;
+  split = __builtin_amdgcn_readfirstlane(split);
   const int plane = p.in.Hi * p.in.Wi, oplane = p.Ho * p.Wo;
 
   f32x4 acc[KK][NBC];
