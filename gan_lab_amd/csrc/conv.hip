@@ -915,8 +915,12 @@ __global__ __launch_bounds__(256, (RW_NSLOTS == 6 ? 4 : 3)) void conv_fwd_roll_k
 // One tile per workgroup (thick layers: dozens of K-chunks per tile amortise the set-up, and the register budget
 // has no room for the strip bookkeeping).
 constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the AFF kernels keep in LDS
+#ifndef GL_FWD_PIPE_WG
+#define GL_FWD_PIPE_WG 4
+#endif
 template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
-__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4 && Cfg::NB >= 4) ? 2 : 3)) void conv_fwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4 && Cfg::NB >= 4) ? 2 :
+                                   (Cfg::KS == 3 && Cfg::MB == 4 && Cfg::NB == 2 && Cfg::G::XMODE == XVEC && !SPLITK) ? GL_FWD_PIPE_WG : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
@@ -989,6 +993,141 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       for (int nb = 0; nb < NB; ++nb) acc2[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // ---- PIPE: the 64-channel x 128-pixel tile of the thick 3x3 layers by HALF chunks ------------------------------------------
+  // The chunk loop below is [barrier][registers -> LDS][barrier][loads][144 MFMAs per wave]: a build without the LDS stores runs
+  // 256 -> 256 @64^2 in 1.035 instead of 1.101 ms (0.95 of the peak) - nothing of this workgroup covers them.  Here the 8-channel
+  // chunk's LDS space holds TWO images of a 4-channel half chunk: the stores of half chunk h+1 go to the image that died at the
+  // previous barrier, in pieces behind the K-steps (taps) of half chunk h's MFMAs, its loads were issued two half chunks earlier
+  // (two register sets), and ONE barrier per half chunk (72 MFMAs per wave) publishes them - the same barriers per MFMA as before.
+#ifndef GL_FWD_PIPE
+#define GL_FWD_PIPE 1
+#endif
+  constexpr bool PIPE = GL_FWD_PIPE && KS == 3 && MB == 4 && NB == 2 && G::XMODE == XVEC && G::NI == 1 && !SPLITK && CI_T == 8 &&
+                        DUMP > 0;
+  if constexpr (PIPE) {
+    constexpr int HC = 4, XH = HC * PLANE, WH = KK * HC * COP;
+    constexpr int XI = HC * G::R * G::ROW4, WI = KK * HC * (CO_T / 4), WPH = (WI + 255) / 256;
+    static_assert(!PIPE || (2 * XH == Cfg::XS && 2 * WH == Cfg::WS && XI <= 256 && WPH == 3), "half-chunk images");
+    constexpr int NOITEM = (int)0x80000000;
+    // staging descriptors of a half chunk (tile-fixed): one patch float4 per thread, three weight float4
+    const bool xv = tid < XI;
+    const int xq = tid % G::ROW4, xt = tid / G::ROW4;
+    const int xr_ = xt % G::R, xci = xt / G::R;
+    const int xvy = oy0 + xr_ - G::PADC, xvx = ox0 - G::LP + 4 * xq;
+    const int xl = xci * PLANE + xr_ * RP + 4 * xq;
+    const bool xin = xv && n0 < p.in.N && (unsigned)xvy < (unsigned)p.in.Hi && (unsigned)xvx < (unsigned)p.in.Wi;
+    const int xg = xin ? (xci * plane + xvy * p.in.Wi + xvx) * 4 : NOITEM;
+    int wgo[WPH];                                       // (the LDS offset (tap * HC + ci) * COP + 4 c4 is recomputed where it is used:
+#pragma unroll                                          //  three instructions against a register across the loop)
+    for (int i = 0; i < WPH; ++i) {
+      const int e = tid + i * 256;
+      const int c4 = e % (CO_T / 4), t = e / (CO_T / 4);
+      const int ci = t % HC, tap = t / HC;
+      wgo[i] = e < WI ? ((tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4) * 4 : NOITEM;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.in.Cin * plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (unsigned)(KK * p.Cin_p * p.Cout_p * 4), 0x00020000);
+    const int nh = (c_end - c_begin) / HC;            // half chunks (even: Cin_p is a multiple of 8)
+    float4 xr2[2], wr2[2][WPH];
+    auto load_x2 = [&](int h, int set) {
+      const int c0 = c_begin + h * HC;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (h < nh && c0 + xci < p.in.Cin) ? xg : NOITEM, c0 * plane * 4, 0);
+      xr2[set] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto load_w2 = [&](int h, int set, int i) {
+      const int c0 = c_begin + h * HC;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, h < nh ? wgo[i] : NOITEM, c0 * p.Cout_p * 4, 0);
+      wr2[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto store_x2 = [&](int h, int set) {               // half chunk h -> image h & 1
+      float4 v = xr2[set];
+      if constexpr (AFF) {
+        const int c = c_begin + h * HC + xci;
+        const bool ok = xin && h < nh && c < p.in.Cin;
+        const float sv = ok ? afftab[ok ? c : 0] : 0.f, tv = ok ? afftab[ok ? AFF_MAXC + c : 0] : 0.f;
+        v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+      }
+      if (xv) *reinterpret_cast<float4*>(Xs + (h & 1) * XH + xl) = v;
+    };
+    auto store_w2 = [&](int h, int set, int i) {
+      const int e = tid + i * 256;
+      if (e < WI) *reinterpret_cast<float4*>(Ws + (h & 1) * WH + (e / (CO_T / 4)) * COP + 4 * (e % (CO_T / 4))) = wr2[set][i];
+    };
+    load_x2(0, 0);
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) load_w2(0, 0, i);
+    load_x2(1, 1);
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) load_w2(1, 1, i);
+    if constexpr (AFF) {
+      for (int c = tid; c < p.in.Cin; c += 256) {
+        afftab[c] = p.in.aff_s[(long long)n0 * p.in.Cin + c];
+        afftab[AFF_MAXC + c] = p.in.aff_t[(long long)n0 * p.in.Cin + c];
+      }
+      __syncthreads();
+    }
+    store_x2(0, 0);
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) store_w2(0, 0, i);
+    load_x2(2, 0);
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) load_w2(2, 0, i);
+    __syncthreads();
+    constexpr int DUMPH = 2 * DUMP;                     // half chunks per accumulator dump
+    auto half_chunk = [&](int h, int par) {             // `par` = h & 1, a literal at both call sites
+      const float* xs = Xs + par * XH;
+      const float* ws = Ws + par * WH + aoff;
+      float a[2][MB], b[2][NB];
+      auto fetch = [&](int k, int st) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[st][mb] = ws[k * HC * COP + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) b[st][nb] = xs[(k / KS) * RP + (k % KS) + boff[nb]];
+      };
+      // staging pieces behind the taps: half chunk h+1 (register set par ^ 1) goes to the other image, then that set is
+      // refilled with half chunk h+3
+      auto piece = [&](int k) {
+        if (k == 0) store_x2(h + 1, par ^ 1);
+        else if (k < 4) store_w2(h + 1, par ^ 1, k - 1);
+        else if (k == 4) load_x2(h + 3, par ^ 1);
+        else if (k < 8) load_w2(h + 3, par ^ 1, k - 5);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        if (k + 1 < KK) fetch(k + 1, (k + 1) & 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[k & 1][nb], a[k & 1][mb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        piece(k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (++since_dump == DUMPH && h + 1 < nh) {
+        since_dump = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc2[mb][nb] += acc[mb][nb];
+            acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      __syncthreads();
+    };
+    for (int h = 0; h < nh; h += 2) {
+      half_chunk(h, 0);
+      half_chunk(h + 1, 1);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
+  } else {
   XRegs<G, XS_t::PT> xr;
   float4 wr[WPT];
   // plain vector staging (the thick layers): patch and weight prefetch through buffer descriptors - out-of-range items
@@ -1128,6 +1267,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
   }
+  }      // (!PIPE)
   // ---- epilogue: + bias, activation, NCHW store ----
   // The patch is the MFMA's A operand and the weights its B operand, so D is [pixel][channel]: a lane holds pixels
   // 4(l>>4)+r (r = 0..3, consecutive along x in every tile geometry) of output channel l&15 -> one 16-byte store

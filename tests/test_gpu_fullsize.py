@@ -480,7 +480,7 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
                 ('conv_s2_up_roll_blur_kernel<1',),
             'thin modulated layer with its tail (generator top)': ('conv_fwd_rollmod_kernel',),
             'rolling-window weight gradient': ('conv_wgrad_roll_kernel',),
-            'rolling-window stride-2 weight gradient': ('conv_s2_wgrad_roll_kernel',)}
+            'rolling-window stride-2 weight gradient': ('conv_s2_wgrad_roll2_kernel',)}
     ran = {what: census.count(*needles) for what, needles in must.items()}
     rep = dict(loss_d=rel_err(ld, cpu['ld']), loss_g=rel_err(lg, cpu['lg']), kernels=ran,
                direct_gradients=f'{taken[0]} of {n_params} parameters')
