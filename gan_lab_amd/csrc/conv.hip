@@ -918,9 +918,13 @@ constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the 
 #ifndef GL_FWD_PIPE_WG
 #define GL_FWD_PIPE_WG 4
 #endif
+#ifndef GL_FWD_MB2_WG
+#define GL_FWD_MB2_WG 3
+#endif
 template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4 && Cfg::NB >= 4) ? 2 :
-                                   (Cfg::KS == 3 && Cfg::MB == 4 && Cfg::NB == 2 && Cfg::G::XMODE == XVEC && !SPLITK) ? GL_FWD_PIPE_WG : 3)) void conv_fwd_kernel(ConvArgs p) {
+                                   (Cfg::KS == 3 && Cfg::MB == 4 && Cfg::NB == 2 && Cfg::G::XMODE == XVEC && !SPLITK) ? GL_FWD_PIPE_WG :
+                                   (Cfg::KS == 3 && Cfg::MB == 2 && Cfg::NB == 4 && Cfg::G::XMODE == XVEC && !SPLITK) ? GL_FWD_MB2_WG : 3)) void conv_fwd_kernel(ConvArgs p) {
   using G = typename Cfg::G;
   constexpr int KS = Cfg::KS, KK = Cfg::KK, MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T;
   constexpr int RP = G::RP, IMG = G::IMG, PLANE = Cfg::PLANE, COP = Cfg::COP;
@@ -1002,21 +1006,29 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
 #ifndef GL_FWD_PIPE
 #define GL_FWD_PIPE 1
 #endif
-  constexpr bool PIPE = GL_FWD_PIPE && KS == 3 && MB == 4 && NB == 2 && G::XMODE == XVEC && G::NI == 1 && !SPLITK && CI_T == 8 &&
-                        DUMP > 0;
+#ifndef GL_FWD_PIPE_MB2         // the 32-channel x 256-pixel tile the same way: 138 instead of 127 VGPRs (three workgroups per CU instead
+#define GL_FWD_PIPE_MB2 0       // of four), 32 -> 32 @512^2 x32 1.245 -> 1.260 ms; forced to 128 VGPRs it spills (1.376): stays off
+#endif
+  constexpr bool PIPE = GL_FWD_PIPE && KS == 3 && ((MB == 4 && NB == 2) || (GL_FWD_PIPE_MB2 && MB == 2 && NB == 4)) && G::XMODE == XVEC &&
+                        G::NI == 1 && !SPLITK && CI_T == 8 && DUMP > 0;
   if constexpr (PIPE) {
     constexpr int HC = 4, XH = HC * PLANE, WH = KK * HC * COP;
-    constexpr int XI = HC * G::R * G::ROW4, WI = KK * HC * (CO_T / 4), WPH = (WI + 255) / 256;
-    static_assert(!PIPE || (2 * XH == Cfg::XS && 2 * WH == Cfg::WS && XI <= 256 && WPH == 3), "half-chunk images");
+    constexpr int XI = HC * G::R * G::ROW4, WI = KK * HC * (CO_T / 4);
+    constexpr int XPH = (XI + 255) / 256, WPH = (WI + 255) / 256;          // 1 + 3 (64 channels x 128 pixels), 2 + 2 (32 x 256)
+    static_assert(!PIPE || (2 * XH == Cfg::XS && 2 * WH == Cfg::WS && 2 * (XPH + WPH) <= KK), "half-chunk images / pieces");
     constexpr int NOITEM = (int)0x80000000;
-    // staging descriptors of a half chunk (tile-fixed): one patch float4 per thread, three weight float4
-    const bool xv = tid < XI;
-    const int xq = tid % G::ROW4, xt = tid / G::ROW4;
-    const int xr_ = xt % G::R, xci = xt / G::R;
-    const int xvy = oy0 + xr_ - G::PADC, xvx = ox0 - G::LP + 4 * xq;
-    const int xl = xci * PLANE + xr_ * RP + 4 * xq;
-    const bool xin = xv && n0 < p.in.N && (unsigned)xvy < (unsigned)p.in.Hi && (unsigned)xvx < (unsigned)p.in.Wi;
-    const int xg = xin ? (xci * plane + xvy * p.in.Wi + xvx) * 4 : NOITEM;
+    // staging descriptors of a half chunk (tile-fixed): byte offset inside the image (or NOITEM) and LDS offset | ci << 20
+    int xg[XPH], xl[XPH];
+#pragma unroll
+    for (int i = 0; i < XPH; ++i) {
+      const int e = tid + i * 256;
+      const int q = e % G::ROW4, t = e / G::ROW4;
+      const int r = t % G::R, ci = t / G::R;
+      const int vy = oy0 + r - G::PADC, vx = ox0 - G::LP + 4 * q;
+      xl[i] = e < XI ? ((ci * PLANE + r * RP + 4 * q) | (ci << 20)) : -1;
+      xg[i] = (e < XI && n0 < p.in.N && (unsigned)vy < (unsigned)p.in.Hi && (unsigned)vx < (unsigned)p.in.Wi)
+                  ? (ci * plane + vy * p.in.Wi + vx) * 4 : NOITEM;
+    }
     int wgo[WPH];                                       // (the LDS offset (tap * HC + ci) * COP + 4 c4 is recomputed where it is used:
 #pragma unroll                                          //  three instructions against a register across the loop)
     for (int i = 0; i < WPH; ++i) {
@@ -1030,37 +1042,39 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wp), 0, (unsigned)(KK * p.Cin_p * p.Cout_p * 4), 0x00020000);
     const int nh = (c_end - c_begin) / HC;            // half chunks (even: Cin_p is a multiple of 8)
-    float4 xr2[2], wr2[2][WPH];
-    auto load_x2 = [&](int h, int set) {
-      const int c0 = c_begin + h * HC;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (h < nh && c0 + xci < p.in.Cin) ? xg : NOITEM, c0 * plane * 4, 0);
-      xr2[set] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    float4 xr2[2][XPH], wr2[2][WPH];
+    auto load_x2 = [&](int h, int set, int i) {
+      const int c0 = c_begin + h * HC, ci = (xl[i] >> 20) & 0x3ff;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (h < nh && c0 + ci < p.in.Cin) ? xg[i] : NOITEM, c0 * plane * 4, 0);
+      xr2[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     };
     auto load_w2 = [&](int h, int set, int i) {
       const int c0 = c_begin + h * HC;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, h < nh ? wgo[i] : NOITEM, c0 * p.Cout_p * 4, 0);
       wr2[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     };
-    auto store_x2 = [&](int h, int set) {               // half chunk h -> image h & 1
-      float4 v = xr2[set];
+    auto store_x2 = [&](int h, int set, int i) {        // half chunk h -> image h & 1
+      float4 v = xr2[set][i];
       if constexpr (AFF) {
-        const int c = c_begin + h * HC + xci;
-        const bool ok = xin && h < nh && c < p.in.Cin;
+        const int c = c_begin + h * HC + ((xl[i] >> 20) & 0x3ff);
+        const bool ok = xl[i] != -1 && xg[i] != NOITEM && h < nh && c < p.in.Cin;
         const float sv = ok ? afftab[ok ? c : 0] : 0.f, tv = ok ? afftab[ok ? AFF_MAXC + c : 0] : 0.f;
         v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
       }
-      if (xv) *reinterpret_cast<float4*>(Xs + (h & 1) * XH + xl) = v;
+      if (xl[i] != -1) *reinterpret_cast<float4*>(Xs + (h & 1) * XH + (xl[i] & 0xfffff)) = v;
     };
     auto store_w2 = [&](int h, int set, int i) {
       const int e = tid + i * 256;
       if (e < WI) *reinterpret_cast<float4*>(Ws + (h & 1) * WH + (e / (CO_T / 4)) * COP + 4 * (e % (CO_T / 4))) = wr2[set][i];
     };
-    load_x2(0, 0);
+    auto load_half = [&](int h, int set) {
 #pragma unroll
-    for (int i = 0; i < WPH; ++i) load_w2(0, 0, i);
-    load_x2(1, 1);
+      for (int i = 0; i < XPH; ++i) load_x2(h, set, i);
 #pragma unroll
-    for (int i = 0; i < WPH; ++i) load_w2(1, 1, i);
+      for (int i = 0; i < WPH; ++i) load_w2(h, set, i);
+    };
+    load_half(0, 0);
+    load_half(1, 1);
     if constexpr (AFF) {
       for (int c = tid; c < p.in.Cin; c += 256) {
         afftab[c] = p.in.aff_s[(long long)n0 * p.in.Cin + c];
@@ -1068,12 +1082,11 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       }
       __syncthreads();
     }
-    store_x2(0, 0);
+#pragma unroll
+    for (int i = 0; i < XPH; ++i) store_x2(0, 0, i);
 #pragma unroll
     for (int i = 0; i < WPH; ++i) store_w2(0, 0, i);
-    load_x2(2, 0);
-#pragma unroll
-    for (int i = 0; i < WPH; ++i) load_w2(2, 0, i);
+    load_half(2, 0);
     __syncthreads();
     constexpr int DUMPH = 2 * DUMP;                     // half chunks per accumulator dump
     auto half_chunk = [&](int h, int par) {             // `par` = h & 1, a literal at both call sites
@@ -1089,10 +1102,10 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       // staging pieces behind the taps: half chunk h+1 (register set par ^ 1) goes to the other image, then that set is
       // refilled with half chunk h+3
       auto piece = [&](int k) {
-        if (k == 0) store_x2(h + 1, par ^ 1);
-        else if (k < 4) store_w2(h + 1, par ^ 1, k - 1);
-        else if (k == 4) load_x2(h + 3, par ^ 1);
-        else if (k < 8) load_w2(h + 3, par ^ 1, k - 5);
+        if (k < XPH) store_x2(h + 1, par ^ 1, k);
+        else if (k < XPH + WPH) store_w2(h + 1, par ^ 1, k - XPH);
+        else if (k < 2 * XPH + WPH) load_x2(h + 3, par ^ 1, k - XPH - WPH);
+        else if (k < 2 * (XPH + WPH)) load_w2(h + 3, par ^ 1, k - 2 * XPH - WPH);
       };
       fetch(0, 0);
 #pragma unroll
