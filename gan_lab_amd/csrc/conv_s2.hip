@@ -424,6 +424,149 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 && !GL_ACC_DUMP ? 3 : 2)) void c
         for (int nb = 0; nb < NBL; ++nb) acc2[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // ---- TPIPE: by half chunks (conv.hip, conv_fwd_kernel PIPE): the two 4-channel groups of the 8-channel chunk's LDS space are
+  // two images; the next half chunk is stored into the one that died at the previous barrier, in pieces behind the (phase, tap)
+  // combinations of the current one; loads two half chunks ahead in two register sets; one barrier per half chunk ----
+#ifndef GL_S2_UP_PIPE
+#define GL_S2_UP_PIPE 1
+#endif
+  constexpr bool TPIPE = GL_S2_UP_PIPE && GL_ACC_DUMP && GL_S2_FRAG_PREFETCH && CI_T == 8 && NBL == 2;
+  if constexpr (TPIPE) {
+    constexpr int HC = 4;
+    constexpr int XI = HC * Cfg::R * Cfg::ROW4, WI = 16 * HC * (CO_T / 4);
+    constexpr int XPH = (XI + 255) / 256, WPH = (WI + 255) / 256;
+    static_assert(!TPIPE || 2 * (XPH + WPH) <= 16, "staging pieces of a half chunk");
+    constexpr int NOITEM = (int)0x80000000;
+    int hxg[XPH], hxl[XPH];          // byte offset inside the image (or NOITEM) ; LDS offset inside the half | ci << 20 (or -1)
+#pragma unroll
+    for (int i = 0; i < XPH; ++i) {
+      const int e = tid + i * 256;
+      const int q = e % Cfg::ROW4, t = e / Cfg::ROW4;
+      const int r = t % Cfg::R, ci = t / Cfg::R;
+      const int gy_ = oy0 - 1 + r, gx_ = ox0 - 4 + 4 * q;
+      hxl[i] = e < XI ? ((ci * PLANE + r * RP + 4 * q) | (ci << 20)) : -1;
+      hxg[i] = (e < XI && (unsigned)gy_ < (unsigned)p.Hl && (unsigned)gx_ < (unsigned)p.Wl) ? (ci * plane + gy_ * p.Wl + gx_) * 4 : NOITEM;
+    }
+    int hwg[WPH];
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) {
+      const int e = tid + i * 256;
+      const int c4 = e % (CO_T / 4), t = e / (CO_T / 4);
+      const int ci = t % HC, tap = t / HC;
+      hwg[i] = e < WI ? ((tap * p.Cin_p + ci) * p.Cout_p + co0 + 4 * c4) * 4 : NOITEM;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (unsigned)(16 * p.Cin_p * p.Cout_p * 4), 0x00020000);
+    const int nh = p.Cin_p / HC;               // even
+    float4 xr2[2][XPH], wr2[2][WPH];
+    auto load_x2 = [&](int h, int set, int i) {
+      const int c0 = h * HC, ci = (hxl[i] >> 20) & 0x3ff;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (h < nh && c0 + ci < p.Cin) ? hxg[i] : NOITEM, c0 * plane * 4, 0);
+      xr2[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto load_w2 = [&](int h, int set, int i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, h < nh ? hwg[i] : NOITEM, h * HC * p.Cout_p * 4, 0);
+      wr2[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto store_x2 = [&](int h, int set, int i) {        // half chunk h -> channels 4 (h & 1) .. of the chunk's planes
+      float4 v = xr2[set][i];
+      if constexpr (AFF) {
+        const int c = h * HC + ((hxl[i] >> 20) & 0x3ff);
+        const bool ok = hxl[i] != -1 && hxg[i] != NOITEM && h < nh && c < p.Cin;
+        const float sv = ok ? afftab[ok ? c : 0] : 0.f, tv = ok ? afftab[ok ? S2_AFF_MAXC + c : 0] : 0.f;
+        v.x = fmaf(v.x, sv, tv); v.y = fmaf(v.y, sv, tv); v.z = fmaf(v.z, sv, tv); v.w = fmaf(v.w, sv, tv);
+      }
+      if (hxl[i] != -1) *reinterpret_cast<float4*>(Xs + (h & 1) * HC * PLANE + (hxl[i] & 0xfffff)) = v;
+    };
+    auto store_w2 = [&](int h, int set, int i) {        // rows (tap, 4 (h & 1) + ci) of the chunk's [tap][8][COP] slab
+      const int e = tid + i * 256;
+      const int c4 = e % (CO_T / 4), t = e / (CO_T / 4);
+      if (e < WI) *reinterpret_cast<float4*>(Ws + ((t / HC) * CI_T + (h & 1) * HC + (t % HC)) * COP + 4 * c4) = wr2[set][i];
+    };
+    auto load_half = [&](int h, int set) {
+#pragma unroll
+      for (int i = 0; i < XPH; ++i) load_x2(h, set, i);
+#pragma unroll
+      for (int i = 0; i < WPH; ++i) load_w2(h, set, i);
+    };
+    load_half(0, 0);
+    load_half(1, 1);
+    if constexpr (AFF) {
+      for (int c = tid; c < p.Cin; c += 256) {
+        afftab[c] = p.aff_s[(long long)n * p.Cin + c];
+        afftab[S2_AFF_MAXC + c] = p.aff_t[(long long)n * p.Cin + c];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < XPH; ++i) store_x2(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < WPH; ++i) store_w2(0, 0, i);
+    load_half(2, 0);
+    __syncthreads();
+    constexpr int DUMPH = 2 * DUMP;
+    auto half_chunk = [&](int h, int par) {
+      constexpr int PD = 2;
+      float av[PD + 1][MB], bv[PD + 1][NBL];
+      auto fetch = [&](int i, int st) {          // (phase, tap) combination i of the 4-channel group `par`
+        const int py = (i >> 3) & 1, px = (i >> 2) & 1, iy = (i >> 1) & 1, ix = i & 1;
+        const int dy = py == 0 ? (iy == 0 ? -1 : 0) : (iy == 0 ? 0 : 1);
+        const int a = py == 0 ? (iy == 0 ? 3 : 1) : (iy == 0 ? 2 : 0);
+        const int dx = px == 0 ? (ix == 0 ? -1 : 0) : (ix == 0 ? 0 : 1);
+        const int b = px == 0 ? (ix == 0 ? 3 : 1) : (ix == 0 ? 2 : 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[st][mb] = Ws[par * 4 * COP + aoff + ((a * 4 + b) * CI_T) * COP + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NBL; ++nb) bv[st][nb] = Xs[par * 4 * PLANE + boff[nb] + dy * RP + dx];
+      };
+      auto piece = [&](int k) {
+        if (k < XPH) store_x2(h + 1, par ^ 1, k);
+        else if (k < XPH + WPH) store_w2(h + 1, par ^ 1, k - XPH);
+        else if (k < 2 * XPH + WPH) load_x2(h + 3, par ^ 1, k - XPH - WPH);
+        else if (k < 2 * (XPH + WPH)) load_w2(h + 3, par ^ 1, k - 2 * XPH - WPH);
+      };
+#pragma unroll
+      for (int i = 0; i < PD; ++i) fetch(i, i % (PD + 1));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + PD < 16) fetch(i + PD, (i + PD) % (PD + 1));
+        const int st = i % (PD + 1), ph = (i >> 2) & 3;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NBL; ++nb)
+            acc[ph][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][mb], bv[st][nb], acc[ph][mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        piece(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (++since_dump == DUMPH && h + 1 < nh) {
+        since_dump = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NBL; ++nb) {
+              acc2[ph][mb][nb] += acc[ph][mb][nb];
+              acc[ph][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+      }
+      __syncthreads();
+    };
+    for (int h = 0; h < nh; h += 2) {
+      half_chunk(h, 0);
+      half_chunk(h + 1, 1);
+    }
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] += acc2[ph][mb][nb];
+  } else {
   float4 xr[XPT], wr[WPT];
   const __amdgpu_buffer_rsrc_t rs_x =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
@@ -565,6 +708,7 @@ __global__ __launch_bounds__(256, (Cfg::MB <= 2 && !GL_ACC_DUMP ? 3 : 2)) void c
 #pragma unroll
         for (int nb = 0; nb < NBL; ++nb) acc[ph][mb][nb] += acc2[ph][mb][nb];
   }
+  }      // (!TPIPE)
   // epilogue (high-res): lane holds px = 0 and px = 1 of its low-res pixel -> float2 stores
   const int Wo = 2 * p.Wl;
   const long long oplane = 4LL * p.Hl * p.Wl;
