@@ -123,9 +123,15 @@ template <class Cfg>
 __global__ __launch_bounds__(256, Cfg::NB >= 4 ? 2 : 3) void conv_s2_down_kernel(S2Args p) {
   constexpr int MB = Cfg::MB, NB = Cfg::NB, CI_T = Cfg::CI_T, PL = Cfg::PL, RPL = Cfg::RPL, COP = Cfg::COP;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, CO_T = Cfg::CO_T, XPT = Cfg::XPT, WPT = Cfg::WPT;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::XS + Cfg::WS];
+  // SPIPE (the 64-channel x 128-pixel tile): TWO images of the patch, one of the weights (47 KB: three workgroups per CU stay) - see
+  // the chunk loop
+#ifndef GL_S2_DOWN_PIPE
+#define GL_S2_DOWN_PIPE 1
+#endif
+  constexpr bool SPIPE = GL_S2_DOWN_PIPE && GL_ACC_DUMP && GL_S2_FRAG_PREFETCH && MB == 4 && NB == 2 && CI_T == 4;
+  __shared__ __attribute__((aligned(16))) float smem[(SPIPE ? 2 : 1) * Cfg::XS + Cfg::WS];
   float* Xs = smem;
-  float* Ws = smem + Cfg::XS;
+  float* Ws = smem + (SPIPE ? 2 : 1) * Cfg::XS;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
   const int co_t = bid % p.tiles_co;
@@ -214,6 +220,106 @@ __global__ __launch_bounds__(256, Cfg::NB >= 4 ? 2 : 3) void conv_s2_down_kernel
       wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
   };
+  // ---- SPIPE: the chunk in two tap halves (tap rows a = 0, 1 | 2, 3; 64 MFMAs per wave each) with a barrier behind each, as
+  // before - but nothing is stored BETWEEN barriers any more.  During half A of chunk k: this chunk's weight rows a = 2, 3 (read
+  // from half B on; their LDS rows died at the previous barrier) go to LDS and are reloaded for chunk k+1.  During half B: the patch of
+  // chunk k+1 goes to the OTHER patch image, chunk k+1's weight rows a = 0, 1 to the rows half A just finished with, and both
+  // register sets are refilled for chunk k+2.  Every store / load is a piece behind a K-step's 8 MFMAs; every load is consumed two
+  // halves (128 MFMAs per wave) later.  (conv.hip, conv_fwd_kernel PIPE, for the measurements that led here.)
+  if constexpr (SPIPE) {
+    static_assert(!SPIPE || (XPT == 4 && WPT == 4 && Cfg::NWI == 4 * 256), "piece schedule");
+    constexpr int NOITEM = (int)0x80000000, XSZ = Cfg::XS;
+    const int nch = p.Cin_p / CI_T;
+    auto load_x1 = [&](int k, int i) {                    // chunk k's patch item i
+      const int ci = (xl[i] >> 20) & 0x3ff, c0 = k * CI_T;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_x, (k < nch && xg[i] >= 0 && c0 + ci < p.Cin) ? xg[i] * 4 : NOITEM, c0 * plane * 4, 0);
+      xr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto load_w1 = [&](int k, int i) {                    // chunk k's weight item i (i < 2: tap rows 0, 1)
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, k < nch ? wg[i] * 4 : NOITEM, k * CI_T * p.Cout_p * 4, 0);
+      wr[i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    };
+    auto store_x1 = [&](int img, int i) {
+      if (xl[i] != -1) {
+        const int l = img * XSZ + (xl[i] & 0xfffff);
+        *reinterpret_cast<float2*>(Xs + l) = float2{xr[i].x, xr[i].z};              // px = 0
+        *reinterpret_cast<float2*>(Xs + l + CI_T * PL) = float2{xr[i].y, xr[i].w};  // px = 1
+      }
+    };
+    auto store_w1 = [&](int i) { *reinterpret_cast<float4*>(Ws + wl[i]) = wr[i]; };
+    // prologue: chunk 0 complete except its weight rows 2, 3 (registers); chunk 1's patch and weight rows 0, 1 in registers
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) load_x1(0, i);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) load_w1(0, i);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) store_x1(0, i);
+    store_w1(0);
+    store_w1(1);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) load_x1(1, i);
+    load_w1(1, 0);
+    load_w1(1, 1);
+    __syncthreads();
+    constexpr int NKH = 8 * (CI_T / 4);                   // K-steps of a tap half
+    for (int k = 0; k < nch; ++k) {
+      const float* xs = Xs + (k & 1) * XSZ;
+      float av[2][MB], bv[2][NB];
+      auto fetch = [&](int kk, int st) {
+        const int tap = kk / (CI_T / 4), c4 = kk % (CI_T / 4), a = tap >> 2, b = tap & 3;
+        const int dy = (a == 0) ? -1 : (a == 3 ? 1 : 0), py = (a == 0 || a == 2) ? 1 : 0;
+        const int dx = cDY(b), px = cPY(b);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[st][mb] = Ws[a * (4 * CI_T * COP) + aoff + (b * CI_T + c4 * 4) * COP + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          bv[st][nb] = xs[(py * 2) * CI_T * PL + dy * RPL + (px * CI_T + c4 * 4) * PL + boff[nb] + dx];
+      };
+      auto piece_a = [&](int j) {          // half A: weight rows 2, 3 of THIS chunk to LDS, then those of the next into the registers
+        if (j < 2) store_w1(2 + j);
+        else if (j < 4) load_w1(k + 1, j);
+      };
+      auto piece_b = [&](int j) {          // half B: chunk k+1's patch and weight rows 0, 1 to LDS; chunk k+2's into the registers
+        if (j < 4) store_x1((k + 1) & 1, j);
+        if (j < 2) store_w1(j);
+        if (j >= 4) load_x1(k + 2, j - 4);
+        if (j >= 4 && j < 6) load_w1(k + 2, j - 4);
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 2 * NKH; ++kk) {
+        if (kk + 1 < 2 * NKH && kk + 1 != NKH) fetch(kk + 1, (kk + 1) & 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk & 1][mb], bv[kk & 1][nb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < NKH) piece_a(kk); else piece_b(kk - NKH);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == NKH - 1) {
+          __syncthreads();                 // weight rows 2, 3 of this chunk are in; rows 0, 1 are free
+          fetch(NKH, NKH & 1);
+        }
+      }
+      if (++since_dump == DUMP && k + 1 < nch) {
+        since_dump = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc2[mb][nb] += acc[mb][nb];
+            acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+      __syncthreads();                     // chunk k+1's patch image and weight rows 0, 1 are in; this chunk's are free
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
+  } else {
   load(0);
   for (int ci0 = 0; ci0 < p.Cin_p; ci0 += CI_T) {
     __syncthreads();
@@ -300,6 +406,7 @@ __global__ __launch_bounds__(256, Cfg::NB >= 4 ? 2 : 3) void conv_s2_down_kernel
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[mb][nb] += acc2[mb][nb];
   }
+  }      // (!SPIPE)
   // epilogue (low-res): + bias, activation
   const long long oplane = (long long)p.Hl * p.Wl;
   float bvv[MB][4];
