@@ -1111,8 +1111,8 @@ int run_S(S2Args a, hipStream_t st) {
 #define GL_S2_DOWN_W16_MB2 1
 #endif
     const long long wg64 = (long long)ceil_div(a.Wl, 16) * ceil_div(a.Hl, 16) * a.N * ceil_div(a.Cout, 64);
-#ifndef GL_S2_DOWN_W16
-#define GL_S2_DOWN_W16 0
+#ifndef GL_S2_DOWN_W16      // 1: the pipelined 64-channel x (16 x 8)-pixel tile here as well (512 workgroups too): 512 -> 512 pool @32^2 x32
+#define GL_S2_DOWN_W16 1    // 0.569 -> 0.521 ms (before that kernel was pipelined the same routing measured equal); 0 / 2: A/B builds
 #endif
     if (GL_S2_DOWN_W16 == 1) return launch_s2<SCfg<4, 4, 2>>(conv_s2_down_kernel<SCfg<4, 4, 2>>, a, st);
     if (GL_S2_DOWN_W16 == 2) return launch_s2<SCfg<2, 4, 2>>(conv_s2_down_kernel<SCfg<2, 4, 2>>, a, st);
