@@ -1006,8 +1006,8 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
 #ifndef GL_FWD_PIPE
 #define GL_FWD_PIPE 1
 #endif
-#ifndef GL_FWD_PIPE_MB2         // the 32-channel x 256-pixel tile the same way: 138 instead of 127 VGPRs (three workgroups per CU instead
-#define GL_FWD_PIPE_MB2 0       // of four), 32 -> 32 @512^2 x32 1.245 -> 1.260 ms; forced to 128 VGPRs it spills (1.376): stays off
+#ifndef GL_FWD_PIPE_MB2         // the 32-channel x 256-pixel tile the same way, with ONE register set (two sets: 138 instead of 127 VGPRs =
+#define GL_FWD_PIPE_MB2 1       // three workgroups per CU instead of four, 32 -> 32 @512^2 x32 1.245 -> 1.260 ms; forced to 128 it spills: 1.376)
 #endif
   constexpr bool PIPE = GL_FWD_PIPE && KS == 3 && ((MB == 4 && NB == 2) || (GL_FWD_PIPE_MB2 && MB == 2 && NB == 4)) && G::XMODE == XVEC &&
                         G::NI == 1 && !SPLITK && CI_T == 8 && DUMP > 0;
@@ -1042,7 +1042,13 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wp), 0, (unsigned)(KK * p.Cin_p * p.Cout_p * 4), 0x00020000);
     const int nh = (c_end - c_begin) / HC;            // half chunks (even: Cin_p is a multiple of 8)
-    float4 xr2[2][XPH], wr2[2][WPH];
+    // register sets: two (loads two half chunks ahead) for the 64-channel tile; ONE for the 32-channel tile (loads one half
+    // chunk ahead - its operands come from L2 - and 16 registers less: the fourth workgroup per CU)
+#ifndef GL_FWD_PIPE_NSET4
+#define GL_FWD_PIPE_NSET4 2
+#endif
+    constexpr int NSET = MB == 4 ? GL_FWD_PIPE_NSET4 : 1;
+    float4 xr2[NSET][XPH], wr2[NSET][WPH];
     auto load_x2 = [&](int h, int set, int i) {
       const int c0 = c_begin + h * HC, ci = (xl[i] >> 20) & 0x3ff;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (h < nh && c0 + ci < p.in.Cin) ? xg[i] : NOITEM, c0 * plane * 4, 0);
@@ -1074,7 +1080,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       for (int i = 0; i < WPH; ++i) load_w2(h, set, i);
     };
     load_half(0, 0);
-    load_half(1, 1);
+    if constexpr (NSET == 2) load_half(1, 1);
     if constexpr (AFF) {
       for (int c = tid; c < p.in.Cin; c += 256) {
         afftab[c] = p.in.aff_s[(long long)n0 * p.in.Cin + c];
@@ -1086,7 +1092,7 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
     for (int i = 0; i < XPH; ++i) store_x2(0, 0, i);
 #pragma unroll
     for (int i = 0; i < WPH; ++i) store_w2(0, 0, i);
-    load_half(2, 0);
+    load_half(NSET == 2 ? 2 : 1, 0);
     __syncthreads();
     constexpr int DUMPH = 2 * DUMP;                     // half chunks per accumulator dump
     auto half_chunk = [&](int h, int par) {             // `par` = h & 1, a literal at both call sites
@@ -1102,10 +1108,12 @@ __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 &&
       // staging pieces behind the taps: half chunk h+1 (register set par ^ 1) goes to the other image, then that set is
       // refilled with half chunk h+3
       auto piece = [&](int k) {
-        if (k < XPH) store_x2(h + 1, par ^ 1, k);
-        else if (k < XPH + WPH) store_w2(h + 1, par ^ 1, k - XPH);
-        else if (k < 2 * XPH + WPH) load_x2(h + 3, par ^ 1, k - XPH - WPH);
-        else if (k < 2 * (XPH + WPH)) load_w2(h + 3, par ^ 1, k - 2 * XPH - WPH);
+        constexpr int AHEAD = NSET == 2 ? 3 : 2;
+        const int set = NSET == 2 ? (par ^ 1) : 0;
+        if (k < XPH) store_x2(h + 1, set, k);
+        else if (k < XPH + WPH) store_w2(h + 1, set, k - XPH);
+        else if (k < 2 * XPH + WPH) load_x2(h + AHEAD, set, k - XPH - WPH);
+        else if (k < 2 * (XPH + WPH)) load_w2(h + AHEAD, set, k - 2 * XPH - WPH);
       };
       fetch(0, 0);
 #pragma unroll
