@@ -463,6 +463,137 @@ __global__ void rb_rgb_finish_kernel(const double* __restrict__ part, float* __r
 
 // ---- host side (called from conv.hip's entry points) ----
 // row strips per column: >= ~4096 workgroups, >= 16 (blurred form: every strip pays one extra step) / 8 steps each
+// ------------------------------------------------------------------------------------------------------------------------------
+// The plain form (conv + bias + activation, no blur) by HALF steps: two output rows per barrier.  The four-row step above is
+// [144 MFMAs per wave][row stores][barrier][prefetched rows -> ring][barrier] with the ring stores 13.5 % of a step
+// (profiles/r04_phase_probe_rb.txt) - they overwrite rows the step still reads.  A half step h reads ring rows 2h .. 2h+3 (rel row r =
+// input row Y0 - 1 + r) for output rows Y0 + 2h, Y0 + 2h + 1; the rows the next half step adds (2h+4, 2h+5) go to the slots of rows
+// 2h-2, 2h-1, dead since the previous barrier: their LDS stores - and the loads of rows 2h+8, 2h+9 into the same register set, two
+// half steps ahead - are pieces between the MFMAs, and one barrier per half step publishes them (conv_s2_wgrad_roll2_kernel,
+// wgrad_roll.hip, for the measurements behind this form).  Same column-block map: wave w owns the 16-pixel block w of both rows.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void conv_fwd_roll2_kernel(RBArgs p) {
+  __shared__ __attribute__((aligned(16))) float ring[RB_SLOTS * RB_SLOT];
+  constexpr int HITEMS = 2 * 16 * RB_Q, HPT = (HITEMS + 255) / 256;       // two rows: 576 float4, 3 per thread
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int co = lane & 15, kk = lane >> 4;
+  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
+  const int txi = bid % p.cols;
+  bid /= p.cols;
+  const int syi = bid % p.strips;
+  const int n0 = bid / p.strips;
+  const int nh = 2 * min(p.spu, p.H / 4 - syi * p.spu);      // half steps = pairs of output rows
+  const int ox0 = txi * RB_TW, Y0 = syi * p.spu * 4;
+  const int plane = p.H * p.W;
+  const float* xb = p.x + (long long)n0 * p.Cin * plane;
+
+  int gb[HPT], lo[HPT];         // byte offset of (ci, column) inside the image (or OOB) ; LDS offset | row of the pair << 16 (or -1)
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    const int e = tid + i * 256;
+    const int q = e % RB_Q, t = e / RB_Q;
+    const int ci = t & 15, k = t >> 4;
+    const int vx = ox0 - 4 + 4 * q;
+    gb[i] = (e < HITEMS && ci < p.Cin && (unsigned)vx < (unsigned)p.W) ? (ci * plane + vx) * 4 : RB_OOB;
+    lo[i] = e < HITEMS ? ((ci * RB_RP + 4 * q) | (k << 16)) : -1;
+  }
+  float wreg[36];
+#pragma unroll
+  for (int st = 0; st < 36; ++st)
+    wreg[st] = p.wp[(long long)((st >> 2) * p.Cin_p + (st & 3) * 4 + kk) * p.Cout_p + co];
+  const bool co_ok = co < p.Cout;
+  const float bv = (p.bias != nullptr && co_ok) ? p.bias[co] * p.bias_scale : 0.f;
+  const long long oplane = (long long)p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (unsigned)(p.Cin * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (long long)n0 * p.Cout * oplane, 0, (unsigned)(p.Cout * oplane * 4), 0x00020000);
+  const int vo_lane = co_ok ? (int)(((long long)co * oplane + ox0 + w * 16 + kk * 4) * 4) : RB_OOB;
+  const int W4 = p.W * 4;
+
+  float4 xr[2][HPT];
+  auto load_item = [&](int r0, bool on, int set, int i) {        // rel rows r0, r0 + 1
+    const int vy = Y0 - 1 + r0 + ((lo[i] >> 16) & 1);
+    const int off = (on && gb[i] != RB_OOB && (unsigned)vy < (unsigned)p.H) ? gb[i] + vy * W4 : RB_OOB;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+    xr[set][i] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+  };
+  auto store_item = [&](int r0, int set, int i) {                // r0 even: slots r0 % 6, r0 % 6 + 1
+    if (lo[i] != -1)
+      *reinterpret_cast<float4*>(ring + ((r0 % RB_SLOTS) + ((lo[i] >> 16) & 1)) * RB_SLOT + (lo[i] & 0xffff)) = xr[set][i];
+  };
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) load_item(0, true, 0, i);
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) load_item(2, true, 1, i);
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) store_item(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) store_item(2, 1, i);
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) load_item(4, true, 0, i);        // stored in half step 0
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) load_item(6, nh > 2, 1, i);      // stored in half step 1
+  __syncthreads();
+
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int a_lane = kk * RB_RP + w * 16 + co + 3;               // + LP(4) - pad(1); `co` doubles as the pixel index here
+  auto half_step = [&](int h, int par) {                         // `par` = h & 1, a literal at both call sites
+    int sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sb[j] = ((2 * h + j) % RB_SLOTS) * RB_SLOT;
+    // fetch order: input rows (0, 3) interleaved - one MFMA each, on different accumulators - then rows 1 and 2 (two MFMAs each)
+    constexpr int PD = 3, NF = 48;
+    float rb[PD + 1];
+    auto fj = [](int f) { return f < 24 ? (f & 1 ? 3 : 0) : (f < 36 ? 1 : 2); };
+    auto fi = [](int f) { return f < 24 ? (f >> 1) : (f - 24) % 12; };
+    auto fetch = [&](int f, int slot) {
+      const int i12 = fi(f), kx = i12 >> 2, c4 = i12 & 3;
+      rb[slot] = ring[sb[fj(f)] + c4 * 4 * RB_RP + kx + a_lane];
+    };
+    auto piece = [&](int k) {          // k < 3: rows 2h+4, 2h+5 -> ring; then the same register set refilled with rows 2h+8, 2h+9
+      if (k < HPT) store_item(2 * h + 4, par, k);
+      else load_item(2 * h + 8, h + 3 < nh, par, k - HPT);
+    };
+#pragma unroll
+    for (int f = 0; f < PD; ++f) fetch(f, f % (PD + 1));
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (f + PD < NF) fetch(f + PD, (f + PD) % (PD + 1));
+      const int slot = f % (PD + 1), j = fj(f), i12 = fi(f), kx = i12 >> 2, c4 = i12 & 3;
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int ky = j - r2;
+        if (ky >= 0 && ky < 3)
+          acc[r2] = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot], wreg[(ky * 3 + kx) * 4 + c4], acc[r2], 0, 0, 0);
+      }
+      if ((f & 7) == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        piece(f >> 3);                 // six pieces at f = 3, 11, 19, 27, 35, 43
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int row = Y0 + 2 * h + r2;
+      u32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[r2][r] + bv;
+        if (p.act == GANLAB_ACT_LRELU) t = gl_lrelu(t, p.slope);
+        o[r] = __float_as_uint(t);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, vo_lane == RB_OOB ? vo_lane : vo_lane + row * W4, 0, 0);
+      acc[r2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+  };
+  for (int h = 0; h < nh; h += 2) {
+    half_step(h, 0);
+    half_step(h + 1, 1);
+  }
+}
+
 static long long rb_plan(RBArgs& a, int N, int H, int W, int blur) {
   a.cols = W / RB_TW;
   const int steps = H / 4;
@@ -491,7 +622,9 @@ int gl_roll_blur_launch(const float* x, const float* wp, const float* bias, floa
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
   const long long grid = rb_plan(a, N, H, W, blur);
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
+  static const int half = [] { const char* e = getenv("GANLAB_ROLL_HALF"); return (e && e[0] == '0') ? 0 : 1; }();
   if (blur) GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_BLUR>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else if (half) GL_LAUNCH(conv_fwd_roll2_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);     // (GANLAB_ROLL_HALF=0: the 4-row steps)
   else GL_LAUNCH(conv_fwd_roll_blur_kernel<RB_PLAIN>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
