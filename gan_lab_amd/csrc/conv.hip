@@ -919,7 +919,7 @@ constexpr int AFF_MAXC = 512;     // channels of the per-image (s, t) table the 
 #define GL_FWD_PIPE_WG 4
 #endif
 #ifndef GL_FWD_MB2_WG
-#define GL_FWD_MB2_WG 3
+#define GL_FWD_MB2_WG 4
 #endif
 template <class Cfg, bool MASK = false, bool SPLITK = false, bool AFF = false, bool TAIL = false>
 __global__ __launch_bounds__(256, (Cfg::G::XMODE == XSCALAR || (Cfg::DUMP > 0 && Cfg::MB >= 4 && Cfg::NB >= 4) ? 2 :
