@@ -179,6 +179,20 @@ size_t ganlab_conv_wgrad_bf16_workspace(const ganlab_conv_geom* g);
 int ganlab_conv_wgrad_bf16(const float* gy, const float* x, float* gw, const ganlab_conv_geom* g, float scale,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fp32 convolutions as split products on the bf16 matrix cores (csrc/conv_x3.hip) ---------------------------------
+ * Same math and call sites as ganlab_conv_fwd_f32 / ganlab_conv_dgrad_f32 (custom_layers.py:202-211), fp32 in, fp32 out:
+ * every operand is cut into three bf16 planes that sum to it EXACTLY, a product is six v_mfma_f32_16x16x32_bf16 products
+ * (the three dropped cross terms are <= 2^-26 of it) and the sums are kept in fp32 chains of one 32-channel chunk each,
+ * so the result is as close to float64 as the exact-fp32 kernels' (tools/op_error_probe.py) at 16/6 of their MFMA rate.
+ * Supported (ganlab_conv_x3_supported): 3x3, pad 1, no up / pool, H % 16 == 0, W % 16 == 0, contraction channels % 64 == 0,
+ * output channels % 64 == 0.  pack: OIHW -> three-plane k-step images, returns the number of bf16 elements
+ * (27*Cout*Cin) when `out` is NULL; mode is GANLAB_PACK_*. */
+int ganlab_conv_x3_supported(const ganlab_conv_geom* g, int dgrad);
+long long ganlab_conv_x3_pack(const float* w, void* out, int Cout, int Cin, int mode, float scale, void* stream);
+int ganlab_conv_fwd_x3(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                       float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+
 /* ---- depthwise / resampling (custom_layers.py:36-53; nn.Upsample / nn.AvgPool2d call sites) ---- */
 /* y = depthwise [1 2 1]x[1 2 1]/16 blur, zero padding (self-adjoint: also its own backward). */
 int ganlab_blur3x3_f32(const float* x, float* y, long long planes, int H, int W, void* stream);

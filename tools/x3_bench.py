@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Split-product (3 x bf16) conv kernels against the exact-fp32 kernels: rms error against float64 next to ATen's CPU fp32
+conv, and ms per launch in interleaved rounds of one process (VERDICT r04 item 1 gate: >= 1.5x and error <= 1.1x ATen's).
+    python tools/x3_bench.py [--batch 32] [--err-only] [--time-only]"""
+import argparse
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from gan_lab_amd import _lib, ops
+from gan_lab_amd._lib import check
+
+LAYERS = [(64, 64, 256), (128, 128, 128), (256, 256, 64), (512, 512, 32), (512, 512, 16)]
+
+
+def pack_x3(w, mode, scale):
+    L = _lib.lib()
+    n = L.ganlab_conv_x3_pack(None, None, w.shape[0], w.shape[1], mode, scale, None)
+    assert n > 0, n
+    out = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    rc = L.ganlab_conv_x3_pack(w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], mode, scale, None)
+    assert rc == n, rc
+    return out
+
+
+def fwd_x3(x, wp, bias, g, act=0):
+    y = torch.empty(g.out_shape, device=x.device)
+    check(_lib.lib().ganlab_conv_fwd_x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                        g.ref(), 1.0, act, 0.2, None), 'conv_fwd_x3')
+    return y
+
+
+def dgrad_x3(gy, wp, g):
+    gx = torch.empty(g.in_shape, device=gy.device)
+    check(_lib.lib().ganlab_conv_dgrad_x3(gy.data_ptr(), wp.data_ptr(), gx.data_ptr(), g.ref(), None), 'conv_dgrad_x3')
+    return gx
+
+
+def err(a, ref):
+    a, ref = a.double().cpu(), ref.double()
+    return ((a - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def errors():
+    torch.manual_seed(0)
+    torch.set_num_threads(16)
+    for ci, co, hw in [(64, 64, 64), (128, 128, 32), (256, 256, 32), (512, 512, 16), (256, 128, 16), (64, 192, 16)]:
+        n = 2
+        x = torch.randn(n, ci, hw, hw)
+        w = torch.randn(co, ci, 3, 3) / (3 * ci ** 0.5)
+        b = torch.randn(co)
+        g = ops.Geom(n, ci, hw, hw, co, 3, 1)
+        exact = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        cpu = F.conv2d(x, w, b, padding=1)
+        hip = ops.k_conv_fwd(x.cuda(), w.cuda(), b.cuda(), g, 1.0)
+        x3 = fwd_x3(x.cuda(), pack_x3(w.cuda(), 0, 1.0), b.cuda(), g)
+        ec, eh, e3 = err(cpu, exact), err(hip, exact), err(x3, exact)
+        print(f'fwd   {ci:3d}->{co:3d} {hw}x{hw}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 {e3:.3e} ({e3 / ec:.2f})', flush=True)
+        gy = torch.randn(n, co, hw, hw)
+        xd = x.double().requires_grad_(True)
+        exact, = torch.autograd.grad(F.conv2d(xd, w.double(), padding=1), xd, gy.double())
+        xf = x.clone().requires_grad_(True)
+        cpu, = torch.autograd.grad(F.conv2d(xf, w, padding=1), xf, gy)
+        hip = ops.k_conv_dgrad(gy.cuda(), w.cuda(), g, 1.0)
+        x3 = dgrad_x3(gy.cuda(), pack_x3(w.cuda(), 1, 1.0), g)
+        ec, eh, e3 = err(cpu, exact), err(hip, exact), err(x3, exact)
+        print(f'dgrad {ci:3d}->{co:3d} {hw}x{hw}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 {e3:.3e} ({e3 / ec:.2f})', flush=True)
+
+
+def times(batch, rounds, reps):
+    for ci, co, hw in LAYERS:
+        x = torch.randn(batch, ci, hw, hw, device='cuda')
+        w = torch.randn(co, ci, 3, 3, device='cuda')
+        g = ops.Geom(batch, ci, hw, hw, co, 3, 1)
+        wp3 = pack_x3(w, 0, 0.05)
+        fl = ops.conv_flops(g)
+        fns = {'fp32': lambda: ops.k_conv_fwd(x, w, None, g, 0.05), 'x3': lambda: fwd_x3(x, wp3, None, g)}
+        d = (fns['fp32']() - fns['x3']()).abs().max().item()
+        ms = {k: [] for k in fns}
+        for k in fns:
+            for _ in range(5):
+                fns[k]()
+        for _ in range(rounds):
+            for k, fn in fns.items():
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms[k].append(e0.elapsed_time(e1) / reps)
+        med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+        print(f'{ci:3d}->{co:3d} @{hw:3d} x{batch}: fp32 MFMA {med["fp32"]:.3f} ms ({fl / med["fp32"] / 1e9:6.1f} TF/s)  3xbf16 {med["x3"]:.3f} ms '
+              f'({fl / med["x3"] / 1e9:6.1f} TF/s fp32-equivalent, {6 * fl / med["x3"] / 1e9:7.1f} bf16)  speed-up {med["fp32"] / med["x3"]:.2f}x  '
+              f'max |diff| {d:.2e}', flush=True)
+        del x, w
+
+
+if __name__ == '__main__':
+    p = argparse.ArgumentParser()
+    p.add_argument('--batch', type=int, default=32)
+    p.add_argument('--rounds', type=int, default=5)
+    p.add_argument('--reps', type=int, default=10)
+    p.add_argument('--err-only', action='store_true')
+    p.add_argument('--time-only', action='store_true')
+    a = p.parse_args()
+    if not a.time_only:
+        errors()
+    if not a.err_only:
+        times(a.batch, a.rounds, a.reps)
