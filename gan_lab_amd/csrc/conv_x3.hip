@@ -86,57 +86,85 @@ struct X3Args {
   const float* bias;
   float* y;
   int N, CI, CO, H, W;
-  int tiles_x, tiles_y, tiles_co;
+  int tiles_x, tiles_y, tiles_co, ntiles;
   float bias_scale, slope;
   int act;
 };
 
+// The MFMAs are inline asm: accumulators pinned in the accumulation registers (tied operand, "a" class), issued in exactly
+// this order.  hipcc's hazard recogniser does not see through asm: an accumulator read by the vector ALU needs the matrix
+// pipe drained first (X3_MFMA_DRAIN before the chain dump and the epilogue).
+#define X3_MFMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+// drain / settle: wait states tied to a whole accumulator set (the set counts as rewritten by them, so neither the vector
+// ALU code in front of the block nor the MFMAs behind it can be scheduled across)
+#define X3_ACC8(a) "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1])
+#define X3_MFMA_DRAIN(a) asm volatile("s_nop 15\n\ts_nop 15" : X3_ACC8(a))
+#define X3_VALU_SETTLE(a) asm volatile("s_nop 7\n\ts_nop 7" : X3_ACC8(a))
+
 // tap offset (units) inside the halo patch
 __host__ __device__ constexpr int x3_toff(int tap) { return (tap / 3) * 18 + tap % 3; }
 
+struct X3Tile { int n, oy0, ox0, co_t; };
+
+// One barrier per stage, in its second k-step: everything a wave must have finished before it (its LDS-DMA of the next stage's
+// weights: all but the `YOUNGER` vector-memory operations issued after them; its ds_writes and ds_reads)
+template <int YOUNGER>
+__device__ __forceinline__ void x3_barrier() {
+  if constexpr (YOUNGER == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  static_assert(YOUNGER == 0 || YOUNGER == 4, "the activation staging issues four loads");
+}
+
+// Persistent workgroups: workgroup b takes the tiles remap(b) + i * gridDim.x; the k-loop runs on across tiles (the next tile's
+// first two half patches and first weight stages are staged during the last stages of this one).
 __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[X3_LDS];
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;          // pixel rows 4wm .. 4wm+3 of the tile, channels 32wn .. 32wn+31
   const int l16 = lane & 15, kg = lane >> 4;
-  int bid = gl_xcd_remap(blockIdx.x, gridDim.x);
-  const int co_t = bid % p.tiles_co; bid /= p.tiles_co;
-  const int txi = bid % p.tiles_x; bid /= p.tiles_x;
-  const int tyi = bid % p.tiles_y;
-  const int n = bid / p.tiles_y;
-  const int oy0 = tyi * 16, ox0 = txi * 16, co0 = co_t * X3_NT;
   const int plane = p.H * p.W;
-  const int nstages = p.CI / 64 * 9, nhalves = p.CI / 16;
+  const int nstages = p.CI / 64 * 9, ndc = p.CI / 64;
+  const int G = gridDim.x;
 
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x + (long long)n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
-  const u32x4* wsrc = p.wp + (long long)co_t * nstages * X3_WSTAGE;
+  auto decode = [&](int t) {
+    X3Tile c;
+    c.co_t = t % p.tiles_co; t /= p.tiles_co;
+    c.ox0 = (t % p.tiles_x) * 16; t /= p.tiles_x;
+    c.oy0 = (t % p.tiles_y) * 16;
+    c.n = t / p.tiles_y;
+    return c;
+  };
 
   // ---- activation staging item of this thread: (channel group g, row r, 4-column group cg, channel quad cq) ----------
   // columns ox0 - 4 + 4cg .. + 3; halo column of element i = 4cg - 3 + i (valid 0 .. 17: cg 0 keeps i = 3, cg 5 keeps i = 0)
   const bool a_item = tid < 432;
-  int a_goff, a_unit, a_i0, a_i1;
+  int a_rel, a_ry, a_rx, a_unit, a_i0, a_i1;
   {
     const int e = a_item ? tid : 0;
     const int cq = e & 1;
     int t = e >> 1;
     const int cg = t % 6; t /= 6;
     const int r = t % 18, g = t / 18;
-    const int vy = oy0 - 1 + r, vx = ox0 - 4 + 4 * cg;
-    const bool ok = a_item && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W;
-    a_goff = ok ? ((g * 8 + cq * 4) * plane + vy * p.W + vx) * 4 : (int)0x80000000;
+    a_ry = r - 1; a_rx = 4 * cg - 4;
+    a_rel = ((g * 8 + cq * 4) * plane + a_ry * p.W + a_rx) * 4;
     a_unit = ((g * 3) * X3_PL + r * 18 + 4 * cg - 3) * 16 + cq * 8;     // byte offset of element 0, plane 0
     a_i0 = cg == 0 ? 3 : 0;
     a_i1 = cg == 5 ? 1 : 4;
   }
   const int cstride = plane * 4;
   float4 ar[4];
-  auto a_load = [&](int half) {     // channels 16 half + 8g + 4cq + j
+  auto a_load = [&](const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j of tile c's halo patch
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (long long)c.n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
+    const bool ok = a_item && (unsigned)(c.oy0 + a_ry) < (unsigned)p.H && (unsigned)(c.ox0 + a_rx) < (unsigned)p.W;
+    int off = ok ? a_rel + (c.oy0 * p.W + c.ox0) * 4 : (int)0x80000000;
+    asm volatile("" : "+v"(off));      // computed here, not kept (spilled) across the k-loop
     const int soff = half * 16 * plane * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_goff + j * cstride, soff, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * cstride, soff, 0);
       ar[j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
   };
@@ -158,19 +186,19 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
       *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
       *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
       *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
+      __builtin_amdgcn_sched_barrier(0);     // one pixel at a time: the split's temporaries stay a dozen registers
     }
   };
 
-  // ---- weight staging: 1536 units per stage (two k-steps), 3 per thread ---------------------------------------------
-  u32x4 wr[3];
-  auto w_load = [&](int st) {
-    const u32x4* s = wsrc + (long long)st * X3_WSTAGE;
+  // ---- weight staging: LDS-DMA, the packed stage image is the LDS image; 24 pieces of 1 KB per stage, 3 per wave ----
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(p.wp), 0, (unsigned)((long long)p.tiles_co * nstages * X3_WSTAGE * 16), 0x00020000);
+  auto w_dma = [&](const X3Tile& c, int st, int buf) {
+    const int soff = (c.co_t * nstages + st) * (X3_WSTAGE * 16) + wv * 3072;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) wr[i] = s[tid + i * 512];
-  };
-  auto w_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) lds[X3_WOFF + buf * X3_WSTAGE + tid + i * 512] = wr[i];
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + X3_WOFF + buf * X3_WSTAGE + wv * 192 + i * 64),
+                                               16, lane * 16 + i * 1024, soff, 0, 0);
   };
 
   f32x4 accS[4][2], accH[4][2], accT[4][2];
@@ -184,118 +212,157 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
   const int laneA = X3_AOFF + (kg & 1) * 3 * X3_PL + (4 * wm) * 18 + l16;
   const int laneB = X3_WOFF + kg * X3_NT + wn * 32 + l16;
   const bool khi = kg >= 2;
+  const int khi_i = khi ? 1 : 0;
 
-  bf16x8 aF[3][4], bF[2][3];
-  auto a_frags = [&](int off, int m) {
+  bf16x8 aF[2][3], bF[2][2][3];
+  auto a_frags = [&](int off, int m) {       // row m of a k-step -> register set m & 1
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) aF[pl][m] = __builtin_bit_cast(bf16x8, lds[off + pl * X3_PL + m * 18]);
+    for (int pl = 0; pl < 3; ++pl) aF[m & 1][pl] = __builtin_bit_cast(bf16x8, lds[off + pl * X3_PL + m * 18]);
   };
   auto b_frags = [&](int buf, int step1, int nn, int set) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
-      bF[set][pl] = __builtin_bit_cast(bf16x8, lds[laneB + buf * X3_WSTAGE + step1 * X3_WSTEP + pl * 4 * X3_NT + nn * 16]);
+      bF[set][nn][pl] = __builtin_bit_cast(bf16x8, lds[laneB + buf * X3_WSTAGE + step1 * X3_WSTEP + pl * 4 * X3_NT + nn * 16]);
   };
 
-  // ---- prologue: halves 0, 1, weights of stage 0; loads of stage 1 in flight -----------------------------------------
-  a_load(0); a_store(0);
-  a_load(1); a_store(1);
-  w_load(0); w_store(0);
-  if (nstages > 1) w_load(1);
-  __syncthreads();
+  int tile = gl_xcd_remap(blockIdx.x, G);
+  if (tile >= p.ntiles) return;          // (grid <= ntiles: never taken)
+  X3Tile cur = decode(tile);
+
+  // ---- prologue: halves 0, 1, weight stages 0, 1 of the first tile -----------------------------------------------------
+  w_dma(cur, 0, 0);
+  a_load(cur, 0); a_store(0);
+  a_load(cur, 1); a_store(1);
+  x3_barrier<0>();
+  if (nstages > 1) w_dma(cur, 1, 1);
+  int offA;                          // this lane's patch offset (units) of the k-step whose rows are being read
   {
-    const int off0 = laneA + (khi ? x3_toff(x3_tap_hi(0)) : x3_toff(x3_tap_lo(0)));
-#pragma unroll
-    for (int m = 0; m < 4; ++m) a_frags(off0, m);
+    offA = laneA + (khi ? x3_toff(x3_tap_hi(0)) : x3_toff(x3_tap_lo(0)));
+    a_frags(offA, 0);
     b_frags(0, 0, 0, 0);
+    b_frags(0, 0, 1, 0);
   }
 
-  int st = 0;                       // global stage index
-  const int ndc = p.CI / 64;
-  int r0 = 0;                       // ring slot of this double chunk's first half: (4 dc) % 3
-  for (int dc = 0; dc < ndc; ++dc) {
-    // ring slots of the halves 4dc + 0 .. 5
-    const int sl0 = r0, sl1 = r0 == 2 ? 0 : r0 + 1, sl2 = sl1 == 2 ? 0 : sl1 + 1;
-    const bool more = dc + 1 < ndc;
+  int st = 0;                       // stage within the tile
+  int gst = 0;                      // stages since the kernel started
+  int r0 = 0;                       // ring slot of this double chunk's first half
+  for (;;) {
+    const int ntile = tile + G;
+    const bool nvalid = ntile < p.ntiles;
+    const X3Tile nxt = decode(nvalid ? ntile : tile);
+    for (int dc = 0; dc < ndc; ++dc) {
+      // ring slots of the halves 4dc + 0 .. 5
+      const int sl0 = r0, sl1 = r0 == 2 ? 0 : r0 + 1, sl2 = sl1 == 2 ? 0 : sl1 + 1;
+      const bool lastdc = dc + 1 == ndc;
+      const bool more = !lastdc || nvalid;       // there is a double chunk after this one
 #pragma unroll
-    for (int j = 0; j < 9; ++j, ++st) {
-      const int buf = st & 1;
-      // stores at the top of the stage (their loads were issued one or two stages ago)
-      if (st + 1 < nstages) w_store(buf ^ 1);
-      if (j == 0 && dc > 0) a_store(sl1);            // half 4dc + 1
-      if (j == 2) a_store(sl2);                      // half 4dc + 2
-      if (j == 4) a_store(sl0);                      // half 4dc + 3
-      if (j == 7 && more) a_store(sl1);              // half 4dc + 4
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const int s18 = 2 * j + (sub >> 1);          // k-step within the double chunk
-        const int nn = sub & 1;
-        // operand prefetch for the next sub-block
-        if (sub == 0) b_frags(buf, 0, 1, 1);
-        if (sub == 1) b_frags(buf, 1, 0, 0);
-        if (sub == 2) b_frags(buf, 1, 1, 1);
-        if (sub == 3) {
-          __syncthreads();           // the next stage's weights (and any half patch stored at the top) are visible
-          if (st + 2 < nstages) w_load(st + 2);
-          if (j == 0) a_load(4 * dc + 2);
-          if (j == 2) a_load(4 * dc + 3);
-          if (j == 5 && more) a_load(4 * dc + 4);
-          if (j == 7 && more) a_load(4 * dc + 5);
-          if (st + 1 < nstages) b_frags(buf ^ 1, 0, 0, 0);
-        }
-        const int set = nn;
-        __builtin_amdgcn_sched_barrier(0);
+      for (int s18 = 0; s18 < 18; ++s18) {
+        const int j = s18 >> 1, par = s18 & 1;
+        const int buf = (gst + j) & 1;           // weight buffer of this stage (the parity runs on across tiles: 9 stages per 64 channels)
+        const int cb = s18 & 1;                  // B register set of this k-step
+        // next k-step: patch offset of this lane
+        const int s1 = s18 == 17 ? 0 : s18 + 1;
+        const int c1 = s1 / 9, s9 = s1 % 9;
+        const int hl = 2 * c1 + x3_half_lo(s9), hh = 2 * c1 + x3_half_hi(s9);
+        const int b0 = s18 == 17 ? 1 : 0;        // the next double chunk's ring starts one slot on
+        const int kl = (hl + b0) % 3, kh = (hh + b0) % 3;
+        const int slot_l = kl == 0 ? sl0 : kl == 1 ? sl1 : sl2, slot_h = kh == 0 ? sl0 : kh == 1 ? sl1 : sl2;
+        int la = laneA;
+        asm volatile("" : "+v"(la));           // keeps the 18 per-step offsets from being hoisted out of the double chunk
+        const int u_lo = slot_l * X3_HALF + x3_toff(x3_tap_lo(s9)), u_hi = slot_h * X3_HALF + x3_toff(x3_tap_hi(s9));
+        const int offN = la + u_lo + khi_i * (u_hi - u_lo);
+        const bool has_next = s18 < 17 || more;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          f32x4 sacc = accS[m][nn];
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[2][m], bF[set][0], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[0][m], bF[set][2], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[1][m], bF[set][1], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[1][m], bF[set][0], sacc, 0, 0, 0);
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[0][m], bF[set][1], sacc, 0, 0, 0);
-          accS[m][nn] = sacc;
-          accH[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[0][m], bF[set][0], accH[m][nn], 0, 0, 0);
-          if (nn == 1 && (s18 < 17 || more)) {        // this tile row's fragments of the next k-step
-            const int s1 = s18 == 17 ? 0 : s18 + 1;   // next k-step within its double chunk
-            const int c1 = s1 / 9, s9 = s1 % 9;       // chunk of the pair, step within the chunk
-            const int hl = 2 * c1 + x3_half_lo(s9), hh = 2 * c1 + x3_half_hi(s9);     // halves 0 .. 3 of that double chunk
-            // ring slots: within this double chunk half k sits in slot (r0 + k) % 3; the next one starts at (r0 + 4) % 3 = sl1
-            const int b0 = s18 == 17 ? 1 : 0;
-            const int kl = (hl + b0) % 3, kh = (hh + b0) % 3;
-            const int slot_l = kl == 0 ? sl0 : kl == 1 ? sl1 : sl2, slot_h = kh == 0 ? sl0 : kh == 1 ? sl1 : sl2;
-            const int offn = laneA + (khi ? slot_h * X3_HALF + x3_toff(x3_tap_hi(s9)) : slot_l * X3_HALF + x3_toff(x3_tap_lo(s9)));
-            a_frags(offn, m);
+          // ---- operand prefetch -----------------------------------------------------------------------------------
+          if (m < 3) a_frags(offA, m + 1);
+          else if (has_next) a_frags(offN, 0);
+          if (par == 0) {                       // next k-step is in the same weight buffer
+            if (m == 0) b_frags(buf, 1, 0, cb ^ 1);
+            if (m == 1) b_frags(buf, 1, 1, cb ^ 1);
+          } else {                              // next k-step opens the next stage: behind the barrier
+            if (m == 1 && has_next) b_frags(buf ^ 1, 0, 0, cb ^ 1);
+            if (m == 2 && has_next) b_frags(buf ^ 1, 0, 1, cb ^ 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn) {
+            X3_MFMA(accS[m][nn], aF[m & 1][2], bF[cb][nn][0]);
+            X3_MFMA(accS[m][nn], aF[m & 1][0], bF[cb][nn][2]);
+            X3_MFMA(accS[m][nn], aF[m & 1][1], bF[cb][nn][1]);
+            X3_MFMA(accS[m][nn], aF[m & 1][1], bF[cb][nn][0]);
+            X3_MFMA(accS[m][nn], aF[m & 1][0], bF[cb][nn][1]);
+            X3_MFMA(accH[m][nn], aF[m & 1][0], bF[cb][nn][0]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (par == 1 && m == 0) {
+            // ---- the stage's barrier: half patches stored now and the next stage's weights are visible behind it ------
+            if (j == 0 && (dc > 0 || st > 0 || tile != gl_xcd_remap(blockIdx.x, G))) a_store(sl1);     // half 4dc + 1
+            if (j == 2) a_store(sl2);                      // half 4dc + 2
+            if (j == 4) a_store(sl0);                      // half 4dc + 3
+            if (j == 7 && more) a_store(sl1);              // half 4dc + 4 (the next tile's half 0 behind the last double chunk)
+            if (j == 1 || j == 3) x3_barrier<4>();
+            else if (j == 6 || j == 8) { if (more) x3_barrier<4>(); else x3_barrier<0>(); }
+            else x3_barrier<0>();
+            // weights two stages on -> the buffer this stage has finished reading
+            {
+              const int s2 = st + j + 2;
+              if (s2 < nstages) w_dma(cur, s2, buf);
+              else if (nvalid) w_dma(nxt, s2 - nstages, buf);
+            }
+            __builtin_amdgcn_sched_barrier(0);    // the counted wait of the next barrier assumes: DMA first, then the 4 loads
+            if (j == 0) a_load(cur, 4 * dc + 2);
+            if (j == 2) a_load(cur, 4 * dc + 3);
+            if (j == 5 && more) { if (lastdc) a_load(nxt, 0); else a_load(cur, 4 * dc + 4); }
+            if (j == 7 && more) { if (lastdc) a_load(nxt, 1); else a_load(cur, 4 * dc + 5); }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-        if (nn == 1 && (s18 == 8 || s18 == 17)) {     // a 32-channel chunk is done: close its hi*hi chain
+        offA = offN;
+        if (s18 == 8 || s18 == 17) {     // a 32-channel chunk is done: close its hi*hi chain
+          X3_MFMA_DRAIN(accH);
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q) { accT[m][q] += accH[m][q]; accH[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          X3_VALU_SETTLE(accH);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      st += 9;
+      gst += 9;
+      r0 = sl1;      // (r0 + 4) % 3
     }
-    r0 = sl1;      // (r0 + 4) % 3
-  }
 
-  // ---- epilogue: T + S + bias, activation; lane = 4 consecutive pixels of one channel ---------------------------------
-  float* yb = p.y + (long long)n * p.CO * plane;
+    // ---- epilogue: T + S + bias, activation; lane = 4 consecutive pixels of one channel --------------------------------
+    {
+      X3_MFMA_DRAIN(accS);
+      float* yb = p.y + (long long)cur.n * p.CO * plane;
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn) {
-    const int co = co0 + wn * 32 + nn * 16 + l16;
-    const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
+      for (int nn = 0; nn < 2; ++nn) {
+        const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
+        const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const long long o = (long long)co * plane + (oy0 + 4 * wm + m) * p.W + ox0 + 4 * kg;
-      f32x4 v = accT[m][nn] + accS[m][nn];
+        for (int m = 0; m < 4; ++m) {
+          const long long o = (long long)co * plane + (cur.oy0 + 4 * wm + m) * p.W + cur.ox0 + 4 * kg;
+          f32x4 v = accT[m][nn] + accS[m][nn];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float f = v[r] + bv;
-        if (p.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, p.slope);
-        v[r] = f;
+          for (int r = 0; r < 4; ++r) {
+            float f = v[r] + bv;
+            if (p.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, p.slope);
+            v[r] = f;
+          }
+          *reinterpret_cast<f32x4*>(yb + o) = v;
+          accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+          accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
-      *reinterpret_cast<f32x4*>(yb + o) = v;
+      X3_VALU_SETTLE(accS);
     }
+    if (!nvalid) break;
+    tile = ntile;
+    cur = nxt;
+    st = 0;
   }
 }
 
@@ -312,9 +379,11 @@ int x3_launch(const float* x, const void* wp, const float* bias, float* y, int N
   a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
   a.tiles_x = W / 16; a.tiles_y = H / 16; a.tiles_co = CO / X3_NT;
   a.bias_scale = bias_scale; a.slope = slope; a.act = act;
-  const long long grid = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
-  if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;
-  GL_LAUNCH(conv_x3_fwd_kernel, dim3((unsigned)grid), dim3(512), 0, st, a);
+  const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)a.tiles_co * (CI / 64 * 9) * X3_WSTAGE * 16 > 0xffffffffLL) return GANLAB_EINVAL;
+  a.ntiles = (int)ntiles;
+  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);       // one workgroup per CU (146 KB of LDS), persistent
+  GL_LAUNCH(conv_x3_fwd_kernel, dim3(grid), dim3(512), 0, st, a);
   return GL_CHECK_LAUNCH();
 }
 
