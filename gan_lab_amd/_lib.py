@@ -80,6 +80,11 @@ SIGNATURES = {
     'ganlab_conv_x3_pack': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
     'ganlab_conv_fwd_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_dgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_dgrad_mask_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p]),
+    'ganlab_conv_fwd_aff_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_fwd_aff_tail_x3_chunks': (_c_int, [_GP]),
+    'ganlab_conv_fwd_aff_tail_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f,
+                                             _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_mask_bits_supported': (_c_int, [_c_int, _c_int]),
     'ganlab_blur3x3_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_ll, _c_int, _c_int, _c_p]),
     'ganlab_blur_act_bwd_bits_f32': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_f, _c_f,

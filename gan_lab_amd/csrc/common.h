@@ -110,6 +110,38 @@ __device__ __forceinline__ float4 gl_few_dot(const float4 (&xv)[4], const float*
   return a;
 }
 
+// ---- conv_x3.hip packed weights: [co tile 64][k-step][plane 3][k-group 4][co 64][8] bf16, three planes that sum to the fp32
+// weight exactly.  k-step s of a 32-channel chunk: lane groups 0,1 = (tap_lo(s), half_lo(s)), 2,3 = (tap_hi(s), half_hi(s)) with
+//   steps 0-3: taps (0,1) (2,3) (4,5) (6,7) of half 0 | step 4: tap 8 of half 0 and of half 1 | steps 5-8: half 1.
+// gl_x3_pack_position writes the 9 taps x 3 planes of GEMM position (row ci, column co) - shared by the single-weight
+// kernel (conv_x3.hip) and the batched re-pack (pack.hip), so both produce the same bits.  w9: the position's 9 taps in
+// GEMM order (already flipped for the input gradient), scaled here.
+__device__ __forceinline__ void gl_x3_pack_position(const float* __restrict__ w9, bool flip, float scale, __bf16* __restrict__ out,
+                                                    int CI, int ci, int co) {
+  const int steps = CI / 32 * 9;
+  const int ct = co >> 6, col = co & 63, c = ci >> 5, half = (ci >> 4) & 1, g = (ci >> 3) & 1, j = ci & 7;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int s = t < 8 ? (half ? 5 : 0) + (t >> 1) : 4;
+    const int hi = t < 8 ? (t & 1) : half;
+    const int kg = hi * 2 + g;
+    float v = w9[flip ? 8 - t : t] * scale;
+    asm volatile("" : "+v"(v));      // the ROUNDED product is what is split: no contraction of this multiply into v - h below
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    __bf16* base = out + (((long long)ct * steps + c * 9 + s) * (3 * 4 * 64)) * 8;
+    base[((0 * 4 + kg) * 64 + col) * 8 + j] = h;
+    base[((1 * 4 + kg) * 64 + col) * 8 + j] = m;
+    base[((2 * 4 + kg) * 64 + col) * 8 + j] = l;
+  }
+}
+
+// ---- conv.hip: mean / rstd of every (n, c) plane from per-tile sums of y and y^2 (fixed order, fp64) ---------------------------
+extern "C" int gl_tail_stats_finish(const double* spart, float* mean, float* rstd, long long planes, int chunks, double inv_hw, float eps,
+                         hipStream_t st);
+
 // ---- wgrad_roll.hip: rolling-window weight gradient of the thin 3x3 layers (used by ganlab_conv_wgrad_f32) ----------
 bool gl_wgrad_roll_supported(int N, int Cin, int Cout, int H, int W, int ks, int pad, int up, const void* x,
                              const void* gy);

@@ -2644,6 +2644,14 @@ __global__ void conv_tail_stats_finish_kernel(const double* __restrict__ spart, 
   rstd[pl] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+/* conv_x3.hip's TAIL form finishes its statistics with the same fixed-order kernel (declared in common.h) */
+int gl_tail_stats_finish(const double* spart, float* mean, float* rstd, long long planes, int chunks, double inv_hw, float eps,
+                         hipStream_t st) {
+  GL_LAUNCH(conv_tail_stats_finish_kernel, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, st, spart, mean, rstd, planes,
+            chunks, inv_hw, eps);
+  return GL_CHECK_LAUNCH();
+}
+
 /* statistics tiles per (n, c) plane ganlab_conv_fwd_aff_tail_f32 writes (workspace: N * Cout * tiles * 2 doubles); 0 = not
  * a geometry that form takes */
 int ganlab_conv_fwd_aff_tail_chunks(const ganlab_conv_geom* g) {

@@ -48,36 +48,19 @@ __host__ __device__ constexpr int x3_tap_hi(int s) { return s < 4 ? 2 * s + 1 : 
 __host__ __device__ constexpr int x3_half_lo(int s) { return s <= 4 ? 0 : 1; }
 __host__ __device__ constexpr int x3_half_hi(int s) { return s < 4 ? 0 : 1; }
 
-// ---- weight packing: OIHW fp32 -> [co tile][k-step][plane][k-group][co 64][8] bf16 ------------------------------------
+// ---- weight packing: OIHW fp32 -> [co tile][k-step][plane][k-group][co 64][8] bf16 (common.h gl_x3_pack_position) ------
+// one thread per GEMM position (ci, co); adjacent threads = adjacent output columns
 __global__ void x3_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int mode, float scale) {
-  const int CO = mode == GANLAB_PACK_DGRAD ? Cin : Cout;     // GEMM roles
-  const int CI = mode == GANLAB_PACK_DGRAD ? Cout : Cin;
-  const long long total = 9LL * CO * CI;                      // elements per plane
-  const int steps = CI / 32 * 9;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(e & 7);
-    long long t = e >> 3;
-    const int col = (int)(t % X3_NT); t /= X3_NT;
-    const int kg = (int)(t & 3); t >>= 2;
-    const int ks = (int)(t % steps);
-    const int ct = (int)(t / steps);
-    const int c = ks / 9, s = ks % 9;
-    const int tap = (kg >> 1) ? x3_tap_hi(s) : x3_tap_lo(s);
-    const int half = (kg >> 1) ? x3_half_hi(s) : x3_half_lo(s);
-    const int ci = c * 32 + half * 16 + (kg & 1) * 8 + j;
-    const int co = ct * X3_NT + col;
-    float v = mode == GANLAB_PACK_DGRAD ? w[((long long)ci * Cin + co) * 9 + (8 - tap)] : w[((long long)co * Cin + ci) * 9 + tap];
-    v *= scale;
-    const __bf16 h = (__bf16)v;
-    const float r1 = v - x3_up(h);
-    const __bf16 m = (__bf16)r1;
-    const __bf16 l = (__bf16)(r1 - x3_up(m));
-    // unit index within the k-step image: (plane * 4 + kg) * 64 + col
-    __bf16* base = out + ((long long)ct * steps + ks) * X3_WSTEP * 8;
-    base[((0 * 4 + kg) * X3_NT + col) * 8 + j] = h;
-    base[((1 * 4 + kg) * X3_NT + col) * 8 + j] = m;
-    base[((2 * 4 + kg) * X3_NT + col) * 8 + j] = l;
-  }
+  const bool dg = mode == GANLAB_PACK_DGRAD;
+  const int CO = dg ? Cin : Cout, CI = dg ? Cout : Cin;        // GEMM roles
+  const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (e >= (long long)CO * CI) return;
+  const int col = (int)(e & 63);
+  const long long t = e >> 6;
+  const int ci = (int)(t % CI), ct = (int)(t / CI);
+  const int co = ct * 64 + col;
+  const float* w9 = dg ? w + ((long long)ci * Cin + co) * 9 : w + ((long long)co * Cin + ci) * 9;
+  gl_x3_pack_position(w9, dg, scale, out, CI, ci, co);
 }
 
 struct X3Args {
@@ -89,7 +72,17 @@ struct X3Args {
   int tiles_x, tiles_y, tiles_co, ntiles;
   float bias_scale, slope;
   int act;
+  const float* mask;        // MASK: y *= (mask > 0 ? 1 : mslope), mask shaped like y (the input gradient of a conv whose input
+  float mslope;             //       is a LeakyReLU output comes out multiplied by that LeakyReLU's derivative)
+  const float* aff_s;       // AFF: the conv reads x * aff_s[n][ci] + aff_t[n][ci] inside the image (deferred InstanceNorm)
+  const float* aff_t;
+  const float* noise;       // TAIL: y = act(conv + noise_w[c] * noise[n][hw] + bias) and this tile's sums of y, y^2 per (n, c):
+  const float* noise_w;     //       spart[((n * CO + c) * 4 tiles_per_plane + 4 tile + wave row) * 2]
+  double* spart;
 };
+
+// kernel forms
+constexpr int X3_PLAIN = 0, X3_MASK = 1, X3_AFF = 2, X3_AFF_TAIL = 3;
 
 // The MFMAs are inline asm: accumulators pinned in the accumulation registers (tied operand, "a" class), issued in exactly
 // this order.  hipcc's hazard recogniser does not see through asm: an accumulator read by the vector ALU needs the matrix
@@ -111,19 +104,23 @@ struct X3Tile { int n, oy0, ox0, co_t; };
 template <int YOUNGER>
 __device__ __forceinline__ void x3_barrier() {
   if constexpr (YOUNGER == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  static_assert(YOUNGER == 0 || YOUNGER == 4, "the activation staging issues four loads");
+  else if constexpr (YOUNGER == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  static_assert(YOUNGER == 0 || YOUNGER == 4 || YOUNGER == 6, "the activation staging issues four loads (six with the affine)");
 }
 
 // Persistent workgroups: workgroup b takes the tiles remap(b) + i * gridDim.x; the k-loop runs on across tiles (the next tile's
 // first two half patches and first weight stages are staged during the last stages of this one).
+template <int FORM>
 __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
+  constexpr bool MASK = FORM == X3_MASK, AFF = FORM == X3_AFF || FORM == X3_AFF_TAIL, TAIL = FORM == X3_AFF_TAIL;
+  constexpr int NLOADS = AFF ? 6 : 4;           // vector-memory loads one activation staging issues
   __shared__ __attribute__((aligned(16))) u32x4 lds[X3_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;          // pixel rows 4wm .. 4wm+3 of the tile, channels 32wn .. 32wn+31
-  const int l16 = lane & 15, kg = lane >> 4;
+  const int l16 = lane & 15, kg = lane >> 4, lane16 = lane * 16;
   const int plane = p.H * p.W;
   const int nstages = p.CI / 64 * 9, ndc = p.CI / 64;
   const int G = gridDim.x;
@@ -139,45 +136,62 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
 
   // ---- activation staging item of this thread: (channel group g, row r, 4-column group cg, channel quad cq) ----------
   // columns ox0 - 4 + 4cg .. + 3; halo column of element i = 4cg - 3 + i (valid 0 .. 17: cg 0 keeps i = 3, cg 5 keeps i = 0)
+  // One register holds the item: bits 0-14 byte offset of element 0 / plane 0 in a half slot + 48 (>= 0), 16-17 first kept
+  // element, 18-20 one past the last, 21-25 patch row, 26-28 column group, 29-30 channel quad index (g * 2 + cq).
   const bool a_item = tid < 432;
-  int a_rel, a_ry, a_rx, a_unit, a_i0, a_i1;
+  int a_pack;
   {
     const int e = a_item ? tid : 0;
     const int cq = e & 1;
     int t = e >> 1;
     const int cg = t % 6; t /= 6;
     const int r = t % 18, g = t / 18;
-    a_ry = r - 1; a_rx = 4 * cg - 4;
-    a_rel = ((g * 8 + cq * 4) * plane + a_ry * p.W + a_rx) * 4;
-    a_unit = ((g * 3) * X3_PL + r * 18 + 4 * cg - 3) * 16 + cq * 8;     // byte offset of element 0, plane 0
-    a_i0 = cg == 0 ? 3 : 0;
-    a_i1 = cg == 5 ? 1 : 4;
+    const int unit48 = ((g * 3) * X3_PL + r * 18 + 4 * cg) * 16 + cq * 8;     // + 48: the element-0 unit of cg = 0 is 3 units before
+    a_pack = unit48 | ((cg == 0 ? 3 : 0) << 16) | ((cg == 5 ? 1 : 4) << 18) | (r << 21) | (cg << 26) | ((g * 2 + cq) << 29);
   }
   const int cstride = plane * 4;
   float4 ar[4];
+  float4 a_sv, a_tv;                                  // AFF: scale / shift of the item's four channels (zeros outside the image)
   auto a_load = [&](const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j of tile c's halo patch
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + (long long)c.n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
-    const bool ok = a_item && (unsigned)(c.oy0 + a_ry) < (unsigned)p.H && (unsigned)(c.ox0 + a_rx) < (unsigned)p.W;
-    int off = ok ? a_rel + (c.oy0 * p.W + c.ox0) * 4 : (int)0x80000000;
-    asm volatile("" : "+v"(off));      // computed here, not kept (spilled) across the k-loop
+    int pk = a_pack;
+    asm volatile("" : "+v"(pk));      // offsets computed HERE, not hoisted out of the k-loop and spilled
+    const int ry = ((pk >> 21) & 31) - 1, rx = ((pk >> 26) & 7) * 4 - 4, a_ch = ((pk >> 29) & 3) * 4;
+    const bool ok = a_item && (unsigned)(c.oy0 + ry) < (unsigned)p.H && (unsigned)(c.ox0 + rx) < (unsigned)p.W;
+    const int off = ok ? (a_ch * plane + (c.oy0 + ry) * p.W + c.ox0 + rx) * 4 : (int)0x80000000;
     const int soff = half * 16 * plane * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * cstride, soff, 0);
       ar[j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
     }
+    if constexpr (AFF) {       // an item outside the image reads zeros for s and t as well: 0 * 0 + 0 keeps the padding zero
+      const long long tab = (long long)p.N * p.CI * 4;
+      const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_s), 0, (unsigned)tab, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_t), 0, (unsigned)tab, 0x00020000);
+      const int o = ok ? a_ch * 4 : (int)0x80000000;
+      const int so = (c.n * p.CI + half * 16) * 4;
+      const u32x4 sv = __builtin_amdgcn_raw_buffer_load_b128(rss, o, so, 0), tv = __builtin_amdgcn_raw_buffer_load_b128(rst, o, so, 0);
+      a_sv = float4{__uint_as_float(sv.x), __uint_as_float(sv.y), __uint_as_float(sv.z), __uint_as_float(sv.w)};
+      a_tv = float4{__uint_as_float(tv.x), __uint_as_float(tv.y), __uint_as_float(tv.z), __uint_as_float(tv.w)};
+    }
   };
   auto a_store = [&](int slot) {
     if (!a_item) return;
-    unsigned char* dst = reinterpret_cast<unsigned char*>(lds + X3_AOFF + slot * X3_HALF) + a_unit;
+    int pk = a_pack;
+    asm volatile("" : "+v"(pk));
+    const int a_i0 = (pk >> 16) & 3, a_i1 = (pk >> 18) & 7;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(lds + X3_AOFF + slot * X3_HALF) + ((pk & 0x7fff) - 48);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < a_i0 || i >= a_i1) continue;
       bf16x4 h, m, l;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
+        float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
+        if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
+                                    j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
         h[j] = (__bf16)v;
         const float r1 = v - x3_up(h[j]);
         m[j] = (__bf16)r1;
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + X3_WOFF + buf * X3_WSTAGE + wv * 192 + i * 64),
-                                               16, lane * 16 + i * 1024, soff, 0, 0);
+                                               16, lane16, soff + i * 1024, 0, 0);
   };
 
   f32x4 accS[4][2], accH[4][2], accT[4][2];
@@ -301,8 +315,8 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
             if (j == 2) a_store(sl2);                      // half 4dc + 2
             if (j == 4) a_store(sl0);                      // half 4dc + 3
             if (j == 7 && more) a_store(sl1);              // half 4dc + 4 (the next tile's half 0 behind the last double chunk)
-            if (j == 1 || j == 3) x3_barrier<4>();
-            else if (j == 6 || j == 8) { if (more) x3_barrier<4>(); else x3_barrier<0>(); }
+            if (j == 1 || j == 3) x3_barrier<NLOADS>();
+            else if (j == 6 || j == 8) { if (more) x3_barrier<NLOADS>(); else x3_barrier<0>(); }
             else x3_barrier<0>();
             // weights two stages on -> the buffer this stage has finished reading
             {
@@ -337,24 +351,63 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
     // ---- epilogue: T + S + bias, activation; lane = 4 consecutive pixels of one channel --------------------------------
     {
       X3_MFMA_DRAIN(accS);
-      float* yb = p.y + (long long)cur.n * p.CO * plane;
+      // the epilogue's arguments are read from the kernel-argument segment HERE: held in scalar registers across the k-loop
+      // they cost a dozen spills
+      const X3Args* kp = (const X3Args*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      const X3Args& q = *kp;
+      const long long ib = (long long)cur.n * p.CO * plane;
+      float bv[2], nwv[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn) {
         const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
-        const float bv = p.bias != nullptr ? p.bias[co] * p.bias_scale : 0.f;
+        bv[nn] = q.bias != nullptr ? q.bias[co] * q.bias_scale : 0.f;
+        nwv[nn] = 0.f;
+        if constexpr (TAIL) nwv[nn] = q.noise != nullptr ? q.noise_w[co] : 0.f;
+      }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const long long o = (long long)co * plane + (cur.oy0 + 4 * wm + m) * p.W + cur.ox0 + 4 * kg;
+      for (int m = 0; m < 4; ++m) {
+        const int px = (cur.oy0 + 4 * wm + m) * p.W + cur.ox0 + 4 * kg;
+        float4 nz = float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (TAIL) { if (q.noise != nullptr) nz = *reinterpret_cast<const float4*>(q.noise + (long long)cur.n * plane + px); }
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+          const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
+          const long long o = ib + (long long)co * plane + px;
+          f32x4 mk;
+          if constexpr (MASK) mk = *reinterpret_cast<const f32x4*>(q.mask + o);
           f32x4 v = accT[m][nn] + accS[m][nn];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float f = v[r] + bv;
-            if (p.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, p.slope);
+            float f;
+            if constexpr (TAIL) f = fmaf(r == 0 ? nz.x : r == 1 ? nz.y : r == 2 ? nz.z : nz.w, nwv[nn], v[r] + bv[nn]);
+            else f = v[r] + bv[nn];
+            if (q.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, q.slope);
+            if constexpr (MASK) { if (!(mk[r] > 0.f)) f *= q.mslope; }
             v[r] = f;
           }
-          *reinterpret_cast<f32x4*>(yb + o) = v;
+          *reinterpret_cast<f32x4*>(q.y + o) = v;
+          if constexpr (TAIL) {
+            s1[nn] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[nn] += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+          }
           accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
           accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (TAIL) {      // this wave's 64 pixels of each channel: fp64 from the lane sums on, one partial per wave row
+        const long long chunks = (long long)p.tiles_x * p.tiles_y * 4, tl = ((long long)(cur.oy0 >> 4) * p.tiles_x + (cur.ox0 >> 4)) * 4 + wm;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+          double a = (double)s1[nn], b = (double)s2[nn];
+          a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+          b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+          const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
+          if (kg == 0) {
+            double* dst = q.spart + (((long long)cur.n * p.CO + co) * chunks + tl) * 2;
+            dst[0] = a; dst[1] = b;
+          }
         }
       }
       X3_VALU_SETTLE(accS);
@@ -372,19 +425,30 @@ bool x3_ok(const ganlab_conv_geom* g, int dgrad) {
   return CI % 64 == 0 && CO % X3_NT == 0 && g->Hin % 16 == 0 && g->Win % 16 == 0 && g->N > 0;
 }
 
-int x3_launch(const float* x, const void* wp, const float* bias, float* y, int N, int CI, int CO, int H, int W, float bias_scale,
-              int act, float slope, hipStream_t st) {
-  X3Args a;
-  a.x = x; a.wp = reinterpret_cast<const u32x4*>(wp); a.bias = bias; a.y = y;
-  a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
-  a.tiles_x = W / 16; a.tiles_y = H / 16; a.tiles_co = CO / X3_NT;
-  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
-  const long long ntiles = (long long)N * a.tiles_x * a.tiles_y * a.tiles_co;
-  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)a.tiles_co * (CI / 64 * 9) * X3_WSTAGE * 16 > 0xffffffffLL) return GANLAB_EINVAL;
+int x3_launch(int form, X3Args a, hipStream_t st) {
+  a.tiles_x = a.W / 16; a.tiles_y = a.H / 16; a.tiles_co = a.CO / X3_NT;
+  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y * a.tiles_co;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)a.tiles_co * (a.CI / 64 * 9) * X3_WSTAGE * 16 > 0xffffffffLL ||
+      (long long)a.CI * a.H * a.W * 4 > 0x7fffffffLL || (long long)a.N * a.CI * 4 > 0x7fffffffLL)
+    return GANLAB_EINVAL;
   a.ntiles = (int)ntiles;
   const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);       // one workgroup per CU (146 KB of LDS), persistent
-  GL_LAUNCH(conv_x3_fwd_kernel, dim3(grid), dim3(512), 0, st, a);
+  switch (form) {
+    case X3_PLAIN: GL_LAUNCH(conv_x3_fwd_kernel<X3_PLAIN>, dim3(grid), dim3(512), 0, st, a); break;
+    case X3_MASK: GL_LAUNCH(conv_x3_fwd_kernel<X3_MASK>, dim3(grid), dim3(512), 0, st, a); break;
+    case X3_AFF: GL_LAUNCH(conv_x3_fwd_kernel<X3_AFF>, dim3(grid), dim3(512), 0, st, a); break;
+    default: GL_LAUNCH(conv_x3_fwd_kernel<X3_AFF_TAIL>, dim3(grid), dim3(512), 0, st, a); break;
+  }
   return GL_CHECK_LAUNCH();
+}
+
+X3Args x3_args(const float* x, const void* wp, const float* bias, float* y, int N, int CI, int CO, int H, int W, float bias_scale,
+               int act, float slope) {
+  X3Args a{};
+  a.x = x; a.wp = reinterpret_cast<const u32x4*>(wp); a.bias = bias; a.y = y;
+  a.N = N; a.CI = CI; a.CO = CO; a.H = H; a.W = W;
+  a.bias_scale = bias_scale; a.slope = slope; a.act = act;
+  return a;
 }
 
 }  // namespace
@@ -400,10 +464,9 @@ long long ganlab_conv_x3_pack(const float* w, void* out, int Cout, int Cin, int 
   const long long n = 3LL * 9 * Cout * Cin;       // bf16 elements
   if (out == nullptr) return n;
   if (w == nullptr) return GANLAB_EINVAL;
-  const long long per_plane = n / 3;
-  const int blocks = (int)((per_plane + 255) / 256 < 4096 ? (per_plane + 255) / 256 : 4096);
-  GL_LAUNCH(x3_pack_kernel, dim3(blocks), dim3(256), 0, gl_stream(stream), w, reinterpret_cast<__bf16*>(out), Cout, Cin, mode,
-            scale);
+  const long long positions = (long long)Cout * Cin;
+  GL_LAUNCH(x3_pack_kernel, dim3((unsigned)((positions + 255) / 256)), dim3(256), 0, gl_stream(stream), w,
+            reinterpret_cast<__bf16*>(out), Cout, Cin, mode, scale);
   const int st = GL_CHECK_LAUNCH();
   return st != GANLAB_OK ? st : n;
 }
@@ -411,12 +474,50 @@ long long ganlab_conv_x3_pack(const float* w, void* out, int Cout, int Cin, int 
 int ganlab_conv_fwd_x3(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g, float bias_scale,
                        int act, float slope, void* stream) {
   if (!x3_ok(g, 0) || x == nullptr || wp == nullptr || y == nullptr) return GANLAB_EINVAL;
-  return x3_launch(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope, gl_stream(stream));
+  return x3_launch(X3_PLAIN, x3_args(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope), gl_stream(stream));
 }
 
 int ganlab_conv_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream) {
   if (!x3_ok(g, 1) || gy == nullptr || wp == nullptr || gx == nullptr) return GANLAB_EINVAL;
-  return x3_launch(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin, g->Win, 1.f, GANLAB_ACT_NONE, 0.f, gl_stream(stream));
+  return x3_launch(X3_PLAIN, x3_args(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin, g->Win, 1.f, GANLAB_ACT_NONE, 0.f),
+                   gl_stream(stream));
+}
+
+/* ganlab_conv_dgrad_mask_f32: gx = dgrad(gy, w) * lrelu'(x), x shaped like gx */
+int ganlab_conv_dgrad_mask_x3(const float* gy, const void* wp, const float* x, float* gx, const ganlab_conv_geom* g, float slope,
+                              void* stream) {
+  if (!x3_ok(g, 1) || gy == nullptr || wp == nullptr || gx == nullptr || x == nullptr) return GANLAB_EINVAL;
+  X3Args a = x3_args(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin, g->Win, 1.f, GANLAB_ACT_NONE, 0.f);
+  a.mask = x; a.mslope = slope;
+  return x3_launch(X3_MASK, a, gl_stream(stream));
+}
+
+/* ganlab_conv_fwd_aff_f32: the forward on b = x * aff_s[n][ci] + aff_t[n][ci] (zero padding of b stays zero) */
+int ganlab_conv_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias, float* y,
+                           const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream) {
+  if (!x3_ok(g, 0) || x == nullptr || wp == nullptr || y == nullptr || aff_s == nullptr || aff_t == nullptr) return GANLAB_EINVAL;
+  X3Args a = x3_args(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope);
+  a.aff_s = aff_s; a.aff_t = aff_t;
+  return x3_launch(X3_AFF, a, gl_stream(stream));
+}
+
+/* ganlab_conv_fwd_aff_tail_f32: y = act(conv(x * aff_s + aff_t, w) + noise_w * noise + bias * bias_scale), mean / rstd = the
+ * InstanceNorm statistics of y.  ganlab_conv_fwd_aff_tail_x3_chunks: partial sums per plane (workspace: N * Cout * tiles * 2 doubles) */
+int ganlab_conv_fwd_aff_tail_x3_chunks(const ganlab_conv_geom* g) { return x3_ok(g, 0) ? (g->Hin / 16) * (g->Win / 16) * 4 : 0; }
+int ganlab_conv_fwd_aff_tail_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
+                                const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
+                                const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  const int chunks = ganlab_conv_fwd_aff_tail_x3_chunks(g);
+  if (chunks <= 0) return GANLAB_EUNSUPPORTED;
+  if (!x || !wp || !y || !aff_s || !aff_t || !mean || !rstd || (noise && !noise_w)) return GANLAB_EINVAL;
+  const long long planes = (long long)g->N * g->Cout;
+  if (!workspace || workspace_bytes < (size_t)planes * chunks * 2 * sizeof(double)) return GANLAB_EWORKSPACE;
+  X3Args a = x3_args(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope);
+  a.aff_s = aff_s; a.aff_t = aff_t; a.noise = noise; a.noise_w = noise_w; a.spart = reinterpret_cast<double*>(workspace);
+  const int rc = x3_launch(X3_AFF_TAIL, a, gl_stream(stream));
+  if (rc != GANLAB_OK) return rc;
+  return gl_tail_stats_finish(a.spart, mean, rstd, planes, chunks, 1.0 / ((double)g->Hin * g->Win), eps, gl_stream(stream));
 }
 
 }  // extern "C"

@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const ganlab_pack_desc* 
         for (int kx = 0; kx < 3; ++kx) v += comb_s2(d.up, a, ky) * comb_s2(d.up, bb, kx) * k9[ky * 3 + kx];
       out[tap * plane] = v * d.scale;
     }
+  } else if (d.kind == GANLAB_PACKKIND_X3) {      // conv_x3.hip: three bf16 planes per weight, k-step images
+    const bool dg = d.mode == GANLAB_PACK_DGRAD;
+    const int CO = dg ? d.Cin : d.Cout, CI = dg ? d.Cout : d.Cin;
+    if (e >= (long long)CO * CI) return;
+    const int col = (int)(e & 63);
+    const long long t = e >> 6;
+    const int ci = (int)(t % CI), ct = (int)(t / CI);
+    const int co = ct * 64 + col;
+    const float* w9 = dg ? w + ((long long)ci * d.Cin + co) * 9 : w + ((long long)co * d.Cin + ci) * 9;
+    gl_x3_pack_position(w9, dg, d.scale, reinterpret_cast<__bf16*>(d.dst), CI, ci, co);
   } else {      // GANLAB_PACKKIND_BF16: [chunk = ci/32][tap][kg = (ci%32)/8][CO][ci%8]
     const int dg = d.mode == GANLAB_PACK_DGRAD;
     const int CO = dg ? d.Cin : d.Cout;

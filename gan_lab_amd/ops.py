@@ -14,6 +14,7 @@ Layering:
 All ops require contiguous fp32 CUDA(HIP) tensors and raise otherwise - there is no CPU path.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -187,7 +188,7 @@ _PACK_SERIAL = [0]
 _PACK_GEN = [0]          # bumped when buffers a captured graph may point at are dropped: full flush, table rebuild
 _PACK_RANGES = {}        # (lo, hi) byte range -> serial of its last rewrite
 _PACK_TABLES = {}        # (lo, hi) -> (entry keys, device descriptor table, total blocks)
-_KIND_PLAIN, _KIND_S2, _KIND_BF16 = 0, 1, 2
+_KIND_PLAIN, _KIND_S2, _KIND_BF16, _KIND_X3 = 0, 1, 2, 3
 
 
 def bump_weight_epoch(ranges=None):
@@ -228,6 +229,8 @@ def _pack_one(e):
         rc = L.ganlab_conv_s2_pack_f32(_p(e.w), _p(e.out), cout, cin, up, mode, scale, _st())
     elif kind == _KIND_BF16:
         rc = L.ganlab_conv_pack_bf16(_p(e.w), e.out.data_ptr(), cout, cin, mode, scale, _st())
+    elif kind == _KIND_X3:
+        rc = L.ganlab_conv_x3_pack(_p(e.w), e.out.data_ptr(), cout, cin, mode, scale, _st())
     else:
         rc = L.ganlab_conv_pack_f32(_p(e.w), _p(e.out), cout, cin, ks, mode, scale, _st())
     if rc != total:
@@ -263,7 +266,7 @@ def _repack_range(r):
             d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = kind, cout, cin, ks, mode, up, scale, \
                 total, blocks
             # one thread per weight position, all of its taps (csrc/pack.hip pack_many_kernel)
-            blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else ks * ks)) + 255) // 256
+            blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else (27 if kind == _KIND_X3 else ks * ks))) + 255) // 256
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         if tab is not None:
             _PACK_GEN[0] += 1       # the old table's memory goes back to the allocator
@@ -339,6 +342,52 @@ def _packed_bf16(w, mode, scale):
     if rc != n:
         raise _lib.GanlabLibraryError(f'conv_pack_bf16 failed ({rc})')
     return _pack_store(key, w, out, (_KIND_BF16, cout, cin, 3, mode, 0, float(scale), int(n)))
+
+
+# ---- fp32 convolutions as split products on the bf16 matrix cores (csrc/conv_x3.hip) --------------------------------
+# Three bf16 planes per operand, six products per fp32 product, fp32 chains of one 32-channel chunk: as close to float64 as
+# the exact-fp32 MFMA kernels (tools/x3_bench.py: 0.45-0.51 of ATen's rms error against 0.82-1.00) at 1.6-1.9x their speed.
+# On by default for the thick plain 3x3 layers; GANLAB_X3=0 (or set_x3(False)) restores the exact-fp32 kernels everywhere.
+_X3 = [os.environ.get('GANLAB_X3', '1') != '0']
+_X3_MIN_TILES = 128       # (16 x 16 pixels x 64 channels) tiles below which the launch leaves most of the 256 CUs idle
+
+
+def set_x3(enabled):
+    """Switch the split-product kernels on / off (returns the previous setting)."""
+    old = _X3[0]
+    _X3[0] = bool(enabled)
+    return old
+
+
+def x3_enabled():
+    return _X3[0]
+
+
+def x3_ok(g, dgrad=False):
+    """Does this conv (forward, or its input gradient) run on the split-product kernels?"""
+    if not _X3[0] or g.bf is not None or g.s2 or g.up or g.pool or g.ks != 3 or g.pad != 1:
+        return False
+    co = g.Cin if dgrad else g.Cout
+    if g.N * (g.Hin // 16) * (g.Win // 16) * (co // 64) < _X3_MIN_TILES:
+        return False
+    return bool(_lib.lib().ganlab_conv_x3_supported(g.ref(), 1 if dgrad else 0))
+
+
+def _packed_x3(w, mode, scale):
+    key = (w.data_ptr(), w._version, tuple(w.shape), mode, float(scale), 'x3')
+    hit = _pack_lookup(key)
+    if hit is not None:
+        return hit
+    cout, cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    n = L.ganlab_conv_x3_pack(None, None, cout, cin, mode, scale, None)
+    if n <= 0:
+        raise _lib.GanlabLibraryError(f'conv_x3_pack size query failed ({n}) for weight {tuple(w.shape)}')
+    out = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    rc = L.ganlab_conv_x3_pack(_p(w), out.data_ptr(), cout, cin, mode, scale, _st())
+    if rc != n:
+        raise _lib.GanlabLibraryError(f'conv_x3_pack failed ({rc})')
+    return _pack_store(key, w, out, (_KIND_X3, cout, cin, 3, mode, 0, float(scale), int(n)))
 
 
 # ---- "input gradient only" mode ---------------------------------------------------------------------
@@ -534,8 +583,12 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         if bias is not None or act != ACT_NONE:
             y = k_bias_act(y, bias, None, None, bias_scale, act, slope)
         return y
-    wp = _packed(w, PACK_FWD, scale)
     L = _lib.lib()
+    if x3_ok(g):
+        check(L.ganlab_conv_fwd_x3(_p(x), _packed_x3(w, PACK_FWD, scale).data_ptr(), _p(bias), _p(y), g.ref(), bias_scale, act,
+                                   slope, _st()), 'conv_fwd_x3')
+        return y
+    wp = _packed(w, PACK_FWD, scale)
     split = 0 if g.up else L.ganlab_conv_splitk_plan(g.ref(), 0)
     if split >= 2:     # few output tiles, long contraction (512-channel 4x4 / 8x8 maps, small-batch linears)
         ws = torch.empty((split,) + tuple(y.shape), dtype=torch.float32, device=x.device)
@@ -574,6 +627,11 @@ def k_conv_dgrad(gy, w, g, scale):
         gx = _new(g.in_shape, gy)
         check(_lib.lib().ganlab_conv_s2_dgrad_f32(_p(gy), _p(wp), _p(gx), g.ref(), _st()), 'conv_s2_dgrad')
         return gx
+    if x3_ok(g, True):
+        gx = _new(g.in_shape, gy)
+        check(_lib.lib().ganlab_conv_dgrad_x3(_p(gy), _packed_x3(w, PACK_DGRAD, scale).data_ptr(), _p(gx), g.ref(), _st()),
+              'conv_dgrad_x3')
+        return gx
     wp = _packed(w, PACK_DGRAD, scale)
     hv, wv = (2 * g.Hin, 2 * g.Win) if g.up else (g.Hin, g.Win)
     gxv = _new((g.N, g.Cin, hv, wv), gy)
@@ -599,6 +657,10 @@ def k_conv_dgrad_mask(gy, w, x, g, scale, slope):
     assert tuple(gy.shape) == g.out_shape and tuple(x.shape) == g.in_shape
     _note('dgrad', g)
     gx = torch.empty_like(x)
+    if x3_ok(g, True):
+        check(_lib.lib().ganlab_conv_dgrad_mask_x3(_p(gy), _packed_x3(w, PACK_DGRAD, scale).data_ptr(), _p(x), _p(gx), g.ref(),
+                                                   slope, _st()), 'conv_dgrad_mask_x3')
+        return gx
     check(_lib.lib().ganlab_conv_dgrad_mask_f32(_p(gy), _p(_packed(w, PACK_DGRAD, scale)), _p(x), _p(gx), g.ref(), slope,
                                                 _st()), 'conv_dgrad_mask')
     return gx
@@ -2176,6 +2238,9 @@ def k_conv_fwd_aff(a, s_, t_, w, g, scale):
         wp = _packed(w, PACK_FWD, scale, s2_up=1)
         check(L.ganlab_conv_s2_fwd_aff_f32(_p(a), _p(wp), _p(s_), _p(t_), None, _p(y), g.ref(), 1.0, ACT_NONE, 0.2, _st()),
               'conv_s2_fwd_aff')
+    elif x3_ok(g):
+        check(L.ganlab_conv_fwd_aff_x3(_p(a), _packed_x3(w, PACK_FWD, scale).data_ptr(), _p(s_), _p(t_), None, _p(y), g.ref(), 1.0,
+                                       ACT_NONE, 0.2, _st()), 'conv_fwd_aff_x3')
     else:
         wp = _packed(w, PACK_FWD, scale)
         check(L.ganlab_conv_fwd_aff_f32(_p(a), _p(wp), _p(s_), _p(t_), None, _p(y), g.ref(), 1.0, ACT_NONE, 0.2, _st()),
@@ -2249,11 +2314,22 @@ class _ConvModTail(Function):
         ctx.link = link
         g = Geom(n, cin, h, wd, cout, 3, 1, 0)
         _note('fwd', g)
-        wp = _packed(w, PACK_FWD, scale)
         noise = _c(noise) if noise is not None else None
         y = _new((n, cout, h, wd), a_in)
         mean, rstd = _new((n, cout), a_in), _new((n, cout), a_in)
-        if mod_conv_shape_ok(a_in.shape, w):       # thin layer: the rolling-window kernel
+        thin = mod_conv_shape_ok(a_in.shape, w)
+        if not thin and x3_ok(g):                  # thick layer on the split-product kernel, same one-pass form
+            chunks = L.ganlab_conv_fwd_aff_tail_x3_chunks(g.ref())
+            ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
+            check(L.ganlab_conv_fwd_aff_tail_x3(_p(a_in), _packed_x3(w, PACK_FWD, scale).data_ptr(), _p(s_in), _p(t_in), _p(bias),
+                                                _p(noise), _p(noise_w), _p(y), _p(mean), _p(rstd), g.ref(), bias_scale, act, slope,
+                                                eps, _p(ws), ws.numel() * 8, _st()), 'conv_fwd_aff_tail_x3')
+            wp = None
+        else:
+            wp = _packed(w, PACK_FWD, scale)
+        if wp is None:
+            pass
+        elif thin:                                 # thin layer: the rolling-window kernel
             chunks = L.ganlab_mod_conv_stat_chunks(g.ref())
             ws = torch.empty((n * cout * chunks * 2,), dtype=torch.float64, device=a_in.device)
             check(L.ganlab_mod_conv_fwd_f32(_p(a_in), _p(wp), _p(s_in), _p(t_in), _p(bias), _p(noise), _p(noise_w), _p(y),

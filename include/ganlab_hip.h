@@ -192,6 +192,17 @@ long long ganlab_conv_x3_pack(const float* w, void* out, int Cout, int Cin, int 
 int ganlab_conv_fwd_x3(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
                        float bias_scale, int act, float slope, void* stream);
 int ganlab_conv_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+/* the forms of the exact-fp32 entry points the thick layers use, same arguments except the packed weights:
+ * ganlab_conv_dgrad_mask_f32, ganlab_conv_fwd_aff_f32, ganlab_conv_fwd_aff_tail_f32 (+ its tiles-per-plane query) */
+int ganlab_conv_dgrad_mask_x3(const float* gy, const void* wp, const float* x, float* gx, const ganlab_conv_geom* g,
+                              float slope, void* stream);
+int ganlab_conv_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
+                           float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_fwd_aff_tail_x3_chunks(const ganlab_conv_geom* g);
+int ganlab_conv_fwd_aff_tail_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
+                                const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
+                                const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ---- depthwise / resampling (custom_layers.py:36-53; nn.Upsample / nn.AvgPool2d call sites) ---- */
 /* y = depthwise [1 2 1]x[1 2 1]/16 blur, zero padding (self-adjoint: also its own backward). */
@@ -513,9 +524,10 @@ int ganlab_conv_wgrad_act_bits_f32(const float* gy, const unsigned* ybits, const
 #define GANLAB_PACKKIND_PLAIN 0
 #define GANLAB_PACKKIND_S2 1
 #define GANLAB_PACKKIND_BF16 2
+#define GANLAB_PACKKIND_X3 3     /* three-plane bf16 k-step images of csrc/conv_x3.hip (27*Cout*Cin bf16 elements) */
 typedef struct ganlab_pack_desc {
   const float* src;      /* OIHW parameter */
-  void* dst;             /* packed buffer of `total` elements (float, or bf16 for GANLAB_PACKKIND_BF16) */
+  void* dst;             /* packed buffer of `total` elements (float, or bf16 for GANLAB_PACKKIND_BF16 / _X3) */
   int kind;              /* GANLAB_PACKKIND_* */
   int Cout, Cin, ks;
   int mode;              /* PLAIN / BF16: GANLAB_PACK_FWD or _DGRAD; S2: transpose flag */

@@ -1,0 +1,209 @@
+"""Split-product (3 x bf16) conv kernels (csrc/conv_x3.hip) through the C-ABI: every form against float64 on the CPU and
+against the exact-fp32 MFMA kernels of the same entry points, at the accuracy bar of the fp32 kernels (TOL of test_gpu_ops).
+The reference computes F.conv2d in fp32 (utils/custom_layers.py:202-211); the bar that the split products are 'fp32' is the
+rms distance to float64, which must not exceed ATen's own (tools/x3_bench.py; here: <= 1.1 x the exact kernels')."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from gan_lab_amd import ops as _ops, _lib
+    _lib.lib()
+    return _ops
+
+
+def rms_rel(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def launched(ops):
+    from gan_lab_amd import _lib
+    return _lib.last_launch()[0] or ''
+
+
+# N, Cin, Cout, H, W: multi-tile per workgroup (more tiles than CUs), one / two / eight 64-channel double chunks, 2+ co tiles,
+# non-square, the ring wrapping across tiles with an odd number of stages per tile (64 channels)
+X3_CASES = [(2, 64, 64, 16, 16), (3, 128, 192, 32, 16), (2, 256, 128, 16, 48), (1, 512, 64, 16, 16), (5, 64, 128, 64, 64),
+            (9, 128, 64, 32, 32)]
+
+
+@pytest.mark.parametrize('case', X3_CASES)
+def test_x3_forward_and_input_gradient(ops, case):
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(11 + n + ci)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    b = torch.randn(co, generator=g)
+    gy = torch.randn(n, co, h, w, generator=g)
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    scale = 1.0 / (3 * ci ** 0.5)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        assert ops.x3_ok(geom) and ops.x3_ok(geom, True)
+        y3 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+        assert 'conv_x3_fwd_kernel' in launched(ops)
+        gx3 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+        assert 'conv_x3_fwd_kernel' in launched(ops)
+        prev = ops.set_x3(False)
+        try:
+            y1 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+            assert 'conv_x3_fwd_kernel' not in launched(ops)
+            gx1 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+        finally:
+            ops.set_x3(prev)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    yd = F.leaky_relu(F.conv2d(x.double(), wt.double() * scale, None, padding=1) + 0.5 * b.double().view(1, -1, 1, 1), 0.2)
+    xd = x.double().requires_grad_(True)
+    gxd, = torch.autograd.grad(F.conv2d(xd, wt.double() * scale, padding=1), xd, gy.double())
+    assert_close(y3.cpu(), yd, TOL, 'x3 forward vs float64')
+    assert_close(gx3.cpu(), gxd, TOL, 'x3 input gradient vs float64')
+    assert_close(y3.cpu(), y1.cpu(), TOL, 'x3 forward vs exact-fp32 kernel')
+    assert_close(gx3.cpu(), gx1.cpu(), TOL, 'x3 input gradient vs exact-fp32 kernel')
+    # "fp32" means: no further from float64 than the exact-fp32 kernels (rms over the tensor)
+    assert rms_rel(y3, yd) <= 1.1 * rms_rel(y1, yd), (rms_rel(y3, yd), rms_rel(y1, yd))
+    assert rms_rel(gx3, gxd) <= 1.1 * rms_rel(gx1, gxd), (rms_rel(gx3, gxd), rms_rel(gx1, gxd))
+
+
+def test_x3_masked_input_gradient(ops):
+    n, ci, co, h, w = 3, 128, 64, 32, 32
+    g = torch.Generator().manual_seed(5)
+    x = F.leaky_relu(torch.randn(n, ci, h, w, generator=g), 0.2)       # the conv's input: a LeakyReLU output
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    gy = torch.randn(n, co, h, w, generator=g)
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        gx3 = ops.k_conv_dgrad_mask(gy.cuda(), wt.cuda(), x.cuda(), geom, 0.03, 0.2)
+        assert 'conv_x3_fwd_kernel' in launched(ops)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    xd = torch.zeros(n, ci, h, w, dtype=torch.float64, requires_grad=True)
+    gxd, = torch.autograd.grad(F.conv2d(xd, wt.double() * 0.03, padding=1), xd, gy.double())
+    gxd = gxd * torch.where(x > 0, 1.0, 0.2).double()
+    assert_close(gx3.cpu(), gxd, TOL, 'x3 masked input gradient vs float64')
+
+
+@pytest.mark.parametrize('noise', [True, False])
+def test_x3_affine_on_load_and_tail(ops, noise):
+    from gan_lab_amd import _lib
+    n, ci, co, h, w = 3, 128, 128, 32, 32
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(n, ci, h, w, generator=g)
+    s_ = torch.rand(n, ci, generator=g) + 0.5
+    t_ = torch.randn(n, ci, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    b = torch.randn(co, generator=g)
+    nz = torch.randn(n, 1, h, w, generator=g) if noise else None
+    nw = torch.randn(co, generator=g) if noise else None
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    scale, eps = 0.02, 1e-8
+    bd = a.double() * s_.double().view(n, ci, 1, 1) + t_.double().view(n, ci, 1, 1)
+    conv = F.conv2d(bd, wt.double() * scale, None, padding=1)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        y = ops.k_conv_fwd_aff(a.cuda(), s_.cuda(), t_.cuda(), wt.cuda(), geom, scale)
+        assert 'conv_x3_fwd_kernel' in launched(ops)
+        assert_close(y.cpu(), conv, TOL, 'x3 affine-on-load forward vs float64')
+        # the whole layer: + noise, bias, LeakyReLU, InstanceNorm statistics
+        L = _lib.lib()
+        chunks = L.ganlab_conv_fwd_aff_tail_x3_chunks(geom.ref())
+        assert chunks == (h // 16) * (w // 16) * 4
+        yt = torch.empty(n, co, h, w, device='cuda')
+        mean, rstd = torch.empty(n, co, device='cuda'), torch.empty(n, co, device='cuda')
+        ws = torch.empty(n * co * chunks * 2, dtype=torch.float64, device='cuda')
+        wp = ops._packed_x3(wt.cuda(), ops.PACK_FWD, scale)
+        p = lambda v: ctypes.c_void_p(v.data_ptr()) if v is not None else None
+        ac, sc, tc, bc = a.cuda(), s_.cuda(), t_.cuda(), b.cuda()
+        nzc, nwc = (nz.cuda(), nw.cuda()) if noise else (None, None)
+        _lib.check(L.ganlab_conv_fwd_aff_tail_x3(p(ac), p(wp), p(sc), p(tc), p(bc), p(nzc), p(nwc), p(yt), p(mean), p(rstd),
+                                                 geom.ref(), 0.7, ops.ACT_LRELU, 0.2, eps, p(ws), ws.numel() * 8, None), 'tail')
+    finally:
+        ops._X3_MIN_TILES = old_min
+    pre = conv + 0.7 * b.double().view(1, -1, 1, 1)
+    if noise:
+        pre = pre + nw.double().view(1, -1, 1, 1) * nz.double()
+    yd = F.leaky_relu(pre, 0.2)
+    assert_close(yt.cpu(), yd, TOL, 'x3 layer tail vs float64')
+    md = yd.mean(dim=(2, 3))
+    rd = 1.0 / torch.sqrt(yd.var(dim=(2, 3), unbiased=False) + eps)
+    assert_close(mean.cpu(), md, TOL, 'x3 layer tail: mean')
+    assert_close(rstd.cpu(), rd, TOL, 'x3 layer tail: rstd')
+
+
+def test_x3_padding_stays_zero_under_the_affine(ops):
+    """b = a*s + t is zero-padded AFTER the affine: a constant shift t must not leak into the border taps."""
+    n, ci, co, h, w = 1, 64, 64, 16, 16
+    a = torch.zeros(n, ci, h, w)
+    s_, t_ = torch.ones(n, ci), torch.ones(n, ci)
+    wt = torch.ones(co, ci, 3, 3)
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        y = ops.k_conv_fwd_aff(a.cuda(), s_.cuda(), t_.cuda(), wt.cuda(), geom, 1.0).cpu()
+    finally:
+        ops._X3_MIN_TILES = old_min
+    assert y[0, 0, 8, 8].item() == 9 * ci and y[0, 0, 0, 0].item() == 4 * ci and y[0, 0, 0, 5].item() == 6 * ci
+
+
+def test_x3_batched_repack_equals_single_pack(ops):
+    """ganlab_pack_many's X3 kind writes the bits ganlab_conv_x3_pack writes (both call gl_x3_pack_position)."""
+    from gan_lab_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(128, 64, 3, 3, generator=g).cuda(), torch.randn(64, 192, 3, 3, generator=g).cuda()]
+    singles, outs = [], []
+    arr = (_lib.PackDesc * 4)()
+    blocks, i = 0, 0
+    for wt in ws:
+        for mode in (ops.PACK_FWD, ops.PACK_DGRAD):
+            co, ci = wt.shape[0], wt.shape[1]
+            n = L.ganlab_conv_x3_pack(None, None, co, ci, mode, 0.37, None)
+            assert n == 27 * co * ci
+            one = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+            assert L.ganlab_conv_x3_pack(wt.data_ptr(), one.data_ptr(), co, ci, mode, 0.37, None) == n
+            singles.append(one)
+            out = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+            outs.append(out)
+            d = arr[i]
+            d.src, d.dst, d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = \
+                wt.data_ptr(), out.data_ptr(), 3, co, ci, 3, mode, 0, 0.37, n, blocks
+            blocks += (co * ci + 255) // 256
+            i += 1
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    _lib.check(L.ganlab_pack_many(tab.data_ptr(), 4, blocks, None), 'pack_many')
+    torch.cuda.synchronize()
+    for one, out in zip(singles, outs):
+        assert torch.equal(one.view(torch.int16), out.view(torch.int16))
+    # the three planes sum to the scaled weight exactly: h + m + l == fl(w * scale)
+    wt = ws[0]
+    pk = singles[0].float().view(2, 18, 3, 4, 64, 8)     # [co tile][k-step][plane][k-group][co][8]
+    total = pk.sum(dim=2)                                # exact in fp32: three bf16 values within 2^-24 of each other's ulp
+    # k-step 0 of chunk 0: lane groups 0,1 = tap 0, channels 0..15; groups 2,3 = tap 1
+    ref0 = (wt[:64, :16, 0, 0] * 0.37).t().reshape(2, 8, 64).permute(0, 2, 1)       # [g][co][j]
+    assert torch.equal(total[0, 0, 0:2], ref0)
+    ref1 = (wt[:64, :16, 0, 1] * 0.37).t().reshape(2, 8, 64).permute(0, 2, 1)
+    assert torch.equal(total[0, 0, 2:4], ref1)
+
+
+def test_x3_switch_restores_exact_path(ops):
+    geom = ops.Geom(32, 256, 64, 64, 256, 3, 1)
+    assert ops.x3_ok(geom) and ops.x3_ok(geom, True)
+    prev = ops.set_x3(False)
+    try:
+        assert not ops.x3_ok(geom)
+    finally:
+        ops.set_x3(prev)
+    assert not ops.x3_ok(ops.Geom(32, 32, 512, 512, 32, 3, 1))          # thin layers stay on the exact kernels
+    assert not ops.x3_ok(ops.Geom(1, 512, 16, 16, 512, 3, 1))           # a launch that would leave the chip idle does too
