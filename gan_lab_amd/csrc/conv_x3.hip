@@ -365,25 +365,34 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
         nwv[nn] = 0.f;
         if constexpr (TAIL) nwv[nn] = q.noise != nullptr ? q.noise_w[co] : 0.f;
       }
+      // every load of the epilogue in flight before the first use (one round trip, not one per tile row)
+      float4 nzs[TAIL ? 4 : 1];
+      f32x4 mks[MASK ? 4 : 1][MASK ? 2 : 1];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int px = (cur.oy0 + 4 * wm + m) * p.W + cur.ox0 + 4 * kg;
-        float4 nz = float4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (TAIL) { if (q.noise != nullptr) nz = *reinterpret_cast<const float4*>(q.noise + (long long)cur.n * plane + px); }
+        if constexpr (TAIL) nzs[m] = q.noise != nullptr ? *reinterpret_cast<const float4*>(q.noise + (long long)cur.n * plane + px) : float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MASK) {
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+            mks[m][nn] = *reinterpret_cast<const f32x4*>(q.mask + ib + (long long)(cur.co_t * X3_NT + wn * 32 + nn * 16 + l16) * plane + px);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int px = (cur.oy0 + 4 * wm + m) * p.W + cur.ox0 + 4 * kg;
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
           const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
           const long long o = ib + (long long)co * plane + px;
-          f32x4 mk;
-          if constexpr (MASK) mk = *reinterpret_cast<const f32x4*>(q.mask + o);
           f32x4 v = accT[m][nn] + accS[m][nn];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float f;
-            if constexpr (TAIL) f = fmaf(r == 0 ? nz.x : r == 1 ? nz.y : r == 2 ? nz.z : nz.w, nwv[nn], v[r] + bv[nn]);
+            if constexpr (TAIL) f = fmaf(r == 0 ? nzs[m].x : r == 1 ? nzs[m].y : r == 2 ? nzs[m].z : nzs[m].w, nwv[nn], v[r] + bv[nn]);
             else f = v[r] + bv[nn];
             if (q.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, q.slope);
-            if constexpr (MASK) { if (!(mk[r] > 0.f)) f *= q.mslope; }
+            if constexpr (MASK) { if (!(mks[m][nn][r] > 0.f)) f *= q.mslope; }
             v[r] = f;
           }
           *reinterpret_cast<f32x4*>(q.y + o) = v;
@@ -394,7 +403,6 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
           accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
           accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (TAIL) {      // this wave's 64 pixels of each channel: fp64 from the lane sums on, one partial per wave row
         const long long chunks = (long long)p.tiles_x * p.tiles_y * 4, tl = ((long long)(cur.oy0 >> 4) * p.tiles_x + (cur.ox0 >> 4)) * 4 + wm;

@@ -69,7 +69,7 @@ def errors():
         print(f'dgrad {ci:3d}->{co:3d} {hw}x{hw}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 {e3:.3e} ({e3 / ec:.2f})', flush=True)
 
 
-def times(batch, rounds, reps):
+def times(batch, rounds, reps, forms=False):
     for ci, co, hw in LAYERS:
         x = torch.randn(batch, ci, hw, hw, device='cuda')
         w = torch.randn(co, ci, 3, 3, device='cuda')
@@ -77,7 +77,26 @@ def times(batch, rounds, reps):
         wp3 = pack_x3(w, 0, 0.05)
         fl = ops.conv_flops(g)
         fns = {'fp32': lambda: ops.k_conv_fwd(x, w, None, g, 0.05), 'x3': lambda: fwd_x3(x, wp3, None, g)}
-        d = (fns['fp32']() - fns['x3']()).abs().max().item()
+        if forms and not ops.conv_tail_shape_ok(x.shape, w):
+            continue
+        if forms:
+            def sw(fn, on):
+                def f():
+                    prev = ops.set_x3(on)
+                    try:
+                        return fn()
+                    finally:
+                        ops.set_x3(prev)
+                return f
+            gy = torch.randn(*g.out_shape, device='cuda')
+            s_, t_ = torch.rand(batch, ci, device='cuda') + 0.5, torch.randn(batch, ci, device='cuda')
+            mask = lambda: ops.k_conv_dgrad_mask(gy, w, x, g, 0.05, 0.2)
+            aff = lambda: ops.k_conv_fwd_aff(x, s_, t_, w, g, 0.05)
+            bias, nz, nw = torch.randn(co, device='cuda'), torch.randn(batch, 1, hw, hw, device='cuda'), torch.randn(co, device='cuda')
+            tail = lambda: ops._ConvModTail.apply(x, s_, t_, w, bias, nz, nw, None, 0.05, 1.0, ops.ACT_LRELU, 0.2, 1e-8)
+            fns = {'fp32': sw(mask, False), 'x3': sw(mask, True), 'aff fp32': sw(aff, False), 'aff x3': sw(aff, True),
+                   'tail fp32': sw(tail, False), 'tail x3': sw(tail, True)}
+        d = 0.0 if forms else (fns['fp32']() - fns['x3']()).abs().max().item()
         ms = {k: [] for k in fns}
         for k in fns:
             for _ in range(5):
@@ -93,6 +112,11 @@ def times(batch, rounds, reps):
                 torch.cuda.synchronize()
                 ms[k].append(e0.elapsed_time(e1) / reps)
         med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+        if forms:
+            print(f'{ci:3d}->{co:3d} @{hw:3d} x{batch}: masked dgrad {med["fp32"]:.3f} -> {med["x3"]:.3f} ms ({med["fp32"] / med["x3"]:.2f}x) | affine fwd '
+                  f'{med["aff fp32"]:.3f} -> {med["aff x3"]:.3f} ({med["aff fp32"] / med["aff x3"]:.2f}x) | layer tail {med["tail fp32"]:.3f} -> '
+                  f'{med["tail x3"]:.3f} ({med["tail fp32"] / med["tail x3"]:.2f}x)', flush=True)
+            continue
         print(f'{ci:3d}->{co:3d} @{hw:3d} x{batch}: fp32 MFMA {med["fp32"]:.3f} ms ({fl / med["fp32"] / 1e9:6.1f} TF/s)  3xbf16 {med["x3"]:.3f} ms '
               f'({fl / med["x3"] / 1e9:6.1f} TF/s fp32-equivalent, {6 * fl / med["x3"] / 1e9:7.1f} bf16)  speed-up {med["fp32"] / med["x3"]:.2f}x  '
               f'max |diff| {d:.2e}', flush=True)
@@ -106,8 +130,11 @@ if __name__ == '__main__':
     p.add_argument('--reps', type=int, default=10)
     p.add_argument('--err-only', action='store_true')
     p.add_argument('--time-only', action='store_true')
+    p.add_argument('--forms', action='store_true', help='time the masked / affine / layer-tail forms through ops')
     a = p.parse_args()
     if not a.time_only:
         errors()
     if not a.err_only:
         times(a.batch, a.rounds, a.reps)
+        if a.forms:
+            times(a.batch, a.rounds, a.reps, True)
