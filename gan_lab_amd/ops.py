@@ -1997,6 +1997,10 @@ class Deferred(object):
             self.link.readers += 1
         return self
 
+    @property
+    def shape(self):
+        return self.a.shape
+
 
 class RgbGradLink(object):
     """Link between a generator layer's tail (the producer of a ``Deferred``) and toRGB where toRGB is its ONLY reader (the
@@ -2015,10 +2019,6 @@ def _rgb_link_ok(link, n, c, crgb, hw):
     return link is not None and link.readers == 1 and get_compute_dtype() == 'f32' and \
         os.environ.get('GANLAB_TORGB_FOLD') != '0' and \
         bool(_lib.lib().ganlab_instnorm_bwd_rgb_supported(n, c, crgb, hw))
-
-    @property
-    def shape(self):
-        return self.a.shape
 
 
 def _affine_from_stats(mean, rstd, style, n, c):
@@ -2479,12 +2479,14 @@ class _ToRGBMod(Function):
         L = _lib.lib()
         g = Geom(n, cin, h, wd, cout, 1, 0, 0)
         ga = None
+        if ctx.link is not None:                         # a link left armed by a backward whose tail never ran is disarmed here
+            ctx.link.grgb = ctx.link.wp = None
         if ctx.needs_input_grad[0]:                      # d/d(a*s + t)
             link = ctx.link
             if _rgb_link_ok(link, n, cin, cout, h * wd):
                 # the producer's InstanceNorm backward recomputes it from gy (RgbGradLink); the engine only needs the shape
                 link.grgb, link.wp, link.crgb = gy, _packed(w, PACK_DGRAD, ctx.scale), cout
-                ga = torch.empty((1,), dtype=a.dtype, device=a.device).expand(a.shape)
+                ga = torch.zeros((1,), dtype=a.dtype, device=a.device).expand(a.shape)      # (a 4-byte memset: never garbage)
             else:
                 ga = k_conv_dgrad(gy, w, g, ctx.scale)
         gw = gb = None

@@ -227,13 +227,6 @@ class LayerNorm(nn.LayerNorm):
         return ops.layer_norm(x, self.weight, self.bias, eps=self.eps, act_slope=act_slope)
 
 
-class Tanh(nn.Module):
-    """nn.Tanh stand-in (ResNet generators' output nonlinearity)."""
-
-    def forward(self, x):
-        return ops.tanh(x)
-
-
 class NormalizeLayer(nn.Module):
     """All normalisation methods in one place (custom_layers.py:88-111)."""
 

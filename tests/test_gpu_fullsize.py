@@ -151,8 +151,6 @@ def _grad_errors(hip, ref, floor_frac=1e-3):
 
 
 MAX_TIE_CHANNELS = 2
-# generator entries of the learner-path case, judged as a set (see the test): median e_hip / e_cpu and worst e_hip
-G_MEDIAN_BAR, G_WORST_BAR = 2.0, 1e-2
 
 
 def _without_tie_channels(k, hip, ex, scale):
@@ -267,6 +265,11 @@ def test_full_width_step_vs_oracle(kind, res, b, loss, gp, capsys):
     rep['n_entries'] = (len(ed), len(eg))
     with capsys.disabled():
         print(f'\n{kind}-{res} b{b} {loss}+{gp} full width, HIP vs oracle:', rep)
+        print('SUMMARY %s-%d-b%d %s+%s: img %.1e d_real %.1e gp %.1e loss_d %.1e loss_g %.1e | worst d %.1e g %.1e (vs fp32 oracle) | '
+              'entries > 1e-3: d %d g %d, beyond strict rule %d | ties %d' % (
+                  kind, res, b, loss, gp, rep['img'], rep['d_real'], rep['gp'], rep['loss_d'], rep['loss_g'], rep['worst_d_grad'][1],
+                  rep['worst_g_grad'][1], sum(v > 1e-3 for v in ed.values()), sum(v > 1e-3 for v in eg.values()), len(still),
+                  len(rep.get('lrelu_tie_channels', {}))))
     for k in ('img', 'd_real', 'd_fake', 'gp', 'loss_d', 'loss_g'):
         assert rep[k] <= TOL, (k, rep)
     assert not still, still
@@ -304,6 +307,8 @@ def test_stylegan128_bf16_b8_step_vs_oracle(capsys):
     rep['worst_grad_cosine'] = worst
     with capsys.disabled():
         print('\nbf16 StyleGAN-128 b8 step vs fp32 oracle:', rep)
+        print('SUMMARY bf16 stylegan-128-b8 (own bar 2e-2 / cosine 0.98): img %.1e gp %.1e loss_d %.1e loss_g %.1e | worst gradient '
+              'cosine %.4f (%s)' % (rep['img'], rep['gp'], rep['loss_d'], rep['loss_g'], worst[0], worst[1]))
     assert rep['img'] < 2e-2 and rep['loss_d'] < 1e-2 and rep['loss_g'] < 1e-2 and rep['gp'] < 2e-2, rep
     assert worst[0] > 0.98, rep
 
@@ -499,19 +504,17 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
     if bad_g:
         # Every generator gradient of the G step is J_G^T applied to ONE vector, the critic's input gradient
         # d loss / d image: all ~80 generator entries inherit ONE realisation of its rounding error, on the CPU fp32 path
-        # exactly as on the HIP path, so the generator entries are judged as a set: the strict per-entry rule where it
-        # holds, otherwise the common factor - median e_hip / e_cpu, both against float64 - within G_MEDIAN_BAR and no
-        # entry further than G_WORST_BAR from float64.  (Round 3: 5 and 3e-2, while the thick conv kernels carried ONE
-        # fmaf chain per output and rounded 2-2.5x worse than ATen; the chains are split now - tools/op_error_probe.py.)
+        # exactly as on the HIP path.  Judged per entry like the critic's: e_hip <= max(TOL, 1.5 e_cpu), both against
+        # float64 (the set rule of rounds 3 / 4 - median ratio and worst entry as a fallback - is gone: no entry needs it);
+        # the common-mode numbers are reported only.
         s_, j, ties = _judge_outliers('g.', bad_g, gg, cpu['gg'], ex['gg'],
                                       max(v.abs().max().item() for v in ex['gg'].values()))
+        still.update(s_)
         rep.setdefault('lrelu_tie_channels', {}).update(ties)
         rep['judged_g'] = {k: ('%.2e' % a, '%.2e' % c) for k, (a, c) in j.items()}
         ratios = sorted(a / max(c, 1e-30) for a, c in j.values())
         rep['g_common_mode'] = dict(median_ratio=round(ratios[len(ratios) // 2], 2), worst_e_hip='%.2e' % max(
             a for a, _ in j.values()), entries_beyond_strict_rule=len(s_), entries=len(j))
-        if s_ and not (ratios[len(ratios) // 2] <= G_MEDIAN_BAR and max(a for a, _ in j.values()) <= G_WORST_BAR):
-            still.update(s_)
     # Adam (beta1 = 0, first step): every element moves by lr * g / (|g| + eps).  Two checks.  (i) The optimiser's own
     # arithmetic: the update the fused kernel made against that formula evaluated in float64 on the gradient IT was given
     # (the arena's) - every element of every parameter, to 1e-3 of the step size plus the parameter's own fp32 spacing.
@@ -551,6 +554,14 @@ def test_learner_step_full_width_vs_oracle(res, b, capsys, tmp_path):
                           oracle_f64=round(ex['seconds'], 1), threads=threads)
     with capsys.disabled():
         print(f'\nlearner d_step + g_step, StyleGAN-{res} b{b} full width, vs FunctionalGAN:', rep)
+        cm = rep.get('g_common_mode', {})
+        # one line the driver's tail keeps (<= 400 bytes)
+        print(('SUMMARY learner-%d-b%d: loss_d %.1e loss_g %.1e | worst d %.1e g %.1e (vs fp32 oracle) | entries > 1e-3: d %d g %d, '
+               'beyond strict rule %d | g median e_hip/e_cpu %s worst e_hip %s | ties %d | census %s | adam %.2f ewma %.0e')
+              % (res, b, rep['loss_d'], rep['loss_g'], rep['worst_d_grad'][1], rep['worst_g_grad'][1],
+                 sum(v > 1e-3 for v in ed.values()), sum(v > 1e-3 for v in eg.values()), len(still),
+                 cm.get('median_ratio', '-'), cm.get('worst_e_hip', '-'), len(rep.get('lrelu_tie_channels', {})),
+                 'ok' if all(n > 0 for n in ran.values()) else 'MISSING', worst_arith[0], worst_lag[0]))
     assert all(n > 0 for n in ran.values()), ran
     assert taken[0] >= 0.6 * n_params, rep['direct_gradients']
     assert rep['loss_d'] <= TOL and rep['loss_g'] <= TOL, rep

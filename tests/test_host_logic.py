@@ -495,3 +495,19 @@ def test_step_graphs_own_what_they_captured(monkeypatch):
     assert sg._common_signature(torch.zeros(4, 3, 8, 8)) != sig1
     ops.bump_weight_epoch([(0, 16)])                                     # an optimiser step: nothing dropped
     assert ops.pack_generation() == gen0 + 1
+
+
+def test_deferred_exposes_the_shape_of_its_tensor():
+    """``Deferred.shape`` had slipped out of the class (an edit left it as dead code under a function)."""
+    import torch
+    from gan_lab_amd import ops
+    a = torch.zeros(2, 3, 4, 5)
+    d = ops.Deferred(a, None, None, None, None, None)
+    assert d.shape == a.shape and d.read() is d
+
+
+def test_custom_layers_define_tanh_once():
+    import inspect
+    from gan_lab_amd.utils import custom_layers
+    src = inspect.getsource(custom_layers)
+    assert src.count('class Tanh(') == 1
