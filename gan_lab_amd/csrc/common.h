@@ -138,6 +138,44 @@ __device__ __forceinline__ void gl_x3_pack_position(const float* __restrict__ w9
   }
 }
 
+// the transposed 4x4 stride-2 form of conv_x3.hip (layout and tap sets: see conv_x3_up_kernel there)
+__device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__ w9, int up, float scale, __bf16* __restrict__ out,
+                                                    int CI, int ci, int co) {
+  const int nst = CI / 16;
+  const int ct = co >> 6, col = co & 63, half = ci >> 4, g = (ci >> 3) & 1, j = ci & 7;
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          float v = 0.f;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int ry = up ? ky : 2 - ky, rx = up ? kx : 2 - kx;       // position in the up-forward row / column sets
+              const bool iny = py == 0 ? (ty == 0 ? ry == 0 : ry >= 1) : (ty == 0 ? ry <= 1 : ry == 2);
+              const bool inx = px == 0 ? (tx == 0 ? rx == 0 : rx >= 1) : (tx == 0 ? rx <= 1 : rx == 2);
+              if (iny && inx) v += w9[ky * 3 + kx];
+            }
+          v = v * (up ? scale : 0.25f * scale);
+          asm volatile("" : "+v"(v));
+          const __bf16 h = (__bf16)v;
+          const float r1 = v - (float)h;
+          const __bf16 mm = (__bf16)r1;
+          const __bf16 l = (__bf16)(r1 - (float)mm);
+          const int kgq = tx * 2 + g;
+          __bf16* base = out + ((((long long)(ct * 2 + py) * 2 + px) * nst + half) * 2 + ty) * (3 * 4 * 64) * 8;
+          base[((0 * 4 + kgq) * 64 + col) * 8 + j] = h;
+          base[((1 * 4 + kgq) * 64 + col) * 8 + j] = mm;
+          base[((2 * 4 + kgq) * 64 + col) * 8 + j] = l;
+        }
+}
+
+
 // ---- conv.hip: mean / rstd of every (n, c) plane from per-tile sums of y and y^2 (fixed order, fp64) ---------------------------
 extern "C" int gl_tail_stats_finish(const double* spart, float* mean, float* rstd, long long planes, int chunks, double inv_hw, float eps,
                          hipStream_t st);

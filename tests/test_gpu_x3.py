@@ -207,3 +207,100 @@ def test_x3_switch_restores_exact_path(ops):
         ops.set_x3(prev)
     assert not ops.x3_ok(ops.Geom(32, 32, 512, 512, 32, 3, 1))          # thin layers stay on the exact kernels
     assert not ops.x3_ok(ops.Geom(1, 512, 16, 16, 512, 3, 1))           # a launch that would leave the chip idle does too
+
+
+# ---- the transposed stride-2 form: an up layer's forward (+ affine on load), a pooled layer's input gradient -------------------
+S2_CASES = [(2, 64, 64, 16, 16), (3, 128, 64, 32, 16), (2, 256, 128, 16, 32), (5, 64, 128, 32, 32)]     # N, Cin, Cout, Hl, Wl
+
+
+@pytest.mark.parametrize('case', S2_CASES)
+def test_x3_up_layer_forward(ops, case):
+    n, ci, co, hl, wl = case
+    g = torch.Generator().manual_seed(21 + ci + n)
+    x = torch.randn(n, ci, hl, wl, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    b = torch.randn(co, generator=g)
+    s_ = torch.rand(n, ci, generator=g) + 0.5
+    t_ = torch.randn(n, ci, generator=g)
+    geom = ops.Geom(n, ci, hl, wl, co, 3, 1, up=1)
+    scale = 1.0 / (3 * ci ** 0.5)
+    assert geom.s2
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        assert ops.x3_s2_ok(geom)
+        y3 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+        assert 'conv_x3_up_kernel' in launched(ops)
+        ya = ops.k_conv_fwd_aff(x.cuda(), s_.cuda(), t_.cuda(), wt.cuda(), geom, scale)
+        assert 'conv_x3_up_kernel' in launched(ops)
+        prev = ops.set_x3(False)
+        try:
+            y1 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+            assert 'conv_x3_up_kernel' not in launched(ops)
+        finally:
+            ops.set_x3(prev)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    up = F.interpolate(x.double(), scale_factor=2, mode='nearest')
+    yd = F.leaky_relu(F.conv2d(up, wt.double() * scale, None, padding=1) + 0.5 * b.double().view(1, -1, 1, 1), 0.2)
+    bd = x.double() * s_.double().view(n, ci, 1, 1) + t_.double().view(n, ci, 1, 1)
+    yad = F.conv2d(F.interpolate(bd, scale_factor=2, mode='nearest'), wt.double() * scale, None, padding=1)
+    assert_close(y3.cpu(), yd, TOL, 'x3 up layer vs float64')
+    assert_close(y3.cpu(), y1.cpu(), TOL, 'x3 up layer vs exact-fp32 kernel')
+    assert_close(ya.cpu(), yad, TOL, 'x3 up layer, affine on load vs float64')
+    assert rms_rel(y3, yd) <= 1.1 * rms_rel(y1, yd), (rms_rel(y3, yd), rms_rel(y1, yd))
+
+
+@pytest.mark.parametrize('case', S2_CASES)
+def test_x3_pooled_layer_input_gradient(ops, case):
+    n, co_, ci_, hl, wl = case          # the pooled layer: ci_ -> co_ channels, input 2hl x 2wl
+    cin, cout = ci_, co_
+    g = torch.Generator().manual_seed(31 + cin + n)
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    gy = torch.randn(n, cout, hl, wl, generator=g)
+    geom = ops.Geom(n, cin, 2 * hl, 2 * wl, cout, 3, 1, pool=1)
+    scale = 1.0 / (3 * cin ** 0.5)
+    assert geom.s2
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        assert ops.x3_s2_ok(geom, True)
+        gx3 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+        assert 'conv_x3_up_kernel' in launched(ops)
+        prev = ops.set_x3(False)
+        try:
+            gx1 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+            assert 'conv_x3_up_kernel' not in launched(ops)
+        finally:
+            ops.set_x3(prev)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    xd = torch.zeros(n, cin, 2 * hl, 2 * wl, dtype=torch.float64, requires_grad=True)
+    gxd, = torch.autograd.grad(F.avg_pool2d(F.conv2d(xd, wt.double() * scale, padding=1), 2), xd, gy.double())
+    assert_close(gx3.cpu(), gxd, TOL, 'x3 pooled layer input gradient vs float64')
+    assert_close(gx3.cpu(), gx1.cpu(), TOL, 'x3 pooled layer input gradient vs exact-fp32 kernel')
+    assert rms_rel(gx3, gxd) <= 1.1 * rms_rel(gx1, gxd), (rms_rel(gx3, gxd), rms_rel(gx1, gxd))
+
+
+def test_x3_s2_batched_repack_equals_single_pack(ops):
+    from gan_lab_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    wt = torch.randn(128, 64, 3, 3, generator=g).cuda()
+    arr = (_lib.PackDesc * 2)()
+    singles, outs, blocks = [], [], 0
+    for i, up in enumerate((1, 0)):
+        n = L.ganlab_conv_s2_x3_pack(None, None, 128, 64, up, 0.41, None)
+        assert n == 48 * 128 * 64
+        one = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+        assert L.ganlab_conv_s2_x3_pack(wt.data_ptr(), one.data_ptr(), 128, 64, up, 0.41, None) == n
+        out = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+        singles.append(one)
+        outs.append(out)
+        d = arr[i]
+        d.src, d.dst, d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = \
+            wt.data_ptr(), out.data_ptr(), 3, 128, 64, 4, 0, up, 0.41, n, blocks
+        blocks += (128 * 64 + 255) // 256
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    _lib.check(L.ganlab_pack_many(tab.data_ptr(), 2, blocks, None), 'pack_many')
+    torch.cuda.synchronize()
+    for one, out in zip(singles, outs):
+        assert torch.equal(one.view(torch.int16), out.view(torch.int16))
