@@ -24,6 +24,14 @@
 // Staging is register-staged (buffer loads -> split -> ds_write), loads issued one to two stages ahead of their ds_write.
 #include "common.h"
 
+#include <type_traits>
+
+// Ablation builds (make VARIANT=.. DEFS=-DX3_EXP=n; wrong results, timing only): bit 0 no activation split / LDS stores,
+// bit 1 no epilogue stores, bit 2 no activation loads
+#ifndef X3_EXP
+#define X3_EXP 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -80,6 +88,26 @@ struct X3Args {
   const float* noise_w;     //       spart[((n * CO + c) * 4 tiles_per_plane + 4 tile + wave row) * 2]
   double* spart;
 };
+
+// Activation loads are inline asm: hipcc neither sees them in its vmcnt bookkeeping (beside an LDS-DMA it waits vmcnt(0) in
+// front of the first use of any load it does see: the whole prefetch pipeline drained several times per stage) nor may recycle
+// their registers before x3_ld_wait, which is tied to them and counts the younger operations by hand.
+__device__ __forceinline__ u32x4 x3_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) & 0xffffu,
+               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void x3_ld(f32x4& d, const u32x4& rs, int voff, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff));
+}
+template <int YOUNGER>
+__device__ __forceinline__ void x3_ld_wait(f32x4 (&a)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(YOUNGER));
+}
+template <int YOUNGER>
+__device__ __forceinline__ void x3_ld_wait(f32x4 (&a)[4], f32x4& s_, f32x4& t_) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(s_), "+v"(t_) : "n"(YOUNGER));
+}
 
 // kernel forms
 constexpr int X3_PLAIN = 0, X3_MASK = 1, X3_AFF = 2, X3_AFF_TAIL = 3;
@@ -150,56 +178,60 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
     a_pack = unit48 | ((cg == 0 ? 3 : 0) << 16) | ((cg == 5 ? 1 : 4) << 18) | (r << 21) | (cg << 26) | ((g * 2 + cq) << 29);
   }
   const int cstride = plane * 4;
-  float4 ar[4];
-  float4 a_sv, a_tv;                                  // AFF: scale / shift of the item's four channels (zeros outside the image)
+  f32x4 ar[4];
+  f32x4 a_sv, a_tv;                                  // AFF: scale / shift of the item's four channels (zeros outside the image)
   auto a_load = [&](const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j of tile c's halo patch
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (long long)c.n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
+    const u32x4 rs = x3_rsrc(p.x + (long long)c.n * p.CI * plane, (unsigned)((long long)p.CI * plane * 4));
     int pk = a_pack;
     asm volatile("" : "+v"(pk));      // offsets computed HERE, not hoisted out of the k-loop and spilled
     const int ry = ((pk >> 21) & 31) - 1, rx = ((pk >> 26) & 7) * 4 - 4, a_ch = ((pk >> 29) & 3) * 4;
     const bool ok = a_item && (unsigned)(c.oy0 + ry) < (unsigned)p.H && (unsigned)(c.ox0 + rx) < (unsigned)p.W;
     const int off = ok ? (a_ch * plane + (c.oy0 + ry) * p.W + c.ox0 + rx) * 4 : (int)0x80000000;
     const int soff = half * 16 * plane * 4;
+    if (X3_EXP & 4) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * cstride, soff, 0);
-      ar[j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-    }
+    for (int j = 0; j < 4; ++j) x3_ld(ar[j], rs, off + j * cstride, soff);
     if constexpr (AFF) {       // an item outside the image reads zeros for s and t as well: 0 * 0 + 0 keeps the padding zero
-      const long long tab = (long long)p.N * p.CI * 4;
-      const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_s), 0, (unsigned)tab, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_t), 0, (unsigned)tab, 0x00020000);
+      const unsigned tab = (unsigned)((long long)p.N * p.CI * 4);
+      const u32x4 rss = x3_rsrc(p.aff_s, tab), rst = x3_rsrc(p.aff_t, tab);
       const int o = ok ? a_ch * 4 : (int)0x80000000;
       const int so = (c.n * p.CI + half * 16) * 4;
-      const u32x4 sv = __builtin_amdgcn_raw_buffer_load_b128(rss, o, so, 0), tv = __builtin_amdgcn_raw_buffer_load_b128(rst, o, so, 0);
-      a_sv = float4{__uint_as_float(sv.x), __uint_as_float(sv.y), __uint_as_float(sv.z), __uint_as_float(sv.w)};
-      a_tv = float4{__uint_as_float(tv.x), __uint_as_float(tv.y), __uint_as_float(tv.z), __uint_as_float(tv.w)};
+      x3_ld(a_sv, rss, o, so);
+      x3_ld(a_tv, rst, o, so);
     }
   };
-  auto a_store = [&](int slot) {
-    if (!a_item) return;
+  // the loads' data, once all but the `YOUNGER` vector-memory operations issued after them have completed
+  auto a_wait = [&](auto younger) {
+    if constexpr (AFF) x3_ld_wait<decltype(younger)::value>(ar, a_sv, a_tv); else x3_ld_wait<decltype(younger)::value>(ar);
+  };
+  // one pixel (of the item's four) per call: the split is vector-ALU work that belongs BETWEEN the rows' MFMA blocks, not in
+  // front of the stage's barrier where every wave would wait for it (ablation: 19 % of the kernel there)
+  auto a_store_px = [&](int slot, int i) {
+    if (!a_item || (X3_EXP & 1)) return;
     int pk = a_pack;
     asm volatile("" : "+v"(pk));
     const int a_i0 = (pk >> 16) & 3, a_i1 = (pk >> 18) & 7;
     unsigned char* dst = reinterpret_cast<unsigned char*>(lds + X3_AOFF + slot * X3_HALF) + ((pk & 0x7fff) - 48);
+    if (i < a_i0 || i >= a_i1) return;
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
+      if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
+                                  j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
+      h[j] = (__bf16)v;
+      const float r1 = v - x3_up(h[j]);
+      m[j] = (__bf16)r1;
+      l[j] = (__bf16)(r1 - x3_up(m[j]));
+    }
+    *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
+    *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
+    *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
+  };
+  auto a_store = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (i < a_i0 || i >= a_i1) continue;
-      bf16x4 h, m, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
-        if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
-                                    j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
-        h[j] = (__bf16)v;
-        const float r1 = v - x3_up(h[j]);
-        m[j] = (__bf16)r1;
-        l[j] = (__bf16)(r1 - x3_up(m[j]));
-      }
-      *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
-      *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
-      *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
+      a_store_px(slot, i);
       __builtin_amdgcn_sched_barrier(0);     // one pixel at a time: the split's temporaries stay a dozen registers
     }
   };
@@ -245,8 +277,8 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
 
   // ---- prologue: halves 0, 1, weight stages 0, 1 of the first tile -----------------------------------------------------
   w_dma(cur, 0, 0);
-  a_load(cur, 0); a_store(0);
-  a_load(cur, 1); a_store(1);
+  a_load(cur, 0); a_wait(std::integral_constant<int, 0>{}); a_store(0);
+  a_load(cur, 1); a_wait(std::integral_constant<int, 0>{}); a_store(1);
   x3_barrier<0>();
   if (nstages > 1) w_dma(cur, 1, 1);
   int offA;                          // this lane's patch offset (units) of the k-step whose rows are being read
@@ -309,12 +341,22 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
             X3_MFMA(accH[m][nn], aF[m & 1][0], bF[cb][nn][0]);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (par == 0) {
+            // a half patch goes to LDS in the first k-step of its stage, one pixel of every item behind each row's MFMAs
+            // (visible behind the stage's barrier in the second k-step)
+            const bool first_half1 = j == 0 && (dc > 0 || st > 0 || tile != gl_xcd_remap(blockIdx.x, G));
+            // behind the loads of this half: the DMA of the stage in between (3 operations; a tile's epilogue stores on top
+            // of them are simply waited for as well)
+            if (m == 0 && (first_half1 || j == 2 || j == 4 || (j == 7 && more))) a_wait(std::integral_constant<int, 3>{});
+            if (first_half1) a_store_px(sl1, m);                 // half 4dc + 1
+            if (j == 2) a_store_px(sl2, m);                      // half 4dc + 2
+            if (j == 4) a_store_px(sl0, m);                      // half 4dc + 3
+            if (j == 7 && more) a_store_px(sl1, m);              // half 4dc + 4 (the next tile's half 0 behind the last double chunk)
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (par == 1 && m == 0) {
-            // ---- the stage's barrier: half patches stored now and the next stage's weights are visible behind it ------
-            if (j == 0 && (dc > 0 || st > 0 || tile != gl_xcd_remap(blockIdx.x, G))) a_store(sl1);     // half 4dc + 1
-            if (j == 2) a_store(sl2);                      // half 4dc + 2
-            if (j == 4) a_store(sl0);                      // half 4dc + 3
-            if (j == 7 && more) a_store(sl1);              // half 4dc + 4 (the next tile's half 0 behind the last double chunk)
+            // ---- the stage's barrier: the next stage's weights (and a half patch stored in the first k-step) are visible
+            //      behind it ---------------------------------------------------------------------------------------------
             if (j == 1 || j == 3) x3_barrier<NLOADS>();
             else if (j == 6 || j == 8) { if (more) x3_barrier<NLOADS>(); else x3_barrier<0>(); }
             else x3_barrier<0>();
@@ -353,9 +395,16 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
       X3_MFMA_DRAIN(accS);
       // the epilogue's arguments are read from the kernel-argument segment HERE: held in scalar registers across the k-loop
       // they cost a dozen spills
-      const X3Args* kp = (const X3Args*)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kp));
-      const X3Args& q = *kp;
+      // (a copy in registers, read once per tile by scalar loads: through the laundered pointer every use would be a flat load
+      // re-issued behind each store)
+      typedef const __attribute__((address_space(4))) X3Args* X3ArgsK;
+      unsigned long long kpi = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kpi));
+      const X3ArgsK kp = (X3ArgsK)kpi;
+      struct { float* y; const float* bias; const float* mask; const float* noise; const float* noise_w; double* spart;
+               float bias_scale, slope, mslope; int act; } q;
+      q.y = kp->y; q.bias = kp->bias; q.mask = kp->mask; q.noise = kp->noise; q.noise_w = kp->noise_w; q.spart = kp->spart;
+      q.bias_scale = kp->bias_scale; q.slope = kp->slope; q.mslope = kp->mslope; q.act = kp->act;
       const long long ib = (long long)cur.n * p.CO * plane;
       float bv[2], nwv[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -395,7 +444,7 @@ __global__ __launch_bounds__(512) void conv_x3_fwd_kernel(X3Args p) {
             if constexpr (MASK) { if (!(mks[m][nn][r] > 0.f)) f *= q.mslope; }
             v[r] = f;
           }
-          *reinterpret_cast<f32x4*>(q.y + o) = v;
+          if (!(X3_EXP & 2)) *reinterpret_cast<f32x4*>(q.y + o) = v;
           if constexpr (TAIL) {
             s1[nn] += (v[0] + v[1]) + (v[2] + v[3]);
             s2[nn] += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
@@ -446,6 +495,7 @@ struct X3UpTile { int n, oy0, ox0, co_t, py, px; };
 template <int FORM>
 __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
   constexpr bool AFF = FORM == X3_AFF;
+  constexpr int NLOADS = AFF ? 6 : 4;
   __shared__ __attribute__((aligned(16))) u32x4 lds[X3_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -483,58 +533,64 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
     a_pack = unit48 | ((cg == 0 ? 3 : 0) << 16) | ((cg == 5 ? 1 : 4) << 18) | (r << 21) | (cg << 26) | ((g * 2 + cq) << 29);
   }
   const int cstride = plane * 4;
-  float4 ar[4];
-  float4 a_sv, a_tv;                                  // AFF: scale / shift of the item's four channels (zeros outside the image)
-  auto a_load = [&](const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j of tile c's halo patch
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (long long)c.n * p.CI * plane), 0, (unsigned)((long long)p.CI * plane * 4), 0x00020000);
+  // TWO register sets: a half patch is requested two stages before it is split (one stage = 96 MFMAs per wave is not always
+  // an HBM round trip), so two are in flight
+  f32x4 arA[4], arB[4];
+  f32x4 svA, tvA, svB, tvB;                          // AFF: scale / shift of the item's four channels (zeros outside the image)
+  auto a_load_to = [&](f32x4 (&ar)[4], f32x4& a_sv, f32x4& a_tv, const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j
+    const u32x4 rs = x3_rsrc(p.x + (long long)c.n * p.CI * plane, (unsigned)((long long)p.CI * plane * 4));
     int pk = a_pack;
     asm volatile("" : "+v"(pk));      // offsets computed HERE, not hoisted out of the k-loop and spilled
     const int ry = ((pk >> 21) & 31) - 1, rx = ((pk >> 26) & 7) * 4 - 4, a_ch = ((pk >> 29) & 3) * 4;
     const bool ok = a_item && (unsigned)(c.oy0 + ry) < (unsigned)p.H && (unsigned)(c.ox0 + rx) < (unsigned)p.W;
     const int off = ok ? (a_ch * plane + (c.oy0 + ry) * p.W + c.ox0 + rx) * 4 : (int)0x80000000;
     const int soff = half * 16 * plane * 4;
+    if (X3_EXP & 4) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * cstride, soff, 0);
-      ar[j] = float4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-    }
+    for (int j = 0; j < 4; ++j) x3_ld(ar[j], rs, off + j * cstride, soff);
     if constexpr (AFF) {       // an item outside the image reads zeros for s and t as well: 0 * 0 + 0 keeps the padding zero
-      const long long tab = (long long)p.N * p.CI * 4;
-      const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_s), 0, (unsigned)tab, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aff_t), 0, (unsigned)tab, 0x00020000);
+      const unsigned tab = (unsigned)((long long)p.N * p.CI * 4);
+      const u32x4 rss = x3_rsrc(p.aff_s, tab), rst = x3_rsrc(p.aff_t, tab);
       const int o = ok ? a_ch * 4 : (int)0x80000000;
       const int so = (c.n * p.CI + half * 16) * 4;
-      const u32x4 sv = __builtin_amdgcn_raw_buffer_load_b128(rss, o, so, 0), tv = __builtin_amdgcn_raw_buffer_load_b128(rst, o, so, 0);
-      a_sv = float4{__uint_as_float(sv.x), __uint_as_float(sv.y), __uint_as_float(sv.z), __uint_as_float(sv.w)};
-      a_tv = float4{__uint_as_float(tv.x), __uint_as_float(tv.y), __uint_as_float(tv.z), __uint_as_float(tv.w)};
+      x3_ld(a_sv, rss, o, so);
+      x3_ld(a_tv, rst, o, so);
     }
   };
-  auto a_store = [&](int slot) {
-    if (!a_item) return;
+  auto a_wait = [&](int set, auto younger) {
+    constexpr int Y = decltype(younger)::value;
+    if (set == 0) { if constexpr (AFF) x3_ld_wait<Y>(arA, svA, tvA); else x3_ld_wait<Y>(arA); }
+    else { if constexpr (AFF) x3_ld_wait<Y>(arB, svB, tvB); else x3_ld_wait<Y>(arB); }
+  };
+  // one pixel (of the item's four) per call: the split is vector-ALU work that belongs BETWEEN the rows' MFMA blocks, not in
+  // front of the stage's barrier where every wave would wait for it (ablation: 19 % of the kernel there)
+  auto a_store_from = [&](const f32x4 (&ar)[4], const f32x4& a_sv, const f32x4& a_tv, int slot, int i) {
+    if (!a_item || (X3_EXP & 1)) return;
     int pk = a_pack;
     asm volatile("" : "+v"(pk));
     const int a_i0 = (pk >> 16) & 3, a_i1 = (pk >> 18) & 7;
     unsigned char* dst = reinterpret_cast<unsigned char*>(lds + X3_AOFF + slot * X3_HALF) + ((pk & 0x7fff) - 48);
+    if (i < a_i0 || i >= a_i1) return;
+    bf16x4 h, m, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < a_i0 || i >= a_i1) continue;
-      bf16x4 h, m, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
-        if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
-                                    j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
-        h[j] = (__bf16)v;
-        const float r1 = v - x3_up(h[j]);
-        m[j] = (__bf16)r1;
-        l[j] = (__bf16)(r1 - x3_up(m[j]));
-      }
-      *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
-      *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
-      *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
-      __builtin_amdgcn_sched_barrier(0);     // one pixel at a time: the split's temporaries stay a dozen registers
+    for (int j = 0; j < 4; ++j) {
+      float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
+      if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
+                                  j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
+      h[j] = (__bf16)v;
+      const float r1 = v - x3_up(h[j]);
+      m[j] = (__bf16)r1;
+      l[j] = (__bf16)(r1 - x3_up(m[j]));
     }
+    *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
+    *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
+    *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
+  };
+  auto a_load = [&](int set, const X3Tile& c, int half) {
+    if (set == 0) a_load_to(arA, svA, tvA, c, half); else a_load_to(arB, svB, tvB, c, half);
+  };
+  auto a_store_px = [&](int set, int slot, int i) {
+    if (set == 0) a_store_from(arA, svA, tvA, slot, i); else a_store_from(arB, svB, tvB, slot, i);
   };
 
   // ---- weight staging: LDS-DMA, the packed stage image is the LDS image; 24 pieces of 1 KB per stage, 3 per wave ----
@@ -578,12 +634,17 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
   X3Tile cur = decode(tile);
   int sa = 0, sb = 1, sc = 2;          // ring slots of the half being multiplied, the next one, the one after
 
-  // ---- prologue: half 0 in LDS, half 1 in registers, weight stages 0 (landed) and 1 (in flight) ---------------------------
+  // ---- prologue: half 0 in LDS, halves 1 and 2 in registers, weight stages 0 (landed) and 1 (in flight) ---------------------------
   w_dma(cur, 0, 0);
-  a_load(cur, 0); a_store(sa);
+  a_load(0, cur, 0);
+  a_wait(0, std::integral_constant<int, 0>{});
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a_store_px(0, sa, i); __builtin_amdgcn_sched_barrier(0); }
   x3_barrier<0>();
   w_dma(cur, 1, 1);
-  a_load(cur, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  a_load(1, cur, 1);            // stored in stage 0
+  a_load(0, cur, 2);            // stored in stage 1
   int offA = laneA + sa * X3_HALF + cur.py * 18 + cur.px + khi_i;       // step 0: taps (0, 0) | (0, 1)
   a_frags(offA, 0);
   b_frags(0, 0, 0, 0);
@@ -630,16 +691,27 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
             X3_MFMA(accH[m][nn], aF[m & 1][0], bF[cb][nn][0]);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (par == 0) {      // the next half goes to LDS one pixel of every item behind each row (register set (stage + 1) & 1)
+            if (hs + 1 < nstages || nvalid) {
+              // behind this half's loads: the DMA of the stage in between (3) and, where there is a half two stages on, its loads
+              if (m == 0) { if (hs + 2 < nstages || nvalid) a_wait((j + 1) & 1, std::integral_constant<int, 3 + NLOADS>{});
+                            else a_wait((j + 1) & 1, std::integral_constant<int, 3>{}); }
+              a_store_px((j + 1) & 1, sb, m);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (par == 1 && m == 0) {
-            // ---- the stage's barrier: the next half is stored in front of it, the one after and the weights two stages on are
-            //      requested behind it -----------------------------------------------------------------------------------
-            const bool next_half = hs + 1 < nstages || nvalid;
-            if (next_half) a_store(sb);
-            x3_barrier<0>();
+            // ---- the stage's barrier; behind it the weights two stages on and the half patch three stages on are requested
+            //      (the barrier waits for the DMA of the stage before: all but the loads issued behind it) -----------------------
+            if (hs + 2 < nstages || nvalid) x3_barrier<NLOADS>(); else x3_barrier<0>();
             {
               const int s2 = hs + 2;
-              if (s2 < nstages) { w_dma(cur, s2, buf); __builtin_amdgcn_sched_barrier(0); a_load(cur, s2); }
-              else if (nvalid) { w_dma(nxt, s2 - nstages, buf); __builtin_amdgcn_sched_barrier(0); a_load(nxt, s2 - nstages); }
+              if (s2 < nstages) w_dma(cur, s2, buf);
+              else if (nvalid) w_dma(nxt, s2 - nstages, buf);
+              __builtin_amdgcn_sched_barrier(0);
+              const int s3 = hs + 3;
+              if (s3 < nstages) a_load((j + 1) & 1, cur, s3);
+              else if (nvalid) a_load((j + 1) & 1, nxt, s3 - nstages);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -662,9 +734,16 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
     // ---- epilogue: this parity's pixels (2y + py, 2x + px) of the 32 x 32 output tile ---------------------------------------
     {
       X3_MFMA_DRAIN(accS);
-      const X3Args* kp = (const X3Args*)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kp));
-      const X3Args& q = *kp;
+      // (a copy in registers, read once per tile by scalar loads: through the laundered pointer every use would be a flat load
+      // re-issued behind each store)
+      typedef const __attribute__((address_space(4))) X3Args* X3ArgsK;
+      unsigned long long kpi = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kpi));
+      const X3ArgsK kp = (X3ArgsK)kpi;
+      struct { float* y; const float* bias; const float* mask; const float* noise; const float* noise_w; double* spart;
+               float bias_scale, slope, mslope; int act; } q;
+      q.y = kp->y; q.bias = kp->bias; q.mask = kp->mask; q.noise = kp->noise; q.noise_w = kp->noise_w; q.spart = kp->spart;
+      q.bias_scale = kp->bias_scale; q.slope = kp->slope; q.mslope = kp->mslope; q.act = kp->act;
       const int oW = 2 * p.W;
       const long long ib = (long long)cur.n * p.CO * plane * 4;
 #pragma unroll
@@ -679,7 +758,7 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
           for (int r = 0; r < 4; ++r) {
             float f = v[r] + bv;
             if (q.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, q.slope);
-            dst[2 * r] = f;
+            if (!(X3_EXP & 2)) dst[2 * r] = f;
           }
           accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
           accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
