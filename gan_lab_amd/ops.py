@@ -389,6 +389,21 @@ def x3_s2_ok(g, dgrad=False):
     return bool(_lib.lib().ganlab_conv_s2_x3_supported(g.ref(), 1 if dgrad else 0))
 
 
+def x3_wgrad_ok(g):
+    """Does this plain 3x3 layer's weight gradient run on the split-product kernel?"""
+    if not _X3[0] or g.bf is not None or g.s2 or g.up or g.pool or g.ks != 3 or g.pad != 1 or g.Cin < 64 or g.Cout < 64:
+        return False
+    return bool(_lib.lib().ganlab_conv_wgrad_x3_supported(g.ref()))
+
+
+def _wgrad_x3(gy, x, s_, t_, gw, g, scale):
+    L = _lib.lib()
+    ws = torch.empty((L.ganlab_conv_wgrad_x3_workspace(g.ref()) + 3) // 4, dtype=torch.float32, device=x.device)
+    check(L.ganlab_conv_wgrad_x3(_p(gy), _p(x), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
+          'conv_wgrad_x3')
+    return gw
+
+
 def _packed_x3_s2(w, up, scale):
     """``up``: 1 = an up layer's forward weights, 0 = a pooled layer's input-gradient weights."""
     key = (w.data_ptr(), w._version, tuple(w.shape), int(up), float(scale), 'x3s2')
@@ -857,6 +872,8 @@ def k_conv_wgrad(gy, x, g, scale):
     _note('wgrad', g)
     L = _lib.lib()
     gw = _take('gw', (g.Cout, g.Cin, g.ks, g.ks), x)
+    if x3_wgrad_ok(g):
+        return _wgrad_x3(gy, x, None, None, gw, g, scale)
     if g.bf is not None:
         if g.bf_fused is not None:
             # the rolling-row kernel reads the half-resolution operand (x of conv(up2 x), gy of pool2(conv x)) in place
@@ -2301,6 +2318,8 @@ def k_conv_wgrad_aff(gy, a, s_, t_, g, scale):
     _note('wgrad', g)
     L = _lib.lib()
     gw = _take('gw', (g.Cout, g.Cin, 3, 3), a)
+    if not g.up and x3_wgrad_ok(g):
+        return _wgrad_x3(gy, a, _c(s_), _c(t_), gw, g, scale)
     if g.up:
         ws = torch.empty((max(L.ganlab_conv_s2_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=a.device)
         check(L.ganlab_conv_s2_wgrad_aff_f32(_p(gy), _p(a), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4,

@@ -211,6 +211,13 @@ int ganlab_conv_s2_fwd_x3(const float* x, const void* wp, const float* bias, flo
 int ganlab_conv_s2_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
                               float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
 int ganlab_conv_s2_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+/* weight gradient of a plain 3x3 layer (csrc/conv_x3_wgrad.hip): ganlab_conv_wgrad_f32, or with aff_s / aff_t non-null
+ * ganlab_conv_wgrad_aff_f32, as split products; H a power of two, W % 32 == 0, Cin % 64 == 0, Cout % 32 == 0.  Deterministic
+ * (per-workgroup slots in the workspace, fixed-order reduction). */
+int ganlab_conv_wgrad_x3_supported(const ganlab_conv_geom* g);
+size_t ganlab_conv_wgrad_x3_workspace(const ganlab_conv_geom* g);
+int ganlab_conv_wgrad_x3(const float* gy, const float* x, const float* aff_s, const float* aff_t, float* gw,
+                         const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes, void* stream);
 int ganlab_conv_fwd_aff_tail_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
                                 const float* noise, const float* noise_w, float* y, float* mean, float* rstd,
                                 const ganlab_conv_geom* g, float bias_scale, int act, float slope, float eps, void* workspace,

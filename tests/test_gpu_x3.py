@@ -304,3 +304,50 @@ def test_x3_s2_batched_repack_equals_single_pack(ops):
     torch.cuda.synchronize()
     for one, out in zip(singles, outs):
         assert torch.equal(one.view(torch.int16), out.view(torch.int16))
+
+
+# ---- weight gradient -------------------------------------------------------------------------------------------------------------
+WG_CASES = [(2, 64, 64, 32, 32), (3, 128, 64, 16, 64), (2, 64, 96, 64, 32), (5, 192, 128, 8, 32), (9, 64, 64, 4, 96)]   # N, Cin, Cout, H, W
+
+
+@pytest.mark.parametrize('case', WG_CASES)
+@pytest.mark.parametrize('aff', [False, True])
+def test_x3_weight_gradient(ops, case, aff):
+    n, ci, co, h, w = case
+    g = torch.Generator().manual_seed(41 + ci + n + h)
+    x = torch.randn(n, ci, h, w, generator=g)
+    gy = torch.randn(n, co, h, w, generator=g)
+    s_ = torch.rand(n, ci, generator=g) + 0.5
+    t_ = torch.randn(n, ci, generator=g)
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    assert ops.x3_wgrad_ok(geom)
+    scale = 0.013
+    run = (lambda: ops.k_conv_wgrad_aff(gy.cuda(), x.cuda(), s_.cuda(), t_.cuda(), geom, scale)) if aff else \
+        (lambda: ops.k_conv_wgrad(gy.cuda(), x.cuda(), geom, scale))
+    gw3 = run()
+    assert 'x3w_reduce_kernel' in launched(ops)
+    prev = ops.set_x3(False)
+    try:      # (the exact-fp32 affine-on-load weight gradient does not take every geometry the split-product one does)
+        gw1 = run() if (not aff or ops.conv_aff_ok((n, ci, h, w), torch.empty(co, ci, 3, 3))) else gw3
+        assert 'x3w_reduce_kernel' not in launched(ops) or gw1 is gw3
+    finally:
+        ops.set_x3(prev)
+    xin = x.double() * s_.double().view(n, ci, 1, 1) + t_.double().view(n, ci, 1, 1) if aff else x.double()
+    wd = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    gwd, = torch.autograd.grad(F.conv2d(xin, wd, padding=1), wd, gy.double())
+    gwd = gwd * scale
+    assert_close(gw3.cpu(), gwd, TOL, 'x3 weight gradient vs float64')
+    assert_close(gw3.cpu(), gw1.cpu(), TOL, 'x3 weight gradient vs exact-fp32 kernel')
+    # (at these sizes - a few thousand terms per weight - both kernels sit at the rounding of the result itself; the bar is the
+    # exact kernels' error or ATen's 2.2e-7 level of tools/op_error_probe.py, whichever is larger)
+    assert rms_rel(gw3, gwd) <= max(1.1 * rms_rel(gw1, gwd), 2.5e-7), (rms_rel(gw3, gwd), rms_rel(gw1, gwd))
+
+
+def test_x3_weight_gradient_is_deterministic(ops):
+    n, ci, co, h, w = 4, 64, 64, 32, 64
+    g = torch.Generator().manual_seed(9)
+    x, gy = torch.randn(n, ci, h, w, generator=g).cuda(), torch.randn(n, co, h, w, generator=g).cuda()
+    geom = ops.Geom(n, ci, h, w, co, 3, 1)
+    a = ops.k_conv_wgrad(gy, x, geom, 1.0).clone()
+    b = ops.k_conv_wgrad(gy, x, geom, 1.0)
+    assert torch.equal(a, b)

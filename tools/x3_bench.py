@@ -69,6 +69,54 @@ def errors():
         print(f'dgrad {ci:3d}->{co:3d} {hw}x{hw}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 {e3:.3e} ({e3 / ec:.2f})', flush=True)
 
 
+def wgrad_report(batch, rounds, reps):
+    """Weight gradient: error against float64 next to ATen's CPU fp32 (batch 4) and ms per launch at the bench batch."""
+    torch.manual_seed(1)
+    for ci, co, hw in [(64, 64, 128), (128, 128, 64), (256, 256, 32)]:
+        n = 4
+        x, gy = torch.randn(n, ci, hw, hw), torch.randn(n, co, hw, hw)
+        g = ops.Geom(n, ci, hw, hw, co, 3, 1)
+        wd = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        exact, = torch.autograd.grad(F.conv2d(x.double(), wd, padding=1), wd, gy.double())
+        wf = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        cpu, = torch.autograd.grad(F.conv2d(x, wf, padding=1), wf, gy)
+        x3 = ops.k_conv_wgrad(gy.cuda(), x.cuda(), g, 1.0)
+        prev = ops.set_x3(False)
+        hip = ops.k_conv_wgrad(gy.cuda(), x.cuda(), g, 1.0)
+        ops.set_x3(prev)
+        ec, eh, e3 = err(cpu, exact), err(hip, exact), err(x3, exact)
+        print(f'wgrad {ci:3d}->{co:3d} {hw}x{hw} x{n}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 {e3:.3e} ({e3 / ec:.2f})', flush=True)
+    for ci, co, hw in LAYERS[:4]:
+        x = torch.randn(batch, ci, hw, hw, device='cuda')
+        gy = torch.randn(batch, co, hw, hw, device='cuda')
+        g = ops.Geom(batch, ci, hw, hw, co, 3, 1)
+        fl = ops.conv_flops(g)
+        ms = {'fp32': [], 'x3': []}
+        def run(on):
+            prev = ops.set_x3(on)
+            try:
+                return ops.k_conv_wgrad(gy, x, g, 0.05)
+            finally:
+                ops.set_x3(prev)
+        for on in (False, True):
+            for _ in range(4):
+                run(on)
+        for _ in range(rounds):
+            for k, on in (('fp32', False), ('x3', True)):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run(on)
+                e1.record()
+                torch.cuda.synchronize()
+                ms[k].append(e0.elapsed_time(e1) / reps)
+        med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+        print(f'wgrad {ci:3d}->{co:3d} @{hw:3d} x{batch}: fp32 MFMA {med["fp32"]:.3f} ms ({fl / med["fp32"] / 1e9:6.1f} TF/s)  3xbf16 {med["x3"]:.3f} ms '
+              f'({fl / med["x3"] / 1e9:6.1f} TF/s fp32-equivalent)  speed-up {med["fp32"] / med["x3"]:.2f}x', flush=True)
+        del x, gy
+
+
 def times(batch, rounds, reps, forms=False):
     for ci, co, hw in LAYERS:
         x = torch.randn(batch, ci, hw, hw, device='cuda')
@@ -130,8 +178,12 @@ if __name__ == '__main__':
     p.add_argument('--reps', type=int, default=10)
     p.add_argument('--err-only', action='store_true')
     p.add_argument('--time-only', action='store_true')
+    p.add_argument('--wgrad', action='store_true', help='weight gradient: error and time')
     p.add_argument('--forms', action='store_true', help='time the masked / affine / layer-tail forms through ops')
     a = p.parse_args()
+    if a.wgrad:
+        wgrad_report(a.batch, a.rounds, a.reps)
+        sys.exit(0)
     if not a.time_only:
         errors()
     if not a.err_only:
