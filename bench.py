@@ -230,11 +230,22 @@ def measure_dominant_kernel(torch, batch, c, res, reps=5):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * 9 * c * c * res * res * batch
+    # The thick fp32 layers run as split products on the bf16 matrix cores (csrc/conv_x3.hip): SIX bf16 MFMA products per
+    # fp32 product.  Such a launch is priced in the bf16 FLOPs it executes against the bf16 MFMA peak; the fp32 product
+    # rate (a sixth of it) is reported beside it.
+    x3 = 'conv_x3' in (kernel or '')
+    if x3:
+        flops *= 6.0
     ach = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS if (bf or x3) else PEAK_F32_MFMA_TFLOPS
     out = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
            'traffic': None, 'kernel': kernel, 'grid': grid, 'instance': f'3x3 {c}->{c} @{res}^2 x{batch}',
            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops}
+    if x3:
+        out['arithmetic'] = '3xbf16 split products, fp32 accumulate'
+        out['bf16_products_per_fp32_product'] = 6
+        out['fp32_equivalent_tflops'] = round(ach / 6.0, 2)
+        out['fp32_mfma_peak'] = PEAK_F32_MFMA_TFLOPS
     t = kernel_traffic(kernel)
     if t is not None and (c, res, batch) == NORTHSTAR_OF_TRAFFIC_TABLE.get(bf):
         out['traffic'], out['traffic_source'] = t
@@ -262,7 +273,12 @@ class InSituKernelTimer(object):
         f0, d0 = self._orig = (ops.k_conv_fwd, ops.k_conv_dgrad)     # whatever is installed now: timers nest
 
         def prepack(w, mode, scale, g):
-            (ops._packed_bf16(w, mode, scale) if g.bf is not None else ops._packed(w, mode, scale))
+            if g.bf is not None:
+                ops._packed_bf16(w, mode, scale)
+            elif ops.x3_ok(g, mode == ops.PACK_DGRAD):
+                ops._packed_x3(w, mode, scale)
+            else:
+                ops._packed(w, mode, scale)
 
         def fwd(x, w, bias, g, *a, **k):
             if len(self.events) >= self.MAX_EVENTS or not self._match(g) or torch.cuda.is_current_stream_capturing():
@@ -692,6 +708,14 @@ def main():
             'world_size_observed': dist.get_world_size() if use_dist else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            # fp32 in, fp32 out, fp32 accumulation everywhere.  The >= 64-channel 3x3 layers (forward, input gradient, plain
+            # weight gradient) multiply on the bf16 matrix cores as split products - three bf16 planes per operand that sum to
+            # it exactly, six products per fp32 product - as close to float64 as the exact-fp32 MFMA kernels (tools/
+            # x3_bench.py: 0.24-0.51 of ATen's rms error); the thin layers and everything else stay on exact fp32 MFMA / VALU.
+            # GANLAB_X3=0 restores the exact-fp32 kernels everywhere (profiles/ holds both lines).
+            'arithmetic': ('3xbf16 split products, fp32 accumulate (thick 3x3 layers) + exact fp32 MFMA (thin layers)'
+                           if (a.dtype == 'f32' and _ops.x3_enabled()) else ('exact fp32 MFMA' if a.dtype == 'f32' else
+                                                                             'bf16 products, fp32 accumulate')),
             'config': {'workload': wl.what, 'baseline_config': a.config, 'global_batch': world * a.batch,
                        'per_gpu_batch': a.batch, 'parallelism': f'dp{world}' if world > 1 else 'single'},
             # executed: what the launchers ran (per GPU) over the MFMA peak of one GPU - a roofline fraction of the step
@@ -721,6 +745,9 @@ def main():
                 r['ms_per_launch'] = round(ms_t, 4)
                 r['achieved'] = round(r['flops_per_launch'] / (ms_t * 1e-3) / 1e12, 2)
                 r['frac'] = round(r['achieved'] / r['peak'], 4)
+                if 'fp32_equivalent_tflops' in r:
+                    r['isolated_fp32_equivalent_tflops'] = r['fp32_equivalent_tflops']
+                    r['fp32_equivalent_tflops'] = round(r['achieved'] / 6.0, 2)
                 r['launches_timed_in_step'] = n_t
             return r
         # the instance as launched INSIDE the timed steps (device events around each launch, forward and input

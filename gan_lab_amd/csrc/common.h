@@ -42,6 +42,11 @@ static inline int gl_take_status() {
 }
 #define GL_CHECK_LAUNCH() gl_take_status()
 
+// Environment knobs (A/B switches and tuning knobs, DESIGN.md "knobs") are read ONCE per process, at their first use - the
+// entry points keep no other global mutable state.  gl_env_str: the string (or nullptr), cached per call site.
+#include <cstdlib>
+#define GL_ENV_ONCE(name) ([]() -> const char* { static const char* const v = getenv(name); return v; }())
+
 static inline hipStream_t gl_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch"):

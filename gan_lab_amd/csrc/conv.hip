@@ -2582,7 +2582,7 @@ int ganlab_conv_wgrad_act_bits_f32(const float* gy, const unsigned* ybits, const
 
 // ---- deferred InstanceNorm: affine-on-load variants (see PatchArgs, mod.hip) ------------------------------------------
 static bool aff_wgrad_roll_ok(const ganlab_conv_geom* g, const void* x, const void* gy) {
-  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  const char* roll_env = GL_ENV_ONCE("GANLAB_WGRAD_ROLL");
   return !(roll_env && roll_env[0] == '0') &&
          gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy);
 }
@@ -2656,7 +2656,7 @@ int gl_tail_stats_finish(const double* spart, float* mean, float* rstd, long lon
  * a geometry that form takes */
 int ganlab_conv_fwd_aff_tail_chunks(const ganlab_conv_geom* g) {
   if (!(ganlab_conv_aff_supported(g) & 1) || (g->Win % 32) != 0 || (g->Hin % 8) != 0) return 0;
-  const char* e = getenv("GANLAB_CONV_TAIL");
+  const char* e = GL_ENV_ONCE("GANLAB_CONV_TAIL");
   if (e != nullptr && e[0] == '0') return 0;
   return (g->Win / (g->Cout <= 32 ? 32 : ThickCfg::G::TW)) * (g->Hin / 8);
 }
@@ -2800,7 +2800,7 @@ int ganlab_conv_wgrad_f32(const float* gy, const float* x, float* gw, const ganl
   int slots = pl.slots;
   // thin 3x3 layers on 64-pixel-aligned planes: the rolling-window kernel (wgrad_roll.hip), one slot per workgroup
   // (GANLAB_WGRAD_ROLL=0 keeps the tile kernel: same-box A/B measurements)
-  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  const char* roll_env = GL_ENV_ONCE("GANLAB_WGRAD_ROLL");
   const bool roll_on = !(roll_env && roll_env[0] == '0');
   bool rolled = false;
   if (roll_on && gl_wgrad_roll_supported(g->N, g->Cin, g->Cout, g->Hin, g->Win, g->ks, g->pad, g->up, x, gy)) {

@@ -922,7 +922,7 @@ int ganlab_conv_fwd_bf16(const float* x, const void* wp, const float* bias, floa
 int ganlab_conv_bf16_splitk_plan(const ganlab_conv_geom* g, int dgrad) {
   if (g == nullptr || !bf16_ok(g)) return 1;
   const int m = g->up ? 2 : 1;
-  const char* e = getenv("GANLAB_BF16_SPLITK");
+  const char* e = GL_ENV_ONCE("GANLAB_BF16_SPLITK");
   if (e != nullptr && e[0] == '0') return 1;
   return dgrad ? bf16_splitk_plan(g->N, g->Cout, g->Cin, g->Hin * m, g->Win * m)
                : bf16_splitk_plan(g->N, g->Cin, g->Cout, g->Hin * m, g->Win * m);

@@ -606,8 +606,7 @@ static long long rb_plan(RBArgs& a, int N, int H, int W, int blur) {
 }
 
 bool gl_roll_blur_supported(int N, int Cin, int Cout, int H, int W, const void* x, const void* y) {
-  const char* e = getenv("GANLAB_ROLL_BLUR");
-  if (e != nullptr && e[0] == '0') return false;                 // A/B knob: conv kernel + blur pass
+  // (the A/B switch GANLAB_ROLL_BLUR=0 - conv kernel + blur pass - is the CALLER's: gan_lab_amd/ops.py k_conv_fwd_blur_bits)
   return N > 0 && Cin >= 1 && Cin <= 16 && Cout >= 1 && Cout <= 16 && W % RB_TW == 0 && H % 4 == 0 &&
          (long long)Cin * H * W * 4 < 0x7fffffffLL && (long long)Cout * H * W * 4 < 0x7fffffffLL &&
          (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;

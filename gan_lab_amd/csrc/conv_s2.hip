@@ -1258,7 +1258,7 @@ int ganlab_conv_s2_aff_supported(const ganlab_conv_geom* g) {
   int bits = 0;
   if (gl_s2_roll_supported(1, g->N, g->Cin, g->Cout, hl, wl, nullptr, nullptr) || (g->Cout > 16 && g->Cin <= S2_AFF_MAXC))
     bits |= 1;
-  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  const char* roll_env = GL_ENV_ONCE("GANLAB_WGRAD_ROLL");
   if (!(roll_env && roll_env[0] == '0') && gl_wgrad_s2_roll_supported(g->N, g->Cin, g->Cout, hl, wl, nullptr, nullptr))
     bits |= 2;
   return bits;
@@ -1317,7 +1317,7 @@ int ganlab_conv_s2_wgrad_f32(const float* gy, const float* x, float* gw, const g
   int slots = pl.slots;
   // planes whose low-resolution width is a multiple of 32: the rolling-window kernel (wgrad_roll.hip), same slot
   // layout; GANLAB_WGRAD_ROLL=0 keeps the tile kernel (same-box A/B measurements)
-  const char* roll_env = getenv("GANLAB_WGRAD_ROLL");
+  const char* roll_env = GL_ENV_ONCE("GANLAB_WGRAD_ROLL");
   bool rolled = false;
   if (!(roll_env && roll_env[0] == '0') && gl_wgrad_s2_roll_supported(g->N, Cl, Ch, hl, wl, a.low, a.high)) {
     const int rs = gl_wgrad_s2_roll_slots(g->N, Cl, Ch, hl, wl);

@@ -382,7 +382,7 @@ void sr_plan(SRArgs& a, int target) {
   const long long columns = (long long)a.cols * a.N;
   int kk = 1;
   while (kk < steps && columns * kk < target && (steps + kk) / (kk + 1) >= 8) ++kk;
-  if (const char* e = getenv("GANLAB_S2_ROLL_STRIPS")) { if (atoi(e) > 0) kk = atoi(e); }    // tuning knob
+  if (const char* e = GL_ENV_ONCE("GANLAB_S2_ROLL_STRIPS")) { if (atoi(e) > 0) kk = atoi(e); }    // tuning knob
   a.spu = (steps + kk - 1) / kk;
   a.strips = (steps + a.spu - 1) / a.spu;
 }

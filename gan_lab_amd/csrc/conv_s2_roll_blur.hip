@@ -372,10 +372,7 @@ __global__ void tb_sum_finish_kernel(const double* __restrict__ part, float* __r
 
 inline bool tb_aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-bool tb_enabled() {
-  const char* e = getenv("GANLAB_S2_ROLL_BLUR");
-  return !(e && e[0] == '0');
-}
+bool tb_enabled() { return true; }      // (the A/B switch GANLAB_S2_ROLL_BLUR=0 is the caller's: gan_lab_amd/ops.py conv_s2_blur_ok)
 
 void tb_plan(TBArgs& a) {
   a.cols = a.Wl / TB_TW;

@@ -679,7 +679,7 @@ static void wr_plan(WRArgs& a) {
   // ones balance the units over the workgroups.  Measured (tools/wgrad_bench.py, MI355X): 64 is best while every
   // workgroup still gets >= 2.5 units (16 -> 16 at 1024^2: 0.746 of peak vs 0.735 at 16), 16 otherwise.
   int spu = 16;
-  if (const char* e = getenv("GANLAB_WR_SPU")) {       // tuning knob (tools/wgrad_bench.py)
+  if (const char* e = GL_ENV_ONCE("GANLAB_WR_SPU")) {       // tuning knob (tools/wgrad_bench.py)
     spu = atoi(e) > 0 ? atoi(e) : 16;
   } else {
     for (int cand = 64; cand > 16; cand >>= 1) {
@@ -697,7 +697,7 @@ static void wr_plan(WRArgs& a) {
   // bytes, profiles/r02_wgrad_roll_pmc.txt) but the thin layers ran 8-10 % SLOWER with it in a same-process A/B
   // (tools/wgrad_bench.py; thick layers: no difference) - the halo lines the neighbours miss are served by the
   // Infinity Cache anyway.  GANLAB_WR_XCD=1 turns it on.
-  { const char* e = getenv("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = GL_ENV_ONCE("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
 }
 
 // number of partial-sum slots ([Cout][Cin][9] floats each) the launch writes
@@ -738,7 +738,7 @@ static void w2r_plan(W2RArgs& a) {
   const long long base = (long long)a.tiles_cl * a.tiles_ch;
   const int target = (int)((768 + base - 1) / base);
   int spu = 16;
-  if (const char* e = getenv("GANLAB_WR_SPU")) {
+  if (const char* e = GL_ENV_ONCE("GANLAB_WR_SPU")) {
     spu = atoi(e) > 0 ? atoi(e) : 16;
   } else {
     for (int cand = 64; cand > 16; cand >>= 1) {
@@ -756,7 +756,7 @@ static void w2r_plan(W2RArgs& a) {
   // bytes, profiles/r02_wgrad_roll_pmc.txt) but the thin layers ran 8-10 % SLOWER with it in a same-process A/B
   // (tools/wgrad_bench.py; thick layers: no difference) - the halo lines the neighbours miss are served by the
   // Infinity Cache anyway.  GANLAB_WR_XCD=1 turns it on.
-  { const char* e = getenv("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = GL_ENV_ONCE("GANLAB_WR_XCD"); a.xcd = (e && e[0] == '1') ? 1 : 0; }
 }
 
 int gl_wgrad_s2_roll_slots(int N, int Cl, int Ch, int Hl, int Wl) {

@@ -799,6 +799,8 @@ def k_conv_fwd_blur_bits(x, w, bias, g, scale, bias_scale, slope):
     (csrc/conv_roll_blur.hip) - or None where the geometry is not the thin one it takes."""
     if g.ks != 3 or g.up or g.pool or g.bf is not None or get_compute_dtype() != 'f32' or not mask_bits_ok_plane():
         return None
+    if os.environ.get('GANLAB_ROLL_BLUR') == '0':      # A/B switch: conv kernel + blur pass
+        return None
     x, w = _c(x, 'conv input'), _c(w, 'conv weight')
     L = _lib.lib()
     y = _new(g.out_shape, x)
