@@ -88,6 +88,10 @@ SIGNATURES = {
     'ganlab_conv_s2_fwd_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_s2_fwd_aff_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
     'ganlab_conv_s2_dgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
+    'ganlab_conv_s2_down_x3_supported': (_c_int, [_GP, _c_int]),
+    'ganlab_conv_s2_down_x3_pack': (_c_ll, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    'ganlab_conv_s2_down_fwd_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f, _c_p]),
+    'ganlab_conv_s2_down_dgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _GP, _c_p]),
     'ganlab_conv_wgrad_x3_supported': (_c_int, [_GP]),
     'ganlab_conv_wgrad_x3_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),

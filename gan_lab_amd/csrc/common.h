@@ -181,6 +181,46 @@ __device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__
 }
 
 
+// the 4x3 combination matrices of the stride-2 fused layers (conv_s2.hip): K4 = M W M^T
+__device__ __forceinline__ float gl_comb_s2(int up, int a, int k) {
+  if (up) {
+    const int lo = (a == 0) ? 2 : (a == 1 ? 1 : 0), hi = (a == 0) ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 0));
+    return (k >= lo && k <= hi) ? 1.f : 0.f;
+  }
+  const int lo = (a <= 1) ? 0 : (a == 2 ? 1 : 2), hi = (a == 0) ? 0 : (a == 1 ? 1 : 2);
+  return (k >= lo && k <= hi) ? 0.5f : 0.f;
+}
+// the strided 4x4 stride-2 form of conv_x3_down.hip: [co tile 128][k-step = (ci / 8) * 4 + a][plane 3][tap column b][co 128][8];
+// K4[a][b] formed in fp32 exactly as pack.hip's stride-2 branch forms it (same operands as the exact-fp32 S kernel)
+__device__ __forceinline__ void gl_x3_down_pack_position(const float* __restrict__ w9, int up, float scale, __bf16* __restrict__ out,
+                                                         int CI, int ci, int co) {
+  const int nsteps = CI / 8 * 4;
+  const int ct = co >> 7, col = co & 127, q = ci >> 3, j = ci & 7;
+  float k9[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) k9[t] = w9[t];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float v = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v += gl_comb_s2(up, a, ky) * gl_comb_s2(up, b, kx) * k9[ky * 3 + kx];
+      v = v * scale;
+      asm volatile("" : "+v"(v));
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 mm = (__bf16)r1;
+      const __bf16 l = (__bf16)(r1 - (float)mm);
+      __bf16* base = out + (((long long)ct * nsteps + q * 4 + a) * (3 * 4 * 128)) * 8;
+      base[((0 * 4 + b) * 128 + col) * 8 + j] = h;
+      base[((1 * 4 + b) * 128 + col) * 8 + j] = mm;
+      base[((2 * 4 + b) * 128 + col) * 8 + j] = l;
+    }
+}
+
 // ---- conv.hip: mean / rstd of every (n, c) plane from per-tile sums of y and y^2 (fixed order, fp64) ---------------------------
 extern "C" int gl_tail_stats_finish(const double* spart, float* mean, float* rstd, long long planes, int chunks, double inv_hw, float eps,
                          hipStream_t st);

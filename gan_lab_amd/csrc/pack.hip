@@ -81,6 +81,16 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const ganlab_pack_desc* 
     const int co = ct * 64 + col;
     const float* w9 = up ? w + ((long long)co * d.Cin + ci) * 9 : w + ((long long)ci * d.Cin + co) * 9;
     gl_x3_up_pack_position(w9, up, d.scale, reinterpret_cast<__bf16*>(d.dst), CI, ci, co);
+  } else if (d.kind == GANLAB_PACKKIND_X3 && d.ks == 5) {      // conv_x3_down.hip, strided stride-2 form (d.up: 0 = pooled layer's
+    const int up = d.up;                                         // forward weights, 1 = up layer's input-gradient weights)
+    const int CO = up ? d.Cin : d.Cout, CI = up ? d.Cout : d.Cin;
+    if (e >= (long long)CO * CI) return;
+    const int col = (int)(e & 127);
+    const long long t = e >> 7;
+    const int ci = (int)(t % CI), ct = (int)(t / CI);
+    const int co = ct * 128 + col;
+    const float* w9 = up ? w + ((long long)ci * d.Cin + co) * 9 : w + ((long long)co * d.Cin + ci) * 9;
+    gl_x3_down_pack_position(w9, up, d.scale, reinterpret_cast<__bf16*>(d.dst), CI, ci, co);
   } else if (d.kind == GANLAB_PACKKIND_X3) {      // conv_x3.hip: three bf16 planes per weight, k-step images
     const bool dg = d.mode == GANLAB_PACK_DGRAD;
     const int CO = dg ? d.Cin : d.Cout, CI = dg ? d.Cout : d.Cin;

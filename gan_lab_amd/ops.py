@@ -231,6 +231,8 @@ def _pack_one(e):
         rc = L.ganlab_conv_pack_bf16(_p(e.w), e.out.data_ptr(), cout, cin, mode, scale, _st())
     elif kind == _KIND_X3 and ks == 4:
         rc = L.ganlab_conv_s2_x3_pack(_p(e.w), e.out.data_ptr(), cout, cin, up, scale, _st())
+    elif kind == _KIND_X3 and ks == 5:
+        rc = L.ganlab_conv_s2_down_x3_pack(_p(e.w), e.out.data_ptr(), cout, cin, up, scale, _st())
     elif kind == _KIND_X3:
         rc = L.ganlab_conv_x3_pack(_p(e.w), e.out.data_ptr(), cout, cin, mode, scale, _st())
     else:
@@ -268,7 +270,7 @@ def _repack_range(r):
             d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = kind, cout, cin, ks, mode, up, scale, \
                 total, blocks
             # one thread per weight position, all of its taps (csrc/pack.hip pack_many_kernel)
-            blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else ((48 if ks == 4 else 27) if kind == _KIND_X3 else ks * ks))) + 255) // 256
+            blocks += (total // (16 if kind == _KIND_S2 else (9 if kind == _KIND_BF16 else ((48 if ks >= 4 else 27) if kind == _KIND_X3 else ks * ks))) + 255) // 256
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         if tab is not None:
             _PACK_GEN[0] += 1       # the old table's memory goes back to the allocator
@@ -402,6 +404,37 @@ def _wgrad_x3(gy, x, s_, t_, gw, g, scale):
     check(L.ganlab_conv_wgrad_x3(_p(gy), _p(x), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
           'conv_wgrad_x3')
     return gw
+
+
+def x3_s2_down_ok(g, dgrad=False):
+    """The strided stride-2 form on the split-product kernel: a pooled layer's forward, an up layer's input gradient."""
+    if not _X3[0] or not g.s2:
+        return False
+    if (g.up if dgrad else g.pool) != 1:
+        return False
+    co = g.Cin if dgrad else g.Cout
+    hl, wl = (g.Hin, g.Win) if dgrad else (g.Hin // 2, g.Win // 2)
+    if g.N * (hl // 8) * (wl // 16) * (co // 128) < _X3_MIN_TILES:
+        return False
+    return bool(_lib.lib().ganlab_conv_s2_down_x3_supported(g.ref(), 1 if dgrad else 0))
+
+
+def _packed_x3_s2_down(w, up, scale):
+    """``up``: 0 = a pooled layer's forward weights, 1 = an up layer's input-gradient weights."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), int(up), float(scale), 'x3s2d')
+    hit = _pack_lookup(key)
+    if hit is not None:
+        return hit
+    cout, cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    n = L.ganlab_conv_s2_down_x3_pack(None, None, cout, cin, int(up), scale, None)
+    if n <= 0:
+        raise _lib.GanlabLibraryError(f'conv_s2_down_x3_pack size query failed ({n}) for weight {tuple(w.shape)}')
+    out = torch.empty((n,), dtype=torch.bfloat16, device=w.device)
+    rc = L.ganlab_conv_s2_down_x3_pack(_p(w), out.data_ptr(), cout, cin, int(up), scale, _st())
+    if rc != n:
+        raise _lib.GanlabLibraryError(f'conv_s2_down_x3_pack failed ({rc})')
+    return _pack_store(key, w, out, (_KIND_X3, cout, cin, 5, 0, int(up), float(scale), int(n)))
 
 
 def _packed_x3_s2(w, up, scale):
@@ -613,6 +646,10 @@ def k_conv_fwd(x, w, bias, g, scale, bias_scale=1.0, act=ACT_NONE, slope=0.2):
         check(L.ganlab_conv_fwd_bf16(_p(xin), wp.data_ptr(), _p(bias), _p(y), ctypes.byref(geom), bias_scale,
                                      act, slope, _st()), 'conv_fwd_bf16')
         return y
+    if x3_s2_down_ok(g):
+        check(_lib.lib().ganlab_conv_s2_down_fwd_x3(_p(x), _packed_x3_s2_down(w, 0, scale).data_ptr(), _p(bias), _p(y), g.ref(),
+                                                    bias_scale, act, slope, _st()), 'conv_s2_down_fwd_x3')
+        return y
     if x3_s2_ok(g):
         check(_lib.lib().ganlab_conv_s2_fwd_x3(_p(x), _packed_x3_s2(w, 1, scale).data_ptr(), _p(bias), _p(y), g.ref(), bias_scale,
                                                act, slope, _st()), 'conv_s2_fwd_x3')
@@ -675,6 +712,11 @@ def k_conv_dgrad(gy, w, g, scale):
             return run(g.bf_fused, _new(g.in_shape, gy))
         gxv = run(g.bf, _new((g.N, g.Cin, g.bf.Hin, g.bf.Win), gy))
         return k_pool2(gxv, 1.0) if g.up else gxv
+    if x3_s2_down_ok(g, True):
+        gx = _new(g.in_shape, gy)
+        check(_lib.lib().ganlab_conv_s2_down_dgrad_x3(_p(gy), _packed_x3_s2_down(w, 1, scale).data_ptr(), _p(gx), g.ref(), _st()),
+              'conv_s2_down_dgrad_x3')
+        return gx
     if x3_s2_ok(g, True):
         gx = _new(g.in_shape, gy)
         check(_lib.lib().ganlab_conv_s2_dgrad_x3(_p(gy), _packed_x3_s2(w, 0, scale).data_ptr(), _p(gx), g.ref(), _st()),

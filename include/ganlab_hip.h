@@ -211,6 +211,15 @@ int ganlab_conv_s2_fwd_x3(const float* x, const void* wp, const float* bias, flo
 int ganlab_conv_s2_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias,
                               float* y, const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream);
 int ganlab_conv_s2_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
+/* ... and their strided form (csrc/conv_x3_down.hip; the exact-fp32 S kernel of csrc/conv_s2.hip): ganlab_conv_s2_fwd_f32 of a
+ * pooled layer (geom.pool = 1; dgrad = 0) and ganlab_conv_s2_dgrad_f32 of an up layer (geom.up = 1; dgrad = 1); low resolution
+ * H % 8 == 0, W % 16 == 0, contraction channels % 16 == 0, output channels % 128 == 0.  pack: `up` = 0 a pooled layer's forward
+ * weights, 1 an up layer's input-gradient weights (48*Cout*Cin bf16 elements; ganlab_pack_desc: kind X3, ks = 5, same `up`). */
+int ganlab_conv_s2_down_x3_supported(const ganlab_conv_geom* g, int dgrad);
+long long ganlab_conv_s2_down_x3_pack(const float* w, void* out, int Cout, int Cin, int up, float scale, void* stream);
+int ganlab_conv_s2_down_fwd_x3(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g,
+                               float bias_scale, int act, float slope, void* stream);
+int ganlab_conv_s2_down_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream);
 /* weight gradient of a plain 3x3 layer (csrc/conv_x3_wgrad.hip): ganlab_conv_wgrad_f32, or with aff_s / aff_t non-null
  * ganlab_conv_wgrad_aff_f32, as split products; H a power of two, W % 32 == 0, Cin % 64 == 0, Cout % 32 == 0.  Deterministic
  * (per-workgroup slots in the workspace, fixed-order reduction). */

@@ -351,3 +351,63 @@ def test_x3_weight_gradient_is_deterministic(ops):
     a = ops.k_conv_wgrad(gy, x, geom, 1.0).clone()
     b = ops.k_conv_wgrad(gy, x, geom, 1.0)
     assert torch.equal(a, b)
+
+
+# ---- the strided stride-2 form: a pooled layer's forward, an up layer's input gradient -----------------------------------------------
+SD_CASES = [(2, 64, 128, 16, 16), (3, 128, 256, 8, 32), (5, 32, 128, 24, 16), (2, 256, 128, 16, 48)]     # N, Cin, Cout, Hl, Wl
+
+
+@pytest.mark.parametrize('case', SD_CASES)
+def test_x3_pooled_layer_forward(ops, case):
+    n, ci, co, hl, wl = case
+    g = torch.Generator().manual_seed(51 + ci + n)
+    x = torch.randn(n, ci, 2 * hl, 2 * wl, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    b = torch.randn(co, generator=g)
+    geom = ops.Geom(n, ci, 2 * hl, 2 * wl, co, 3, 1, pool=1)
+    scale = 1.0 / (3 * ci ** 0.5)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        assert ops.x3_s2_down_ok(geom)
+        y3 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+        assert 'conv_x3_down_kernel' in launched(ops)
+        prev = ops.set_x3(False)
+        try:
+            y1 = ops.k_conv_fwd(x.cuda(), wt.cuda(), b.cuda(), geom, scale, 0.5, ops.ACT_LRELU, 0.2)
+            assert 'conv_x3_down_kernel' not in launched(ops)
+        finally:
+            ops.set_x3(prev)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    yd = F.leaky_relu(F.avg_pool2d(F.conv2d(x.double(), wt.double() * scale, None, padding=1), 2) + 0.5 * b.double().view(1, -1, 1, 1), 0.2)
+    assert_close(y3.cpu(), yd, TOL, 'x3 pooled layer forward vs float64')
+    assert_close(y3.cpu(), y1.cpu(), TOL, 'x3 pooled layer forward vs exact-fp32 kernel')
+    assert rms_rel(y3, yd) <= 1.1 * rms_rel(y1, yd), (rms_rel(y3, yd), rms_rel(y1, yd))
+
+
+@pytest.mark.parametrize('case', SD_CASES)
+def test_x3_up_layer_input_gradient(ops, case):
+    n, co_, ci_, hl, wl = case          # the up layer: ci_ -> co_ channels (GEMM contracts co_), input hl x wl
+    cin, cout = ci_, co_
+    g = torch.Generator().manual_seed(61 + cin + n)
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    gy = torch.randn(n, cout, 2 * hl, 2 * wl, generator=g)
+    geom = ops.Geom(n, cin, hl, wl, cout, 3, 1, up=1)
+    scale = 1.0 / (3 * cin ** 0.5)
+    old_min, ops._X3_MIN_TILES = ops._X3_MIN_TILES, 1
+    try:
+        assert ops.x3_s2_down_ok(geom, True)
+        gx3 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+        assert 'conv_x3_down_kernel' in launched(ops)
+        prev = ops.set_x3(False)
+        try:
+            gx1 = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), geom, scale)
+        finally:
+            ops.set_x3(prev)
+    finally:
+        ops._X3_MIN_TILES = old_min
+    xd = torch.zeros(n, cin, hl, wl, dtype=torch.float64, requires_grad=True)
+    gxd, = torch.autograd.grad(F.conv2d(F.interpolate(xd, scale_factor=2, mode='nearest'), wt.double() * scale, padding=1), xd, gy.double())
+    assert_close(gx3.cpu(), gxd, TOL, 'x3 up layer input gradient vs float64')
+    assert_close(gx3.cpu(), gx1.cpu(), TOL, 'x3 up layer input gradient vs exact-fp32 kernel')
+    assert rms_rel(gx3, gxd) <= 1.1 * rms_rel(gx1, gxd), (rms_rel(gx3, gxd), rms_rel(gx1, gxd))
