@@ -22,11 +22,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XW_CO = 32, XW_CI = 64;
-constexpr int XW_GROW = 3 * 6 * XW_CO;             // units (16 B) of a gy row image: [plane][unit 6: px -8 .. 39][co 32]
-constexpr int XW_XROW = 3 * 4 * XW_CI;             // units of an X row image: [plane][unit 4][ci 64]
+// LDS images are channel-major with an ODD-ish channel pitch: a fragment read takes 16 channels x 16 bytes (pitch 7 resp. 5 units
+// = 112 / 80 bytes: the 16 lanes land on 16 disjoint groups of four banks), a staging store 8 bytes per lane along a channel's
+// pixels.  (Pixel-major images - channels 16 bytes apart - made every staging store a 16- to 32-way bank conflict: 56 % of the
+// kernel's LDS cycles, profiles/r05_x3_pmc.txt.)
+constexpr int XW_GP = 7, XW_XP = 5;                // units per channel: gy 6 (px -8 .. 39) + 1, X 4 + 1
+constexpr int XW_GPL = XW_CO * XW_GP, XW_XPL = XW_CI * XW_XP;      // one bf16 plane of a row image
+constexpr int XW_GROW = 3 * XW_GPL;                // units (16 B) of a gy row image: [plane][co 32][unit 7]
+constexpr int XW_XROW = 3 * XW_XPL;                // units of an X row image: [plane][ci 64][unit 5]
 constexpr int XW_XOFF = 2 * XW_GROW;               // two gy buffers, then four ring slots and the zero slot
 constexpr int XW_ZERO = 4;
-constexpr int XW_LDS = 2 * XW_GROW + 5 * XW_XROW;  // 4992 units = 79,872 bytes
+constexpr int XW_LDS = 2 * XW_GROW + 5 * XW_XROW;  // 6144 units = 98,304 bytes
 constexpr int XW_DUMP = 32;                        // k-steps per hi*hi chain
 
 #define XW_MFMA(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
@@ -98,9 +104,9 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
   //      every wave's operation count is the same), X (ci = tid / 8, pixels x0 + 4q, q = tid % 8) -----------------------------
   const bool g_item = tid < 320;
   const int g_co = g_item ? tid / 10 : 0, g_q = g_item ? tid % 10 : 0;
-  const int g_dst = ((((g_q + 1) >> 1) * XW_CO + g_co) * 16 + ((g_q + 1) & 1) * 8);        // + plane * 6 * 32 * 16
+  const int g_dst = ((g_co * XW_GP + ((g_q + 1) >> 1)) * 16 + ((g_q + 1) & 1) * 8);          // + plane * XW_GPL * 16
   const int x_ci = tid >> 3, x_q = tid & 7;
-  const int x_dst = (((x_q >> 1) * XW_CI + x_ci) * 16 + (x_q & 1) * 8);                    // + plane * 4 * 64 * 16
+  const int x_dst = ((x_ci * XW_XP + (x_q >> 1)) * 16 + (x_q & 1) * 8);                      // + plane * XW_XPL * 16
   float a_s = 1.f, a_t = 0.f;                       // AFF: scale / shift of this thread's input channel in the current image
   int aff_n = -1;
 
@@ -128,8 +134,8 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
     xw_split4(v, h, m, l);
     unsigned char* d = reinterpret_cast<unsigned char*>(lds + buf * XW_GROW) + g_dst;
     *reinterpret_cast<u32x2*>(d) = h;
-    *reinterpret_cast<u32x2*>(d + 6 * XW_CO * 16) = m;
-    *reinterpret_cast<u32x2*>(d + 2 * 6 * XW_CO * 16) = l;
+    *reinterpret_cast<u32x2*>(d + XW_GPL * 16) = m;
+    *reinterpret_cast<u32x2*>(d + 2 * XW_GPL * 16) = l;
   };
   auto x_store = [&](f32x4 v, int slot, int f) {
     if constexpr (AFF) {
@@ -147,8 +153,8 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
     xw_split4(v, h, m, l);
     unsigned char* d = reinterpret_cast<unsigned char*>(lds + XW_XOFF + slot * XW_XROW) + x_dst;
     *reinterpret_cast<u32x2*>(d) = h;
-    *reinterpret_cast<u32x2*>(d + 4 * XW_CI * 16) = m;
-    *reinterpret_cast<u32x2*>(d + 2 * 4 * XW_CI * 16) = l;
+    *reinterpret_cast<u32x2*>(d + XW_XPL * 16) = m;
+    *reinterpret_cast<u32x2*>(d + 2 * XW_XPL * 16) = l;
   };
 
   f32x4 accS[9], accH[9], accT[9];
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
   XW_VALU_SETTLE(accS);
   XW_VALU_SETTLE(accH);
   // fragment addresses (units): gy centre unit 1 + kg of row image `buf`; X unit kg of slot
-  const int laneG = (1 + kg) * XW_CO + wc * 16 + l16;
-  const int laneX = XW_XOFF + kg * XW_CI + wi * 16 + l16;
+  const int laneG = (wc * 16 + l16) * XW_GP + 1 + kg;
+  const int laneX = XW_XOFF + (wi * 16 + l16) * XW_XP + kg;
 
   u32x4 gc[3];              // raw gy centre units of the NEXT k-step (planes)
   unsigned gp_[3], gn_[3];  // ... and the neighbouring dwords: last of the unit before, first of the unit after
@@ -168,10 +174,10 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
   auto g_frags = [&](int buf) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      const int u = buf * XW_GROW + pl * 6 * XW_CO + laneG;
+      const int u = buf * XW_GROW + pl * XW_GPL + laneG;
       gc[pl] = lds[u];
-      gp_[pl] = reinterpret_cast<const unsigned*>(lds + u - XW_CO)[3];
-      gn_[pl] = reinterpret_cast<const unsigned*>(lds + u + XW_CO)[0];
+      gp_[pl] = reinterpret_cast<const unsigned*>(lds + u - 1)[3];
+      gn_[pl] = reinterpret_cast<const unsigned*>(lds + u + 1)[0];
     }
   };
   auto a_build = [&]() {     // kx = 0: gy[px' + 1]; kx = 1: gy[px']; kx = 2: gy[px' - 1]
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_x3_wgrad_kernel(XWArgs p) {
   };
   auto x_frags = [&](int slot, int set) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bX[set][pl] = __builtin_bit_cast(bf16x8, lds[laneX + slot * XW_XROW + pl * 4 * XW_CI]);
+    for (int pl = 0; pl < 3; ++pl) bX[set][pl] = __builtin_bit_cast(bf16x8, lds[laneX + slot * XW_XROW + pl * XW_XPL]);
   };
 
   // ---- prologue: the zero slot; gy row 0 and X rows 0, 1 in LDS; rows (gy 1, X 2) and (gy 2, X 3) in flight ---------------------

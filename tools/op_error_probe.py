@@ -15,7 +15,11 @@ def err(a, ref):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(16)
-    cases = [('fwd', 2, 16, 16, 256, 256, 0, 0), ('fwd', 2, 16, 16, 256, 224, 0, 0), ('fwd', 2, 32, 32, 128, 128, 0, 0),
+    ops._X3_MIN_TILES = 1          # the split-product kernels on these small batches too (the step uses them at batch 32)
+    cases = [('fwd', 2, 64, 64, 128, 128, 0, 0), ('fwd', 2, 256, 256, 32, 32, 0, 0), ('dgrad', 2, 128, 128, 64, 64, 0, 0),
+             ('dgrad', 2, 512, 512, 16, 16, 0, 0), ('fwd', 2, 128, 64, 32, 32, 1, 0), ('dgrad', 2, 64, 128, 64, 64, 0, 1),
+             ('fwd', 2, 64, 128, 64, 64, 0, 1), ('dgrad', 2, 256, 128, 16, 16, 1, 0),
+             ('fwd', 2, 16, 16, 256, 256, 0, 0), ('fwd', 2, 16, 16, 256, 224, 0, 0), ('fwd', 2, 32, 32, 128, 128, 0, 0),
              ('fwd', 2, 64, 64, 64, 64, 0, 0), ('fwd', 2, 512, 512, 16, 16, 0, 0),
              ('fwd', 2, 32, 16, 128, 128, 1, 0), ('fwd', 2, 16, 32, 256, 256, 0, 1), ('fwd', 2, 64, 32, 64, 64, 1, 0),
              ('dgrad', 2, 16, 16, 256, 256, 0, 0), ('dgrad', 2, 32, 16, 128, 128, 1, 0), ('dgrad', 2, 16, 32, 256, 256, 0, 1)]
@@ -28,6 +32,11 @@ def main():
             xi = F.interpolate(xx, scale_factor=2, mode='nearest') if up else xx
             y = F.conv2d(xi, ww, padding=1)
             return F.avg_pool2d(y, 2) if pool else y
+        prev = ops.set_x3(False)          # first the exact-fp32 MFMA kernels ...
+        try:
+            hx = ops.k_conv_fwd(x.cuda(), wt.cuda(), None, g, 1.0) if kind == 'fwd' else None
+        finally:
+            ops.set_x3(prev)
         if kind == 'fwd':
             hip = ops.k_conv_fwd(x.cuda(), wt.cuda(), None, g, 1.0)
             name, _ = _lib.last_launch()
@@ -35,15 +44,22 @@ def main():
             cpu = ref_fwd(x, wt)
         else:
             gy = torch.randn(*g.out_shape)
+            prev = ops.set_x3(False)
+            try:
+                hx = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), g, 1.0)
+            finally:
+                ops.set_x3(prev)
             hip = ops.k_conv_dgrad(gy.cuda(), wt.cuda(), g, 1.0)
             name, _ = _lib.last_launch()
             xd = x.double().requires_grad_(True)
             exact, = torch.autograd.grad(ref_fwd(xd, wt.double()), xd, gy.double())
             xf = x.clone().requires_grad_(True)
             cpu, = torch.autograd.grad(ref_fwd(xf, wt), xf, gy)
-        eh, ec = err(hip, exact), err(cpu, exact)
+        eh, ec, ex = err(hip, exact), err(cpu, exact), err(hx, exact)
+        x3 = 'conv_x3' in name
         print(f'{kind:5s} {ci:3d}->{co:3d} {h}x{w} up{up} pool{pool}: HIP rms {eh[0]:.2e} max {eh[1]:.2e} | CPU fp32 rms {ec[0]:.2e} max {ec[1]:.2e} '
-              f'| ratio rms {eh[0] / ec[0]:.2f}  [{name.split("(")[0][-48:]}]', flush=True)
+              f'| ratio rms {eh[0] / ec[0]:.2f}' + (f' (3xbf16; exact-fp32 kernel {ex[0] / ec[0]:.2f})' if x3 else '') +
+              f'  [{name.split("(")[0][-48:]}]', flush=True)
 
 
 if __name__ == '__main__':
