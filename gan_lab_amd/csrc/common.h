@@ -143,11 +143,14 @@ __device__ __forceinline__ void gl_x3_pack_position(const float* __restrict__ w9
   }
 }
 
-// the transposed 4x4 stride-2 form of conv_x3.hip (layout and tap sets: see conv_x3_up_kernel there)
+// the transposed 4x4 stride-2 form (conv_x3_up.hip): [co tile 64][row parity py][k-step = ci / 8][plane 3][tap kg = ty * 2 + tx][column
+// parity px][co 64][8]; tap (ty, tx) of parity (py, px) sums the 3x3 weights of rows R(py, ty) x columns R(px, tx): up forward
+// R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}; the input gradient of the pooled conv takes the flipped sets
+// (k -> 2 - k) and 1/2 per axis.  `up`: 1 = forward of the up layer (GEMM rows = Cin), 0 = input gradient of the pooled layer.
 __device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__ w9, int up, float scale, __bf16* __restrict__ out,
-                                                    int CI, int ci, int co) {
-  const int nst = CI / 16;
-  const int ct = co >> 6, col = co & 63, half = ci >> 4, g = (ci >> 3) & 1, j = ci & 7;
+                                                       int CI, int ci, int co) {
+  const int nsteps = CI / 8;
+  const int ct = co >> 6, col = co & 63, j = ci & 7;
 #pragma unroll
   for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -172,14 +175,13 @@ __device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__
           const float r1 = v - (float)h;
           const __bf16 mm = (__bf16)r1;
           const __bf16 l = (__bf16)(r1 - (float)mm);
-          const int kgq = tx * 2 + g;
-          __bf16* base = out + ((((long long)(ct * 2 + py) * 2 + px) * nst + half) * 2 + ty) * (3 * 4 * 64) * 8;
-          base[((0 * 4 + kgq) * 64 + col) * 8 + j] = h;
-          base[((1 * 4 + kgq) * 64 + col) * 8 + j] = mm;
-          base[((2 * 4 + kgq) * 64 + col) * 8 + j] = l;
+          __bf16* base = out + ((((long long)ct * 2 + py) * nsteps + (ci >> 3)) * (3 * 4 * 128)) * 8;
+          const int kgq = ty * 2 + tx;
+          base[((0 * 4 + kgq) * 128 + px * 64 + col) * 8 + j] = h;
+          base[((1 * 4 + kgq) * 128 + px * 64 + col) * 8 + j] = mm;
+          base[((2 * 4 + kgq) * 128 + px * 64 + col) * 8 + j] = l;
         }
 }
-
 
 // the 4x3 combination matrices of the stride-2 fused layers (conv_s2.hip): K4 = M W M^T
 __device__ __forceinline__ float gl_comb_s2(int up, int a, int k) {

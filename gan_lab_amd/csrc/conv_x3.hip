@@ -482,314 +482,6 @@ bool x3_ok(const ganlab_conv_geom* g, int dgrad) {
   return CI % 64 == 0 && CO % X3_NT == 0 && g->Hin % 16 == 0 && g->Win % 16 == 0 && g->N > 0;
 }
 
-// ---- the transposed 4x4 stride-2 form: conv3x3(Upsample2x(x)) forward and the input gradient of AvgPool2(conv3x3(x)) ----------
-// (stylegan/architectures.py:292-334, progan/architectures.py:261-284; the exact-fp32 form is csrc/conv_s2.hip's T kernel).
-// Output pixel (2y + py, 2x + px) of parity (py, px) is a 2 x 2-tap convolution of the LOW-resolution input around (y, x):
-// rows y - 1 + py + ty, ty = 0, 1, with the 3x3 weights of the rows that land there summed in fp32 at pack time - 16 instead
-// of 36 products per low-resolution pixel.  One virtual tile = (16 x 16 low-res pixels, 64 output channels, one parity): the
-// same halo patch and wave layout as conv_x3_fwd_kernel, 4 taps per parity -> k-step = (2 taps) x (16 channels), two k-steps
-// = one stage = ONE half patch, so a half is stored (and the next but one loaded) every stage and the ring of three slots
-// simply rotates.  The four parities of a pixel tile run back to back (the patch is re-read from L2).
-struct X3UpTile { int n, oy0, ox0, co_t, py, px; };
-
-template <int FORM>
-__global__ __launch_bounds__(512) void conv_x3_up_kernel(X3Args p) {
-  constexpr bool AFF = FORM == X3_AFF;
-  constexpr int NLOADS = AFF ? 6 : 4;
-  __shared__ __attribute__((aligned(16))) u32x4 lds[X3_LDS];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 1, wn = wv & 1;
-  const int l16 = lane & 15, kg = lane >> 4, lane16 = lane * 16;
-  const int plane = p.H * p.W;                  // LOW-resolution plane (the input)
-  const int nstages = p.CI / 16, ndc = p.CI / 64;
-  const int G = gridDim.x;
-
-  auto decode = [&](int t) {
-    X3UpTile c;
-    c.co_t = t % p.tiles_co; t /= p.tiles_co;
-    c.px = t & 1; c.py = (t >> 1) & 1; t >>= 2;
-    c.ox0 = (t % p.tiles_x) * 16; t /= p.tiles_x;
-    c.oy0 = (t % p.tiles_y) * 16;
-    c.n = t / p.tiles_y;
-    return c;
-  };
-  using X3Tile = X3UpTile;
-
-  // ---- activation staging item of this thread: (channel group g, row r, 4-column group cg, channel quad cq) ----------
-  // columns ox0 - 4 + 4cg .. + 3; halo column of element i = 4cg - 3 + i (valid 0 .. 17: cg 0 keeps i = 3, cg 5 keeps i = 0)
-  // One register holds the item: bits 0-14 byte offset of element 0 / plane 0 in a half slot + 48 (>= 0), 16-17 first kept
-  // element, 18-20 one past the last, 21-25 patch row, 26-28 column group, 29-30 channel quad index (g * 2 + cq).
-  const bool a_item = tid < 432;
-  int a_pack;
-  {
-    const int e = a_item ? tid : 0;
-    const int cq = e & 1;
-    int t = e >> 1;
-    const int cg = t % 6; t /= 6;
-    const int r = t % 18, g = t / 18;
-    const int unit48 = ((g * 3) * X3_PL + r * 18 + 4 * cg) * 16 + cq * 8;     // + 48: the element-0 unit of cg = 0 is 3 units before
-    a_pack = unit48 | ((cg == 0 ? 3 : 0) << 16) | ((cg == 5 ? 1 : 4) << 18) | (r << 21) | (cg << 26) | ((g * 2 + cq) << 29);
-  }
-  const int cstride = plane * 4;
-  // TWO register sets: a half patch is requested two stages before it is split (one stage = 96 MFMAs per wave is not always
-  // an HBM round trip), so two are in flight
-  f32x4 arA[4], arB[4];
-  f32x4 svA, tvA, svB, tvB;                          // AFF: scale / shift of the item's four channels (zeros outside the image)
-  auto a_load_to = [&](f32x4 (&ar)[4], f32x4& a_sv, f32x4& a_tv, const X3Tile& c, int half) {     // channels 16 half + 8g + 4cq + j
-    const u32x4 rs = x3_rsrc(p.x + (long long)c.n * p.CI * plane, (unsigned)((long long)p.CI * plane * 4));
-    int pk = a_pack;
-    asm volatile("" : "+v"(pk));      // offsets computed HERE, not hoisted out of the k-loop and spilled
-    const int ry = ((pk >> 21) & 31) - 1, rx = ((pk >> 26) & 7) * 4 - 4, a_ch = ((pk >> 29) & 3) * 4;
-    const bool ok = a_item && (unsigned)(c.oy0 + ry) < (unsigned)p.H && (unsigned)(c.ox0 + rx) < (unsigned)p.W;
-    const int off = ok ? (a_ch * plane + (c.oy0 + ry) * p.W + c.ox0 + rx) * 4 : (int)0x80000000;
-    const int soff = half * 16 * plane * 4;
-    if (X3_EXP & 4) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x3_ld(ar[j], rs, off + j * cstride, soff);
-    if constexpr (AFF) {       // an item outside the image reads zeros for s and t as well: 0 * 0 + 0 keeps the padding zero
-      const unsigned tab = (unsigned)((long long)p.N * p.CI * 4);
-      const u32x4 rss = x3_rsrc(p.aff_s, tab), rst = x3_rsrc(p.aff_t, tab);
-      const int o = ok ? a_ch * 4 : (int)0x80000000;
-      const int so = (c.n * p.CI + half * 16) * 4;
-      x3_ld(a_sv, rss, o, so);
-      x3_ld(a_tv, rst, o, so);
-    }
-  };
-  auto a_wait = [&](int set, auto younger) {
-    constexpr int Y = decltype(younger)::value;
-    if (set == 0) { if constexpr (AFF) x3_ld_wait<Y>(arA, svA, tvA); else x3_ld_wait<Y>(arA); }
-    else { if constexpr (AFF) x3_ld_wait<Y>(arB, svB, tvB); else x3_ld_wait<Y>(arB); }
-  };
-  // one pixel (of the item's four) per call: the split is vector-ALU work that belongs BETWEEN the rows' MFMA blocks, not in
-  // front of the stage's barrier where every wave would wait for it (ablation: 19 % of the kernel there)
-  auto a_store_from = [&](const f32x4 (&ar)[4], const f32x4& a_sv, const f32x4& a_tv, int slot, int i) {
-    if (!a_item || (X3_EXP & 1)) return;
-    int pk = a_pack;
-    asm volatile("" : "+v"(pk));
-    const int a_i0 = (pk >> 16) & 3, a_i1 = (pk >> 18) & 7;
-    unsigned char* dst = reinterpret_cast<unsigned char*>(lds + X3_AOFF + slot * X3_HALF) + ((pk & 0x7fff) - 48);
-    if (i < a_i0 || i >= a_i1) return;
-    bf16x4 h, m, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = i == 0 ? ar[j].x : i == 1 ? ar[j].y : i == 2 ? ar[j].z : ar[j].w;
-      if constexpr (AFF) v = fmaf(v, j == 0 ? a_sv.x : j == 1 ? a_sv.y : j == 2 ? a_sv.z : a_sv.w,
-                                  j == 0 ? a_tv.x : j == 1 ? a_tv.y : j == 2 ? a_tv.z : a_tv.w);
-      h[j] = (__bf16)v;
-      const float r1 = v - x3_up(h[j]);
-      m[j] = (__bf16)r1;
-      l[j] = (__bf16)(r1 - x3_up(m[j]));
-    }
-    *reinterpret_cast<u32x2*>(dst + i * 16) = __builtin_bit_cast(u32x2, h);
-    *reinterpret_cast<u32x2*>(dst + i * 16 + X3_PL * 16) = __builtin_bit_cast(u32x2, m);
-    *reinterpret_cast<u32x2*>(dst + i * 16 + 2 * X3_PL * 16) = __builtin_bit_cast(u32x2, l);
-  };
-  auto a_load = [&](int set, const X3Tile& c, int half) {
-    if (set == 0) a_load_to(arA, svA, tvA, c, half); else a_load_to(arB, svB, tvB, c, half);
-  };
-  auto a_store_px = [&](int set, int slot, int i) {
-    if (set == 0) a_store_from(arA, svA, tvA, slot, i); else a_store_from(arB, svB, tvB, slot, i);
-  };
-
-  // ---- weight staging: LDS-DMA, the packed stage image is the LDS image; 24 pieces of 1 KB per stage, 3 per wave ----
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u32x4*>(p.wp), 0, (unsigned)((long long)p.tiles_co * 4 * nstages * X3_WSTAGE * 16), 0x00020000);
-  auto w_dma = [&](const X3Tile& c, int st, int buf) {
-    const int soff = (((c.co_t * 2 + c.py) * 2 + c.px) * nstages + st) * (X3_WSTAGE * 16) + wv * 3072;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + X3_WOFF + buf * X3_WSTAGE + wv * 192 + i * 64),
-                                               16, lane16, soff + i * 1024, 0, 0);
-  };
-
-  f32x4 accS[4][2], accH[4][2], accT[4][2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f}; accH[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f}; accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-  const int laneA = X3_AOFF + (kg & 1) * 3 * X3_PL + (4 * wm) * 18 + l16;
-  const int laneB = X3_WOFF + kg * X3_NT + wn * 32 + l16;
-  const bool khi = kg >= 2;
-  const int khi_i = khi ? 1 : 0;
-
-  bf16x8 aF[2][3], bF[2][2][3];
-  auto a_frags = [&](int off, int m) {       // row m of a k-step -> register set m & 1
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) aF[m & 1][pl] = __builtin_bit_cast(bf16x8, lds[off + pl * X3_PL + m * 18]);
-  };
-  auto b_frags = [&](int buf, int step1, int nn, int set) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      bF[set][nn][pl] = __builtin_bit_cast(bf16x8, lds[laneB + buf * X3_WSTAGE + step1 * X3_WSTEP + pl * 4 * X3_NT + nn * 16]);
-  };
-
-
-  int tile = gl_xcd_remap(blockIdx.x, G);
-  if (tile >= p.ntiles) return;
-  X3Tile cur = decode(tile);
-  int sa = 0, sb = 1, sc = 2;          // ring slots of the half being multiplied, the next one, the one after
-
-  // ---- prologue: half 0 in LDS, halves 1 and 2 in registers, weight stages 0 (landed) and 1 (in flight) ---------------------------
-  w_dma(cur, 0, 0);
-  a_load(0, cur, 0);
-  a_wait(0, std::integral_constant<int, 0>{});
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { a_store_px(0, sa, i); __builtin_amdgcn_sched_barrier(0); }
-  x3_barrier<0>();
-  w_dma(cur, 1, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  a_load(1, cur, 1);            // stored in stage 0
-  a_load(0, cur, 2);            // stored in stage 1
-  int offA = laneA + sa * X3_HALF + cur.py * 18 + cur.px + khi_i;       // step 0: taps (0, 0) | (0, 1)
-  a_frags(offA, 0);
-  b_frags(0, 0, 0, 0);
-  b_frags(0, 0, 1, 0);
-
-  int st = 0, gst = 0;
-  for (;;) {
-    const int ntile = tile + G;
-    const bool nvalid = ntile < p.ntiles;
-    const X3Tile nxt = decode(nvalid ? ntile : tile);
-    for (int dc = 0; dc < ndc; ++dc) {
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const int j = s8 >> 1, par = s8 & 1;
-        const int buf = (gst + j) & 1;
-        const int cb = s8 & 1;
-        const int hs = st + j;                              // this stage = this half of the tile
-        const bool has_next = hs + 1 < nstages || par == 0 || nvalid;    // a k-step follows this one
-        // next k-step: the second tap row of this half (par == 0) or the first of the next half; the tile after the last half
-        const bool wrap = par == 1 && hs + 1 == nstages;
-        const int npy = wrap ? nxt.py : cur.py, npx = wrap ? nxt.px : cur.px;
-        int la = laneA;
-        asm volatile("" : "+v"(la));
-        const int offN = la + (par == 0 ? sa : sb) * X3_HALF + (npy + (par == 0 ? 1 : 0)) * 18 + npx + khi_i;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          if (m < 3) a_frags(offA, m + 1);
-          else if (has_next) a_frags(offN, 0);
-          if (par == 0) {
-            if (m == 0) b_frags(buf, 1, 0, cb ^ 1);
-            if (m == 1) b_frags(buf, 1, 1, cb ^ 1);
-          } else {
-            if (m == 1 && has_next) b_frags(buf ^ 1, 0, 0, cb ^ 1);
-            if (m == 2 && has_next) b_frags(buf ^ 1, 0, 1, cb ^ 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int nn = 0; nn < 2; ++nn) {
-            X3_MFMA(accS[m][nn], aF[m & 1][2], bF[cb][nn][0]);
-            X3_MFMA(accS[m][nn], aF[m & 1][0], bF[cb][nn][2]);
-            X3_MFMA(accS[m][nn], aF[m & 1][1], bF[cb][nn][1]);
-            X3_MFMA(accS[m][nn], aF[m & 1][1], bF[cb][nn][0]);
-            X3_MFMA(accS[m][nn], aF[m & 1][0], bF[cb][nn][1]);
-            X3_MFMA(accH[m][nn], aF[m & 1][0], bF[cb][nn][0]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (par == 0) {      // the next half goes to LDS one pixel of every item behind each row (register set (stage + 1) & 1)
-            if (hs + 1 < nstages || nvalid) {
-              // behind this half's loads: the DMA of the stage in between (3) and, where there is a half two stages on, its loads
-              if (m == 0) { if (hs + 2 < nstages || nvalid) a_wait((j + 1) & 1, std::integral_constant<int, 3 + NLOADS>{});
-                            else a_wait((j + 1) & 1, std::integral_constant<int, 3>{}); }
-              a_store_px((j + 1) & 1, sb, m);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (par == 1 && m == 0) {
-            // ---- the stage's barrier; behind it the weights two stages on and the half patch three stages on are requested
-            //      (the barrier waits for the DMA of the stage before: all but the loads issued behind it) -----------------------
-            if (hs + 2 < nstages || nvalid) x3_barrier<NLOADS>(); else x3_barrier<0>();
-            {
-              const int s2 = hs + 2;
-              if (s2 < nstages) w_dma(cur, s2, buf);
-              else if (nvalid) w_dma(nxt, s2 - nstages, buf);
-              __builtin_amdgcn_sched_barrier(0);
-              const int s3 = hs + 3;
-              if (s3 < nstages) a_load((j + 1) & 1, cur, s3);
-              else if (nvalid) a_load((j + 1) & 1, nxt, s3 - nstages);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        offA = offN;
-        if (par == 1) { const int t_ = sa; sa = sb; sb = sc; sc = t_; }      // the ring moves on with every stage
-      }
-      st += 4;
-      gst += 4;
-      // 64 channels x 4 taps = 256 terms: close the hi*hi chain
-      X3_MFMA_DRAIN(accH);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { accT[m][q] += accH[m][q]; accH[m][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      X3_VALU_SETTLE(accH);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue: this parity's pixels (2y + py, 2x + px) of the 32 x 32 output tile ---------------------------------------
-    {
-      X3_MFMA_DRAIN(accS);
-      // (a copy in registers, read once per tile by scalar loads: through the laundered pointer every use would be a flat load
-      // re-issued behind each store)
-      typedef const __attribute__((address_space(4))) X3Args* X3ArgsK;
-      unsigned long long kpi = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kpi));
-      const X3ArgsK kp = (X3ArgsK)kpi;
-      struct { float* y; const float* bias; const float* mask; const float* noise; const float* noise_w; double* spart;
-               float bias_scale, slope, mslope; int act; } q;
-      q.y = kp->y; q.bias = kp->bias; q.mask = kp->mask; q.noise = kp->noise; q.noise_w = kp->noise_w; q.spart = kp->spart;
-      q.bias_scale = kp->bias_scale; q.slope = kp->slope; q.mslope = kp->mslope; q.act = kp->act;
-      const int oW = 2 * p.W;
-      const long long ib = (long long)cur.n * p.CO * plane * 4;
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn) {
-        const int co = cur.co_t * X3_NT + wn * 32 + nn * 16 + l16;
-        const float bv = q.bias != nullptr ? q.bias[co] * q.bias_scale : 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float* dst = q.y + ib + (long long)co * plane * 4 + (long long)(2 * (cur.oy0 + 4 * wm + m) + cur.py) * oW + 2 * (cur.ox0 + 4 * kg) + cur.px;
-          const f32x4 v = accT[m][nn] + accS[m][nn];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float f = v[r] + bv;
-            if (q.act == GANLAB_ACT_LRELU) f = gl_lrelu(f, q.slope);
-            if (!(X3_EXP & 2)) dst[2 * r] = f;
-          }
-          accT[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-          accS[m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      X3_VALU_SETTLE(accS);
-    }
-    if (!nvalid) break;
-    tile = ntile;
-    cur = nxt;
-    st = 0;
-  }
-}
-
-// ---- packing for the transposed form: [co tile][parity py, px][half][k-step 2][plane][k-group][co 64][8] ----------------------
-// k-step ty of a half: lane groups 0,1 = tap (ty, 0), groups 2,3 = tap (ty, 1); tap (ty, tx) of parity (py, px) sums the 3x3
-// weights of rows R(py, ty) x columns R(px, tx): up forward R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}; the
-// input gradient of the pooled conv takes the flipped sets (k -> 2 - k) and 1/2 per axis.  `up`: 1 = forward of the up layer
-// (GEMM rows = Cin), 0 = input gradient of the pooled layer (GEMM rows = Cout).  (common.h gl_x3_up_pack_position)
-__global__ void x3_up_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int up, float scale) {
-  const int CO = up ? Cout : Cin, CI = up ? Cin : Cout;        // GEMM roles
-  const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (e >= (long long)CO * CI) return;
-  const int col = (int)(e & 63);
-  const long long t = e >> 6;
-  const int ci = (int)(t % CI), ct = (int)(t / CI);
-  const int co = ct * 64 + col;
-  const float* w9 = up ? w + ((long long)co * Cin + ci) * 9 : w + ((long long)ci * Cin + co) * 9;
-  gl_x3_up_pack_position(w9, up, scale, out, CI, ci, co);
-}
-
 int x3_launch(int form, X3Args a, hipStream_t st) {
   a.tiles_x = a.W / 16; a.tiles_y = a.H / 16; a.tiles_co = a.CO / X3_NT;
   const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y * a.tiles_co;
@@ -805,30 +497,6 @@ int x3_launch(int form, X3Args a, hipStream_t st) {
     default: GL_LAUNCH(conv_x3_fwd_kernel<X3_AFF_TAIL>, dim3(grid), dim3(512), 0, st, a); break;
   }
   return GL_CHECK_LAUNCH();
-}
-
-int x3_up_launch(int form, X3Args a, hipStream_t st) {       // a.H, a.W: the LOW resolution
-  a.tiles_x = a.W / 16; a.tiles_y = a.H / 16; a.tiles_co = a.CO / X3_NT;
-  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y * a.tiles_co * 4;
-  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)a.tiles_co * 4 * (a.CI / 16) * X3_WSTAGE * 16 > 0xffffffffLL ||
-      (long long)a.CI * a.H * a.W * 4 > 0x7fffffffLL || (long long)a.N * a.CI * 4 > 0x7fffffffLL)
-    return GANLAB_EINVAL;
-  a.ntiles = (int)ntiles;
-  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-  if (form == X3_AFF) GL_LAUNCH(conv_x3_up_kernel<X3_AFF>, dim3(grid), dim3(512), 0, st, a);
-  else GL_LAUNCH(conv_x3_up_kernel<X3_PLAIN>, dim3(grid), dim3(512), 0, st, a);
-  return GL_CHECK_LAUNCH();
-}
-
-// the transposed form takes: an up layer's forward (dgrad = 0) or a pooled layer's input gradient (dgrad = 1)
-bool x3_up_ok(const ganlab_conv_geom* g, int dgrad) {
-  if (g == nullptr || g->ks != 3 || g->pad != 1 || g->N <= 0) return false;
-  if (dgrad ? !(g->pool == 1 && g->up == 0) : !(g->up == 1 && g->pool == 0)) return false;
-  const int CI = dgrad ? g->Cout : g->Cin, CO = dgrad ? g->Cin : g->Cout;
-  // low resolution: the up layer's input; the pooled layer's OUTPUT (its input is Hin x Win)
-  const int Hl = dgrad ? g->Hin / 2 : g->Hin, Wl = dgrad ? g->Win / 2 : g->Win;
-  if (dgrad && ((g->Hin | g->Win) & 1)) return false;
-  return CI % 64 == 0 && CO % X3_NT == 0 && Hl % 16 == 0 && Wl % 16 == 0;
 }
 
 X3Args x3_args(const float* x, const void* wp, const float* bias, float* y, int N, int CI, int CO, int H, int W, float bias_scale,
@@ -870,44 +538,6 @@ int ganlab_conv_dgrad_x3(const float* gy, const void* wp, float* gx, const ganla
   if (!x3_ok(g, 1) || gy == nullptr || wp == nullptr || gx == nullptr) return GANLAB_EINVAL;
   return x3_launch(X3_PLAIN, x3_args(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin, g->Win, 1.f, GANLAB_ACT_NONE, 0.f),
                    gl_stream(stream));
-}
-
-/* ---- the stride-2 fused layers' transposed form (ganlab_conv_s2_fwd_f32 with up = 1, ganlab_conv_s2_dgrad_f32 with pool = 1) ---- */
-int ganlab_conv_s2_x3_supported(const ganlab_conv_geom* g, int dgrad) { return x3_up_ok(g, dgrad) ? 1 : 0; }
-
-/* `up`: 1 = an up layer's forward weights, 0 = a pooled layer's input-gradient weights; 48*Cout*Cin bf16 elements */
-long long ganlab_conv_s2_x3_pack(const float* w, void* out, int Cout, int Cin, int up, float scale, void* stream) {
-  if (Cout <= 0 || Cin <= 0 || (up != 0 && up != 1) || Cout % 64 != 0 || Cin % 64 != 0) return GANLAB_EINVAL;
-  const long long n = 48LL * Cout * Cin;       // 16 taps x 3 planes
-  if (out == nullptr) return n;
-  if (w == nullptr) return GANLAB_EINVAL;
-  const long long positions = (long long)Cout * Cin;
-  GL_LAUNCH(x3_up_pack_kernel, dim3((unsigned)((positions + 255) / 256)), dim3(256), 0, gl_stream(stream), w,
-            reinterpret_cast<__bf16*>(out), Cout, Cin, up, scale);
-  const int st = GL_CHECK_LAUNCH();
-  return st != GANLAB_OK ? st : n;
-}
-
-int ganlab_conv_s2_fwd_x3(const float* x, const void* wp, const float* bias, float* y, const ganlab_conv_geom* g, float bias_scale,
-                          int act, float slope, void* stream) {
-  if (!x3_up_ok(g, 0) || x == nullptr || wp == nullptr || y == nullptr) return GANLAB_EINVAL;
-  return x3_up_launch(X3_PLAIN, x3_args(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope),
-                      gl_stream(stream));
-}
-
-int ganlab_conv_s2_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, const float* aff_t, const float* bias, float* y,
-                              const ganlab_conv_geom* g, float bias_scale, int act, float slope, void* stream) {
-  if (!x3_up_ok(g, 0) || x == nullptr || wp == nullptr || y == nullptr || aff_s == nullptr || aff_t == nullptr) return GANLAB_EINVAL;
-  X3Args a = x3_args(x, wp, bias, y, g->N, g->Cin, g->Cout, g->Hin, g->Win, bias_scale, act, slope);
-  a.aff_s = aff_s; a.aff_t = aff_t;
-  return x3_up_launch(X3_AFF, a, gl_stream(stream));
-}
-
-/* input gradient of AvgPool2(conv3x3(x)): gy is (N, Cout, Hin / 2, Win / 2), gx (N, Cin, Hin, Win) */
-int ganlab_conv_s2_dgrad_x3(const float* gy, const void* wp, float* gx, const ganlab_conv_geom* g, void* stream) {
-  if (!x3_up_ok(g, 1) || gy == nullptr || wp == nullptr || gx == nullptr) return GANLAB_EINVAL;
-  return x3_up_launch(X3_PLAIN, x3_args(gy, wp, nullptr, gx, g->N, g->Cout, g->Cin, g->Hin / 2, g->Win / 2, 1.f, GANLAB_ACT_NONE, 0.f),
-                      gl_stream(stream));
 }
 
 /* ganlab_conv_dgrad_mask_f32: gx = dgrad(gy, w) * lrelu'(x), x shaped like gx */
