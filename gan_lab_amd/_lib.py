@@ -95,6 +95,9 @@ SIGNATURES = {
     'ganlab_conv_wgrad_x3_supported': (_c_int, [_GP]),
     'ganlab_conv_wgrad_x3_workspace': (_c_sz, [_GP]),
     'ganlab_conv_wgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
+    'ganlab_conv_s2_wgrad_x3_supported': (_c_int, [_GP]),
+    'ganlab_conv_s2_wgrad_x3_workspace': (_c_sz, [_GP]),
+    'ganlab_conv_s2_wgrad_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_conv_fwd_aff_tail_x3': (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _GP, _c_f, _c_int, _c_f,
                                              _c_f, _c_p, _c_sz, _c_p]),
     'ganlab_mask_bits_supported': (_c_int, [_c_int, _c_int]),

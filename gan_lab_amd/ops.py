@@ -406,6 +406,21 @@ def _wgrad_x3(gy, x, s_, t_, gw, g, scale):
     return gw
 
 
+def x3_s2_wgrad_ok(g):
+    """Does this stride-2 layer's weight gradient run on the split-product box-sum kernel?"""
+    if not _X3[0] or g.bf is not None or not g.s2 or g.ks != 3 or g.pad != 1:
+        return False
+    return bool(_lib.lib().ganlab_conv_s2_wgrad_x3_supported(g.ref()))
+
+
+def _wgrad_x3_s2(gy, x, s_, t_, gw, g, scale):
+    L = _lib.lib()
+    ws = torch.empty((L.ganlab_conv_s2_wgrad_x3_workspace(g.ref()) + 3) // 4, dtype=torch.float32, device=x.device)
+    check(L.ganlab_conv_s2_wgrad_x3(_p(gy), _p(x), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
+          'conv_s2_wgrad_x3')
+    return gw
+
+
 def x3_s2_down_ok(g, dgrad=False):
     """The strided stride-2 form on the split-product kernel: a pooled layer's forward, an up layer's input gradient."""
     if not _X3[0] or not g.s2:
@@ -946,6 +961,8 @@ def k_conv_wgrad(gy, x, g, scale):
                                        _st()), 'conv_wgrad_bf16')
         return gw
     if g.s2:
+        if x3_s2_wgrad_ok(g):
+            return _wgrad_x3_s2(gy, x, None, None, gw, g, scale)
         nbytes = L.ganlab_conv_s2_wgrad_workspace(g.ref())
         ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
         check(L.ganlab_conv_s2_wgrad_f32(_p(gy), _p(x), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4, _st()),
@@ -2364,6 +2381,8 @@ def k_conv_wgrad_aff(gy, a, s_, t_, g, scale):
     gw = _take('gw', (g.Cout, g.Cin, 3, 3), a)
     if not g.up and x3_wgrad_ok(g):
         return _wgrad_x3(gy, a, _c(s_), _c(t_), gw, g, scale)
+    if g.up and x3_s2_wgrad_ok(g):
+        return _wgrad_x3_s2(gy, a, _c(s_), _c(t_), gw, g, scale)
     if g.up:
         ws = torch.empty((max(L.ganlab_conv_s2_wgrad_workspace(g.ref()), 4) + 3) // 4, dtype=torch.float32, device=a.device)
         check(L.ganlab_conv_s2_wgrad_aff_f32(_p(gy), _p(a), _p(s_), _p(t_), _p(gw), g.ref(), scale, _p(ws), ws.numel() * 4,

@@ -411,3 +411,64 @@ def test_x3_up_layer_input_gradient(ops, case):
     assert_close(gx3.cpu(), gxd, TOL, 'x3 up layer input gradient vs float64')
     assert_close(gx3.cpu(), gx1.cpu(), TOL, 'x3 up layer input gradient vs exact-fp32 kernel')
     assert rms_rel(gx3, gxd) <= 1.1 * rms_rel(gx1, gxd), (rms_rel(gx3, gxd), rms_rel(gx1, gxd))
+
+
+# ---- stride-2 weight gradient: nine taps over the 2x2 box sums of the high-resolution operand ----------------------------------------
+# N, Cin, Cout, Hl, Wl, kind: several strips per image and per workgroup, odd batch sizes (ragged last split), both channel roles
+SW_CASES = [(2, 32, 64, 8, 32, 'pool'), (3, 64, 128, 16, 64, 'pool'), (5, 96, 64, 4, 32, 'pool'), (2, 32, 192, 32, 96, 'pool'),
+            (2, 64, 32, 8, 32, 'up'), (3, 128, 64, 16, 64, 'up'), (5, 64, 96, 4, 32, 'up'), (7, 192, 32, 8, 64, 'up')]
+
+
+@pytest.mark.parametrize('case', SW_CASES)
+@pytest.mark.parametrize('aff', [False, True])
+def test_x3_stride2_weight_gradient(ops, case, aff):
+    n, ci, co, hl, wl, kind = case
+    up = kind == 'up'
+    if aff and not up:
+        pytest.skip('the affine-on-load operand exists for up layers only (the discriminator has no InstanceNorm)')
+    g = torch.Generator().manual_seed(71 + ci + n + hl)
+    hi, wi = (hl, wl) if up else (2 * hl, 2 * wl)
+    x = torch.randn(n, ci, hi, wi, generator=g)
+    gy = torch.randn(n, co, 2 * hl, 2 * wl, generator=g) if up else torch.randn(n, co, hl, wl, generator=g)
+    s_ = torch.rand(n, ci, generator=g) + 0.5
+    t_ = torch.randn(n, ci, generator=g)
+    geom = ops.Geom(n, ci, hi, wi, co, 3, 1, up=1) if up else ops.Geom(n, ci, hi, wi, co, 3, 1, pool=1)
+    assert ops.x3_s2_wgrad_ok(geom)
+    scale = 0.017
+    run = (lambda: ops.k_conv_wgrad_aff(gy.cuda(), x.cuda(), s_.cuda(), t_.cuda(), geom, scale)) if aff else \
+        (lambda: ops.k_conv_wgrad(gy.cuda(), x.cuda(), geom, scale))
+    gw3 = run()
+    assert 'x3sw_reduce_kernel' in launched(ops)
+    prev = ops.set_x3(False)
+    try:
+        gw1 = run()
+        assert 'x3sw_reduce_kernel' not in launched(ops)
+    finally:
+        ops.set_x3(prev)
+    xin = x.double() * s_.double().view(n, ci, 1, 1) + t_.double().view(n, ci, 1, 1) if aff else x.double()
+    wd = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    if up:
+        yd = F.conv2d(F.interpolate(xin, scale_factor=2, mode='nearest'), wd, padding=1)
+    else:
+        yd = F.avg_pool2d(F.conv2d(xin, wd, padding=1), 2)
+    gwd, = torch.autograd.grad(yd, wd, gy.double())
+    gwd = gwd * scale
+    assert_close(gw3.cpu(), gwd, TOL, 'x3 stride-2 weight gradient vs float64')
+    assert_close(gw3.cpu(), gw1.cpu(), TOL, 'x3 stride-2 weight gradient vs exact-fp32 kernel')
+    assert rms_rel(gw3, gwd) <= max(1.1 * rms_rel(gw1, gwd), 2.5e-7), (rms_rel(gw3, gwd), rms_rel(gw1, gwd))
+
+
+def test_x3_stride2_weight_gradient_is_deterministic_and_closes_long_chains(ops):
+    """More than 32 k-steps per workgroup: the hi*hi chains are closed into the workspace and read back (twice here)."""
+    n, ci, co, hl, wl = 2, 32, 64, 64, 32
+    g = torch.Generator().manual_seed(19)
+    x, gy = torch.randn(n, ci, 2 * hl, 2 * wl, generator=g), torch.randn(n, co, hl, wl, generator=g)
+    geom = ops.Geom(n, ci, 2 * hl, 2 * wl, co, 3, 1, pool=1)
+    assert ops.x3_s2_wgrad_ok(geom)
+    a = ops.k_conv_wgrad(gy.cuda(), x.cuda(), geom, 1.0).clone()
+    b = ops.k_conv_wgrad(gy.cuda(), x.cuda(), geom, 1.0)
+    assert torch.equal(a, b)
+    wd = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    gwd, = torch.autograd.grad(F.avg_pool2d(F.conv2d(x.double(), wd, padding=1), 2), wd, gy.double())
+    assert_close(a.cpu(), gwd, TOL, 'x3 stride-2 weight gradient (long chains) vs float64')
+    assert rms_rel(a, gwd) <= 2.5e-7, rms_rel(a, gwd)

@@ -117,6 +117,67 @@ def wgrad_report(batch, rounds, reps):
         del x, gy
 
 
+def s2_wgrad_report(batch, rounds, reps):
+    """Stride-2 weight gradient (box form): error against float64 next to ATen's CPU fp32 (batch 2), ms per launch at the bench batch."""
+    torch.manual_seed(2)
+    for ci, co, hl, kind in [(64, 128, 64, 'pool'), (128, 64, 64, 'up'), (256, 512, 32, 'pool')]:
+        n, up = 2, kind == 'up'
+        hi = hl if up else 2 * hl
+        x = torch.randn(n, ci, hi, hi)
+        gy = torch.randn(n, co, 2 * hl, 2 * hl) if up else torch.randn(n, co, hl, hl)
+        g = ops.Geom(n, ci, hi, hi, co, 3, 1, up=1) if up else ops.Geom(n, ci, hi, hi, co, 3, 1, pool=1)
+
+        def ref(xx, ww):
+            return F.conv2d(F.interpolate(xx, scale_factor=2, mode='nearest'), ww, padding=1) if up else F.avg_pool2d(F.conv2d(xx, ww, padding=1), 2)
+        wd = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        exact, = torch.autograd.grad(ref(x.double(), wd), wd, gy.double())
+        wf = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        cpu, = torch.autograd.grad(ref(x, wf), wf, gy)
+        x3 = ops.k_conv_wgrad(gy.cuda(), x.cuda(), g, 1.0)
+        name = _lib.last_launch()[0]
+        prev = ops.set_x3(False)
+        hip = ops.k_conv_wgrad(gy.cuda(), x.cuda(), g, 1.0)
+        ops.set_x3(prev)
+        ec, eh, e3 = err(cpu, exact), err(hip, exact), err(x3, exact)
+        print(f's2 wgrad {kind:4s} {ci:3d}->{co:3d} low {hl}x{hl} x{n}: ATen {ec:.3e} | fp32 MFMA {eh:.3e} ({eh / ec:.2f}) | 3xbf16 box {e3:.3e} ({e3 / ec:.2f})'
+              f'  [{name.split("(")[0][-40:]}]', flush=True)
+    layers = [(32, 64, 256, 'pool'), (64, 128, 128, 'pool'), (128, 256, 64, 'pool'), (256, 512, 32, 'pool'),
+              (64, 32, 256, 'up'), (128, 64, 128, 'up'), (256, 128, 64, 'up'), (512, 256, 32, 'up')]
+    for ci, co, hl, kind in layers:
+        up = kind == 'up'
+        hi = hl if up else 2 * hl
+        x = torch.randn(batch, ci, hi, hi, device='cuda')
+        gy = torch.randn(batch, co, 2 * hl, 2 * hl, device='cuda') if up else torch.randn(batch, co, hl, hl, device='cuda')
+        g = ops.Geom(batch, ci, hi, hi, co, 3, 1, up=1) if up else ops.Geom(batch, ci, hi, hi, co, 3, 1, pool=1)
+        fl = 2.0 * 16 * ci * co * batch * hl * hl          # the 16-tap low-resolution form the exact kernel is priced on
+        ms = {'fp32': [], 'x3': []}
+
+        def run(on):
+            prev = ops.set_x3(on)
+            try:
+                return ops.k_conv_wgrad(gy, x, g, 0.05)
+            finally:
+                ops.set_x3(prev)
+        for on in (False, True):
+            for _ in range(4):
+                run(on)
+        for _ in range(rounds):
+            for k, on in (('fp32', False), ('x3', True)):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run(on)
+                e1.record()
+                torch.cuda.synchronize()
+                ms[k].append(e0.elapsed_time(e1) / reps)
+        med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
+        gb = (x.numel() + gy.numel()) * 4 / 1e9
+        print(f's2 wgrad {kind:4s} {ci:3d}->{co:3d} low {hl:3d} x{batch}: fp32 MFMA {med["fp32"]:.3f} ms ({fl / med["fp32"] / 1e9:6.1f} TF/s 16-tap)  '
+              f'3xbf16 box {med["x3"]:.3f} ms ({gb / med["x3"] * 1e3:5.0f} GB/s of operands)  speed-up {med["fp32"] / med["x3"]:.2f}x', flush=True)
+        del x, gy
+
+
 def times(batch, rounds, reps, forms=False):
     for ci, co, hw in LAYERS:
         x = torch.randn(batch, ci, hw, hw, device='cuda')
@@ -179,10 +240,14 @@ if __name__ == '__main__':
     p.add_argument('--err-only', action='store_true')
     p.add_argument('--time-only', action='store_true')
     p.add_argument('--wgrad', action='store_true', help='weight gradient: error and time')
+    p.add_argument('--s2wgrad', action='store_true', help='stride-2 weight gradient (box form): error and time')
     p.add_argument('--forms', action='store_true', help='time the masked / affine / layer-tail forms through ops')
     a = p.parse_args()
     if a.wgrad:
         wgrad_report(a.batch, a.rounds, a.reps)
+        sys.exit(0)
+    if a.s2wgrad:
+        s2_wgrad_report(a.batch, a.rounds, a.reps)
         sys.exit(0)
     if not a.time_only:
         errors()
