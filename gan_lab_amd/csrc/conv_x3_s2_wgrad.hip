@@ -21,8 +21,8 @@
 // VQ[y] serves ty = 2 of row y and ty = 0 of row y+1: a k-step runs VP[f] x L[f], VQ[f] x L[f], VQ[f] x L[f+1]; at the last
 // row of a strip the third group takes the NEXT strip's VQ[-1] (= its high row 0 alone, the SP image) instead.
 // Workgroup: 512 threads, 64 low x 32 box channels x 9 taps; wave (wl = 0..3, wb = 0..1) owns 16 x 16 x 9: S and H in
-// registers (72), the closed chains T in the workgroup's slot of the workspace - every 32 k-steps (1024 terms) three taps per
-// k-step are read, added and written back, the reads issued a k-step's matrix work ahead of their use.
+// registers (72), the closed chains T in the workgroup's slot of the workspace - every 32 k-steps (1024 terms) a tap is read, added and
+// written back (one tap per k-step), the reads issued a k-step's matrix work ahead of their use.
 // Staging: threads 0..255 build VP, 256..511 VQ (item = one channel's 8 high pixels of two rows + a halo dword), all 512 one
 // L item; loads two k-steps ahead of their stores (inline asm, hand-counted waits - extra memory operations only make a
 // counted wait stricter).  One barrier per k-step.
@@ -36,14 +36,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XS_CL = 64, XS_CB = 32;
-constexpr int XS_P = 5;                            // units (16 B) per channel of a row image: 4 (+ 1 pad / halo in front)
+// ablation builds: 1 no chain closing, 2 no matrix work, 4 no staging (loads only), 8 no global loads, 16 no fragment reads,
+// 32 no barrier in the k-step, 64 no fragment shift
+#ifndef XS_EXP
+#define XS_EXP 0
+#endif
+#ifndef XS_PV
+#define XS_PV 6
+#endif
+constexpr int XS_P = 5;                            // units (16 B) per channel of an L row image: 4 + 1
+constexpr int XS_Q = XS_PV;                        // ... of a box row array: 4 + 1 (halo in front) + 1
 constexpr int XS_LPL = XS_CL * XS_P;               // one bf16 plane of an L row image
 constexpr int XS_LROW = 3 * XS_LPL;                // [plane][lc 64][5]
-constexpr int XS_VPL = XS_CB * XS_P;               // one plane of one array (P or Q) of a box row image
+constexpr int XS_VPL = XS_CB * XS_Q;               // one plane of one array (P or Q) of a box row image
 constexpr int XS_VARR = 3 * XS_VPL;                // [plane][bc 32][5]
 constexpr int XS_VROW = 2 * XS_VARR;               // [P | Q]
-constexpr int XS_VP0 = 2 * XS_LROW, XS_VQ0 = XS_VP0 + 2 * XS_VROW, XS_SP = XS_VQ0 + 2 * XS_VROW;
-constexpr int XS_LDS = XS_SP + XS_VROW;            // 6720 units = 107,520 bytes
+constexpr int XS_VP0 = 2 * XS_LROW, XS_VQ0 = XS_VP0 + 2 * XS_VROW, XS_SP = XS_VQ0 + 4 * XS_VROW;      // L[2] | VP[2] | VQ[4] | SP
+constexpr int XS_LDS = XS_SP + XS_VROW;            // 8640 units = 138,240 bytes
 constexpr int XS_SLOT = XS_CL * XS_CB * 9;         // floats of one partial slot: [wave 8][tap 9][lane 64][4]
 constexpr int XS_LOADS = 7;                        // vector-memory loads per thread and k-step
 
@@ -91,16 +100,21 @@ __device__ __forceinline__ void xs_wait(XSSet& s) {
   asm volatile("s_waitcnt vmcnt(%7)" : "+v"(s.a0), "+v"(s.a1), "+v"(s.b0), "+v"(s.b1), "+v"(s.lv), "+v"(s.ha), "+v"(s.hb) : "n"(YOUNGER));
 }
 
+// split four values into planes (8 bytes each): two values per v_cvt_pk_bf16_f32 (round to nearest even, like the scalar cast)
+__device__ __forceinline__ unsigned xs_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void xs_split4(const f32x4& v, u32x2& h, u32x2& m, u32x2& l) {
-  bf16x4 hh, mm, ll;
+  float r[4], q[4];
+  h[0] = xs_cvt_pk(v[0], v[1]); h[1] = xs_cvt_pk(v[2], v[3]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    hh[j] = (__bf16)v[j];
-    const float r1 = v[j] - (float)hh[j];
-    mm[j] = (__bf16)r1;
-    ll[j] = (__bf16)(r1 - (float)mm[j]);
-  }
-  h = __builtin_bit_cast(u32x2, hh); m = __builtin_bit_cast(u32x2, mm); l = __builtin_bit_cast(u32x2, ll);
+  for (int j = 0; j < 4; ++j) r[j] = v[j] - __uint_as_float((j & 1) ? (h[j >> 1] & 0xffff0000u) : (h[j >> 1] << 16));
+  m[0] = xs_cvt_pk(r[0], r[1]); m[1] = xs_cvt_pk(r[2], r[3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = r[j] - __uint_as_float((j & 1) ? (m[j >> 1] & 0xffff0000u) : (m[j >> 1] << 16));
+  l[0] = xs_cvt_pk(q[0], q[1]); l[1] = xs_cvt_pk(q[2], q[3]);
 }
 
 template <int U> struct xs_ic { static constexpr int value = U; };
@@ -119,57 +133,72 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
   const int bt = pair % p.tiles_b, lt = pair / p.tiles_b;
   const int l0 = lt * XS_CL, b0 = bt * XS_CB;
   const int s_first = split * p.sps;
-  const int s_count = min(p.sps, p.nstrips - s_first);
-  const int F = s_count << p.hshift;               // k-steps of this workgroup (a multiple of 4)
+  const int s_end = min(s_first + p.sps, p.nstrips);
+  const int F = (s_end - s_first) << p.hshift;     // k-steps of this workgroup (a multiple of 4)
   const int hmask = p.Hl - 1;
-  const int lplane = p.Hl * p.Wl, hplane = 4 * lplane, W2 = 2 * p.Wl;
+  const int lplane = p.Hl * p.Wl, W2 = 2 * p.Wl;
 
-  const u32x4 rs_l = xs_rsrc(p.low, (unsigned)((long long)p.N * p.CL * lplane * 4));
-  const u32x4 rs_h = xs_rsrc(p.high, (unsigned)((long long)p.N * p.CB * hplane * 4));
+  const unsigned lbytes = (unsigned)((long long)p.N * p.CL * lplane * 4), hbytes = (unsigned)((long long)p.N * p.CB * lplane * 16);
+  const u32x4 rs_l = xs_rsrc(p.low, lbytes);
+  const u32x4 rs_h = xs_rsrc(p.high, hbytes);
   float* const twave = p.part + ((long long)pair * p.splits + split) * XS_SLOT + wv * 9 * 256;   // this wave's nine T tiles
-  float* const tbase = twave + lane * 4;                                                         // + t * 256
-  const u32x4 rs_t = xs_rsrc(twave, 9 * 1024);
+  const u32x4 rs_t = xs_rsrc(twave, 9 * 1024);                                                   // tile t of this lane: t * 1024 + lane * 16
+  auto t_store = [&](const f32x4& v, int t) {
+    // (a store of more than 8 bytes reads its data registers over several cycles: the wait states behind it keep the next
+    // instruction - the compiler does not see this store - from overwriting them; without: elements 2, 3 of lanes 12..15 of
+    // every row were the NEXT value of the register)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 2" :: "v"(v), "v"(t * 1024 + lane * 16), "s"(rs_t) : "memory");
+  };
 
   // ---- staging items ---------------------------------------------------------------------------------------------------------
-  const int vq = __builtin_amdgcn_readfirstlane(tid >> 8);     // 0: this thread builds VP rows (high rows 2y, 2y+1), 1: VQ rows (2y+1, 2y+2)
+  // waves 0..3 (vq = 0) build the VP rows (high rows 2y, 2y+1) and run [stage, matrix work] in a k-step, waves 4..7 (vq = 1)
+  // the VQ rows (2y+1, 2y+2) and run [matrix work, stage]: the two waves of a SIMD are half a k-step out of phase, one's
+  // splitting runs under the other's MFMAs
+  const int vq = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int b_ch = (tid & 255) >> 3, b_q = tid & 7;            // box channel, 8-pixel item of the 64 high pixels
   const int l_c = tid >> 3, l_q = tid & 7;                     // low channel, 4-pixel item of the 32 low pixels
   const int l_dst = (l_c * XS_P + (l_q >> 1)) * 16 + (l_q & 1) * 8;                 // + plane * XS_LPL * 16
-  const int p_dst = (b_ch * XS_P + (b_q >> 1)) * 16 + (b_q & 1) * 8;                // + plane * XS_VPL * 16; Q: + (XS_VARR + 1) * 16
-  float a_s = 1.f, a_t = 0.f;
-  int aff_n = -1;
-
-  auto flat_pos = [&](int f, int& n, int& y, int& x0) {
-    const int strip = s_first + (f >> p.hshift);
-    y = f & hmask;
-    n = strip / p.strips_x;
-    x0 = (strip - n * p.strips_x) * 32;
-  };
+  const int p_dst = (b_ch * XS_Q + (b_q >> 1)) * 16 + (b_q & 1) * 8;                // + plane * XS_VPL * 16; Q: + (XS_VARR + 1) * 16
   constexpr int OOB = (int)0x80000000;
-  auto issue_loads = [&](XSSet& s, int g) {       // the rows of k-step g's images (past the end: zeros)
-    int n, y, x0;
-    flat_pos(g, n, y, x0);
-    const bool on = g < F;
-    const int loff = on ? (((n * p.CL + l0 + l_c) * p.Hl + y) * p.Wl + x0 + 4 * l_q) * 4 : OOB;
-    const int cha = ((n * p.CB + b0 + b_ch) * 2 * p.Hl + 2 * y + vq) * W2;        // element offset of row A of this channel
-    int chb = cha + W2, x0b = x0;
-    bool onb = on;
-    if (vq && y == hmask) {                       // VQ at the strip's last row: row B is the NEXT strip's high row 0 (its VQ[-1])
-      int n2, y2;
-      flat_pos(g + 1, n2, y2, x0b);
-      onb = g + 1 < F;
-      chb = ((n2 * p.CB + b0 + b_ch) * 2 * p.Hl) * W2;
+  // per-thread byte offsets (the workgroup's scalar cursor is added by the load's soffset)
+  const int thrL = (l_c * lplane + 4 * l_q) * 4;
+  const int thrRow = (b_ch * 2 * p.Hl + vq) * W2 * 4;          // row A of this thread's channel (row B: + W2 * 4)
+  const int thrA = thrRow + 32 * b_q, thrB = thrA + W2 * 4;
+  float a_s = 1.f, a_t = 0.f;
+
+  // load cursor: k-step g of the next issue_loads (they are issued in order g = 0, 1, 2, ...)
+  int c_y = 0, c_strip = s_first;
+  unsigned c_sL = 0, c_sH = 0, c_sHr = 0;         // scalar byte offsets: low row; high row pair at column 2 x0; ... at column 0
+  int c_thrH = OOB;                               // this thread's halo column (row A), OOB where there is none
+  auto cursor_strip = [&]() {
+    const int n = c_strip / p.strips_x, x0 = (c_strip - n * p.strips_x) * 32;
+    c_sL = (unsigned)__builtin_amdgcn_readfirstlane((((n * p.CL + l0) * p.Hl) * p.Wl + x0) * 4);
+    c_sHr = (unsigned)__builtin_amdgcn_readfirstlane(((n * p.CB + b0) * 2 * p.Hl) * W2 * 4);
+    c_sH = c_sHr + 8 * x0;
+    const bool left = x0 > 0, right = x0 + 32 < p.Wl;
+    c_thrH = b_q == 0 ? (left ? thrRow + (2 * x0 - 1) * 4 : OOB) : (b_q == 7 ? (right ? thrRow + (2 * x0 + 64) * 4 : OOB) : OOB);
+  };
+  cursor_strip();
+  auto issue_loads = [&](XSSet& s) {              // the rows of the cursor's k-step (past the end: zeros), then advance it
+    const bool on = c_strip < s_end;
+    u32x4 ra = rs_h, rb = rs_h, rl = rs_l;
+    ra[2] = on ? hbytes : 0u;
+    rb[2] = (on && !(vq && c_y == hmask)) ? hbytes : 0u;      // VQ[Hl-1]: the row below the plane is zero
+    rl[2] = on ? lbytes : 0u;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(s.a0) : "v"(thrA), "s"(ra), "s"(c_sH) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(s.a1) : "v"(thrA), "s"(ra), "s"(c_sH) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(s.b0) : "v"(thrB), "s"(rb), "s"(c_sH) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(s.b1) : "v"(thrB), "s"(rb), "s"(c_sH) : "memory");
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(s.ha) : "v"(c_thrH), "s"(ra), "s"(c_sHr) : "memory");
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(s.hb) : "v"(c_thrH + W2 * 4), "s"(rb), "s"(c_sHr) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(s.lv) : "v"(thrL), "s"(rl), "s"(c_sL) : "memory");
+    if (++c_y == p.Hl) {
+      c_y = 0;
+      ++c_strip;
+      cursor_strip();
+    } else {
+      c_sL += p.Wl * 4; c_sH += 2 * W2 * 4; c_sHr += 2 * W2 * 4;
     }
-    const int hc = b_q == 0 ? -1 : (b_q == 7 ? 64 : -0x40000000);                  // halo column relative to 2 x0
-    const int ca = 2 * x0 + hc, cb = 2 * x0b + hc;
-    const int offa = on ? (cha + 2 * x0 + 8 * b_q) * 4 : OOB;
-    const int offb = onb ? (chb + 2 * x0b + 8 * b_q) * 4 : OOB;
-    const int offha = (on && ca >= 0 && ca < W2) ? (cha + ca) * 4 : OOB;
-    const int offhb = (onb && cb >= 0 && cb < W2) ? (chb + cb) * 4 : OOB;
-    xs_ld(s.a0, rs_h, offa); xs_ld16(s.a1, rs_h, offa);
-    xs_ld(s.b0, rs_h, offb); xs_ld16(s.b1, rs_h, offb);
-    xs_ld1(s.ha, rs_h, offha); xs_ld1(s.hb, rs_h, offhb);
-    xs_ld(s.lv, rs_l, loff);
   };
   // one box row image from the vertical sums v0 (columns 0..3 of the item), v1 (4..7) and the halo column's vh
   auto emit = [&](const f32x4& v0, const f32x4& v1, float vh, int base) {
@@ -198,13 +227,13 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
       dh[0] = hh; dh[XS_VPL * 8] = mm; dh[2 * XS_VPL * 8] = ll;
     }
   };
-  auto store_images = [&](XSSet& s, int g) {      // k-step g's images: L -> buffer g & 1, VP / VQ -> buffer g & 1, (SP)
-    int n, y, x0;
-    flat_pos(g, n, y, x0);
+  // k-step g's images: L -> buffer g & 1;  VP -> buffer g & 1 (and, first row of a strip, SP = high row 0 alone);  VQ -> slot g & 3
+  auto store_images = [&](XSSet& s, int g, int u) {    // u = g & 3
+    const int y = g & hmask;
     f32x4 v = s.lv;
     if constexpr (AFF) {
-      if (n != aff_n && g < F) {                  // a new image: this channel's affine (once per strip at most)
-        aff_n = n;
+      if (y == 0 && g < F) {                      // a new strip: this channel's affine of its image
+        const int n = (s_first + (g >> p.hshift)) / p.strips_x;
         a_s = p.aff_s[(long long)n * p.CL + l0 + l_c];
         a_t = p.aff_t[(long long)n * p.CL + l0 + l_c];
       }
@@ -213,17 +242,12 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
     }
     u32x2 h, m, l;
     xs_split4(v, h, m, l);
-    unsigned char* d = reinterpret_cast<unsigned char*>(lds + (g & 1) * XS_LROW) + l_dst;
+    unsigned char* d = reinterpret_cast<unsigned char*>(lds + (u & 1) * XS_LROW) + l_dst;
     *reinterpret_cast<u32x2*>(d) = h;
     *reinterpret_cast<u32x2*>(d + XS_LPL * 16) = m;
     *reinterpret_cast<u32x2*>(d + 2 * XS_LPL * 16) = l;
-    const int vbase = (vq ? XS_VQ0 : XS_VP0) + (g & 1) * XS_VROW;
-    if (vq && y == hmask) {
-      emit(s.a0, s.a1, s.ha, vbase);              // VQ[Hl-1] = the last high row alone
-      emit(s.b0, s.b1, s.hb, XS_SP);              // the next strip's VQ[-1] = its high row 0 alone
-    } else {
-      emit(s.a0 + s.b0, s.a1 + s.b1, s.ha + s.hb, vbase);
-    }
+    if (!vq && y == 0) emit(s.a0, s.a1, s.ha, XS_SP);
+    emit(s.a0 + s.b0, s.a1 + s.b1, s.ha + s.hb, vq ? XS_VQ0 + u * XS_VROW : XS_VP0 + (u & 1) * XS_VROW);
   };
 
   f32x4 accS[9], accH[9];
@@ -234,113 +258,141 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
 
   // fragment addresses (units)
   const int laneL = (wl * 16 + l16) * XS_P + kg;
-  const int laneB = (wb * 16 + l16) * XS_P + kg;
-  bf16x8 aL[2][3];          // [set][plane] L fragments of k-steps f (set f & 1) and f + 1
-  bf16x8 bP[3], bQ[3], bS[3];   // [plane] box fragments of a row image: P, Q and Q shifted by one pixel
-  unsigned bq_[3];          // the dword in front of the Q fragment
+  const int laneB = (wb * 16 + l16) * XS_Q + kg;
+  bf16x8 aL[2][3];          // [k-step parity][plane] L fragments
+  bf16x8 bP[2][3], bQ[2][3];   // [set][plane] box fragments of a row image: P, Q
+  unsigned bq_[2][3];       // the dword in front of the Q fragment
   auto l_frags = [&](int buf, int set) {
+    if (XS_EXP & 16) return;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) aL[set][pl] = __builtin_bit_cast(bf16x8, lds[buf * XS_LROW + pl * XS_LPL + laneL]);
   };
-  auto b_frags = [&](int base) {
+  auto b_frags = [&](int base, int set) {
+    if (XS_EXP & 16) return;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      bP[pl] = __builtin_bit_cast(bf16x8, lds[base + pl * XS_VPL + laneB]);
+      bP[set][pl] = __builtin_bit_cast(bf16x8, lds[base + pl * XS_VPL + laneB]);
       const int u = base + XS_VARR + pl * XS_VPL + laneB + 1;
-      bQ[pl] = __builtin_bit_cast(bf16x8, lds[u]);
-      bq_[pl] = reinterpret_cast<const unsigned*>(lds + u - 1)[3];
+      bQ[set][pl] = __builtin_bit_cast(bf16x8, lds[u]);
+      bq_[set][pl] = reinterpret_cast<const unsigned*>(lds + u - 1)[3];
     }
   };
-  auto b_shift = [&]() {    // bS[j] = Q[j - 1]
+  auto b_shift = [&](int set) {    // in place: bQ[j] := Q[j - 1] (behind the MFMAs that read the unshifted fragment)
+    if (XS_EXP & 64) return;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      const u32x4 c = __builtin_bit_cast(u32x4, bQ[pl]);
+      const u32x4 c = __builtin_bit_cast(u32x4, bQ[set][pl]);
       u32x4 dn;
-      dn[0] = __builtin_amdgcn_alignbit(c[0], bq_[pl], 16); dn[1] = __builtin_amdgcn_alignbit(c[1], c[0], 16);
+      dn[0] = __builtin_amdgcn_alignbit(c[0], bq_[set][pl], 16); dn[1] = __builtin_amdgcn_alignbit(c[1], c[0], 16);
       dn[2] = __builtin_amdgcn_alignbit(c[2], c[1], 16); dn[3] = __builtin_amdgcn_alignbit(c[3], c[2], 16);
-      bS[pl] = __builtin_bit_cast(bf16x8, dn);
+      bQ[set][pl] = __builtin_bit_cast(bf16x8, dn);
     }
   };
+// (the P and Q taps alternate: a dependent MFMA right behind its predecessor makes hipcc put an s_nop between them - 4 issue
+// cycles each, 36 per k-step and wave)
 #define XS_TAP(t, A, Bf)                                                                                      \
   XS_MFMA(accS[t], A[2], Bf[0]); XS_MFMA(accS[t], A[0], Bf[2]); XS_MFMA(accS[t], A[1], Bf[1]);                \
   XS_MFMA(accS[t], A[1], Bf[0]); XS_MFMA(accS[t], A[0], Bf[1]); XS_MFMA(accH[t], A[0], Bf[0])
-#define XS_GROUP(ty, A) do { XS_TAP(3 * (ty) + 1, A, bP); XS_TAP(3 * (ty) + 2, A, bQ); XS_TAP(3 * (ty), A, bS); } while (0)
+#define XS_TAP2(t, Bt, u, Bu, A)                                                                              \
+  XS_MFMA(accS[t], A[2], Bt[0]); XS_MFMA(accS[u], A[2], Bu[0]); XS_MFMA(accS[t], A[0], Bt[2]); XS_MFMA(accS[u], A[0], Bu[2]);   \
+  XS_MFMA(accS[t], A[1], Bt[1]); XS_MFMA(accS[u], A[1], Bu[1]); XS_MFMA(accS[t], A[1], Bt[0]); XS_MFMA(accS[u], A[1], Bu[0]);   \
+  XS_MFMA(accS[t], A[0], Bt[1]); XS_MFMA(accS[u], A[0], Bu[1]); XS_MFMA(accH[t], A[0], Bt[0]); XS_MFMA(accH[u], A[0], Bu[0])
+#define XS_GROUP(ty, A, set) do {                                                  \
+    XS_TAP2(3 * (ty) + 1, bP[set], 3 * (ty) + 2, bQ[set], A);                      \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    b_shift(set);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    XS_TAP(3 * (ty), A, bQ[set]);                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
 
-  // ---- prologue: T := 0; images of k-step 0 and the first strip's SP (= its high row 0 alone: row A of the VP threads) in LDS;
-  //      the loads of k-steps 1 and 2 in flight ---------------------------------------------------------------------------------
+  // ---- prologue: T := 0; the images of k-step 0 in LDS, its L and VP fragments in registers; the loads of k-steps 1, 2 in flight
 #pragma unroll
-  for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(tbase + t * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 9; ++t) t_store(f32x4{0.f, 0.f, 0.f, 0.f}, t);
   XSSet s0, s1;
-  issue_loads(s0, 0);
+  issue_loads(s0);
   xs_wait<0>(s0);
-  if (!vq) emit(s0.a0, s0.a1, s0.ha, XS_SP);
-  store_images(s0, 0);
+  store_images(s0, 0, 0);
+  issue_loads(s0);
+  issue_loads(s1);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  issue_loads(s0, 1);
-  issue_loads(s1, 2);
   l_frags(0, 0);
-  b_frags(XS_SP);
-  b_shift();
-  __builtin_amdgcn_sched_barrier(0);
-  XS_GROUP(0, aL[0]);       // ty = 0 of the first row: VQ[-1] x L[0]
-  __builtin_amdgcn_sched_barrier(0);
-  b_frags(XS_VP0);          // VP[0]
+  b_frags(XS_VP0, 0);
 
+  // One k-step f (u = f & 3; c = f & 1: the L fragments aL[c] and VP[f] in fragment set c were read behind the barrier of the
+  // k-step before, under its last 18 MFMAs):
+  //   waves 0..3:  [stage f+1]  VP[f] x L  ->  VQ[f] x L                 | barrier |  read L[f+1], VP[f+1];  VQ[f-1] x L
+  //   waves 4..7:               VP[f] x L  ->  VQ[f] x L  [stage f+1]    | barrier |  ...
+  // (the matrix work stands ONCE in the k-step, outside any branch: accumulators that two paths write get copied.)  The two
+  // waves of a SIMD are out of phase: one splits and stores while the other's 36 MFMAs run; the LDS reads of a group are
+  // issued a group ahead, the first group's across the barrier, so no wave starts a k-step waiting for the LDS.
+#ifndef XS_STAG
+#define XS_STAG 0
+#endif
+  const bool early = XS_STAG == 0 ? true : (XS_STAG == 1 ? vq == 0 : (wv & 1) == 0);      // stages in front of its matrix work
   auto body = [&](auto U, int f) {
-    constexpr int u = decltype(U)::value;          // = f & 1: register set, buffers
-    XSSet& s = u ? s1 : s0;
+    constexpr int u = decltype(U)::value;          // = f & 3
+    constexpr int c = u & 1;
+    XSSet& s = c ? s1 : s0;
     const int y = f & hmask;
-    const int ph = (f & 31) - 29;                   // >= 0: taps 3 ph .. 3 ph + 2 close their hi*hi chains in this k-step
-    f32x4 tq[3];
-    b_shift();
-    __builtin_amdgcn_sched_barrier(0);
-    XS_GROUP(1, aL[u]);                             // ty = 1: VP[f] x L[f]
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- staging: the images of k-step f + 1 (loads requested two k-steps ago; behind them only the seven of the k-step before)
-    xs_wait<XS_LOADS>(s);
-    if (ph >= 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) xs_ld(tq[j], rs_t, (3 * ph + j) * 1024 + lane * 16);
+    const int ph = (XS_EXP & 1) ? -1 : (f & 31) - 23;      // >= 0: tap ph closes its hi*hi chain in this k-step
+    f32x4 tq;
+    if (ph >= 0) xs_ld(tq, rs_t, ph * 1024 + lane * 16);
+    // staging: the images of k-step f + 1 (loads requested two k-steps ago; behind them the seven of the k-step before - and, in
+    // a closing k-step, tq's: a stricter wait, nothing else), then the requests of k-step f + 3
+    auto stage = [&]() {
+      xs_wait<XS_LOADS>(s);
+      if (!(XS_EXP & 4)) store_images(s, f + 1, (u + 1) & 3);
+      if (!(XS_EXP & 8)) issue_loads(s);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (early) stage();
+    if (!(XS_EXP & 2)) {
+      b_frags(XS_VQ0 + u * XS_VROW, c ^ 1);          // VQ[f]
+      __builtin_amdgcn_sched_barrier(0);
+      XS_GROUP(1, aL[c], c);                         // ty = 1: VP[f]
+      b_frags(y == 0 ? XS_SP : XS_VQ0 + ((u + 3) & 3) * XS_VROW, c);   // VQ[f - 1]; first row of a strip: high row 0 alone
+      __builtin_amdgcn_sched_barrier(0);
+      XS_GROUP(2, aL[c], c ^ 1);                     // ty = 2: VQ[f]
     }
-    store_images(s, f + 1);
+    if (!early) stage();
+    if (!(XS_EXP & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the images of k-step f + 1 are visible behind it
     __builtin_amdgcn_sched_barrier(0);
-    b_frags(XS_VQ0 + u * XS_VROW);                  // VQ[f]
-    b_shift();
-    __builtin_amdgcn_sched_barrier(0);
-    XS_GROUP(2, aL[u]);                             // ty = 2: VQ[f] x L[f]
-    __builtin_amdgcn_sched_barrier(0);
-    issue_loads(s, f + 3);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the images stored above are visible behind it
-    __builtin_amdgcn_sched_barrier(0);
-    l_frags(u ^ 1, u ^ 1);                          // L[f + 1]
-    if (y == hmask) {                               // the next strip's VQ[-1] instead of this strip's VQ[Hl-1]
-      b_frags(XS_SP);
-      b_shift();
+    if (!(XS_EXP & 2)) {
+      l_frags(c ^ 1, c ^ 1);                         // L[f + 1]
+      b_frags(XS_VP0 + (c ^ 1) * XS_VROW, c ^ 1);    // VP[f + 1]
+      __builtin_amdgcn_sched_barrier(0);
+      XS_GROUP(0, aL[c], c);                         // ty = 0: VQ[f - 1]
     }
-    __builtin_amdgcn_sched_barrier(0);
-    XS_GROUP(0, aL[u ^ 1]);                         // ty = 0 of the next row: VQ[f] x L[f + 1]
-    __builtin_amdgcn_sched_barrier(0);
-    b_frags(XS_VP0 + (u ^ 1) * XS_VROW);            // VP[f + 1]
-    if (ph >= 0) {                                  // T += H for three taps; only this k-step's seven loads are younger than tq's
-      asm volatile("s_waitcnt vmcnt(%3)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]) : "n"(XS_LOADS));
-      auto close3 = [&](auto O) {
+    if (ph >= 0) {                                 // T += H for one tap; only this k-step's seven loads are younger than tq's
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(tq) : "n"(XS_LOADS));
+      auto close1 = [&](auto O) {
         constexpr int o = decltype(O)::value;
-        XS_MFMA_DRAIN3(accH, o);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { tq[j] += accH[o + j]; accH[o + j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        XS_VALU_SETTLE3(accH, o);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(tbase + (o + j) * 256) = tq[j];
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accH[o]));
+        tq += accH[o];
+        accH[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accH[o]));
+        t_store(tq, o);
       };
-      if (ph == 0) close3(xs_ic<0>{});
-      else if (ph == 1) close3(xs_ic<3>{});
-      else close3(xs_ic<6>{});
+      switch (ph) {
+        case 0: close1(xs_ic<0>{}); break;
+        case 1: close1(xs_ic<1>{}); break;
+        case 2: close1(xs_ic<2>{}); break;
+        case 3: close1(xs_ic<3>{}); break;
+        case 4: close1(xs_ic<4>{}); break;
+        case 5: close1(xs_ic<5>{}); break;
+        case 6: close1(xs_ic<6>{}); break;
+        case 7: close1(xs_ic<7>{}); break;
+        default: close1(xs_ic<8>{}); break;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  for (int f0 = 0; f0 < F; f0 += 2) {
+  for (int f0 = 0; f0 < F; f0 += 4) {
     body(xs_ic<0>{}, f0);
     body(xs_ic<1>{}, f0 + 1);
+    body(xs_ic<2>{}, f0 + 2);
+    body(xs_ic<3>{}, f0 + 3);
   }
 
   // ---- this workgroup's partial sums, in place: T + H + S ---------------------------------------------------------------------
@@ -349,10 +401,13 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
   XS_MFMA_DRAIN9(accH);
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    f32x4* q = reinterpret_cast<f32x4*>(tbase + t * 256);
-    *q = *q + accH[t] + accS[t];
+    f32x4 v;
+    xs_ld(v, rs_t, t * 1024 + lane * 16);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+    t_store(v + accH[t] + accS[t], t);
   }
 #undef XS_TAP
+#undef XS_TAP2
 #undef XS_GROUP
 }
 

@@ -10,7 +10,9 @@ x = torch.randn(b, 256, 64, 64, device='cuda'); w = torch.randn(256, 256, 3, 3, 
 g = ops.Geom(b, 256, 64, 64, 256, 3, 1)
 xl = torch.randn(b, 256, 32, 32, device='cuda'); wu = torch.randn(128, 256, 3, 3, device='cuda'); gu = ops.Geom(b, 256, 32, 32, 128, 3, 1, up=1)
 xp = torch.randn(b, 128, 64, 64, device='cuda'); wp = torch.randn(256, 128, 3, 3, device='cuda'); gp = ops.Geom(b, 128, 64, 64, 256, 3, 1, pool=1)
+gyp = torch.randn(b, 256, 32, 32, device='cuda')
 for _ in range(8):
+    ops.k_conv_wgrad(gyp, xp, gp, 0.05)
     ops.k_conv_fwd(x, w, None, g, 0.05)
     ops.k_conv_dgrad_mask(gy, w, x, g, 0.05, 0.2)
     ops.k_conv_wgrad(gy, x, g, 0.05)
