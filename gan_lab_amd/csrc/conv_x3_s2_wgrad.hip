@@ -288,17 +288,13 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
       bQ[set][pl] = __builtin_bit_cast(bf16x8, dn);
     }
   };
-// (the P and Q taps alternate: a dependent MFMA right behind its predecessor makes hipcc put an s_nop between them - 4 issue
-// cycles each, 36 per k-step and wave)
+// (alternating the P and Q taps' accumulators - no MFMA behind the one that wrote its accumulator, none of hipcc's s_nop between
+// them - was measured 1 % SLOWER here and 4 % slower in conv_x3.hip: dependent MFMAs issue back to back at full rate)
 #define XS_TAP(t, A, Bf)                                                                                      \
   XS_MFMA(accS[t], A[2], Bf[0]); XS_MFMA(accS[t], A[0], Bf[2]); XS_MFMA(accS[t], A[1], Bf[1]);                \
   XS_MFMA(accS[t], A[1], Bf[0]); XS_MFMA(accS[t], A[0], Bf[1]); XS_MFMA(accH[t], A[0], Bf[0])
-#define XS_TAP2(t, Bt, u, Bu, A)                                                                              \
-  XS_MFMA(accS[t], A[2], Bt[0]); XS_MFMA(accS[u], A[2], Bu[0]); XS_MFMA(accS[t], A[0], Bt[2]); XS_MFMA(accS[u], A[0], Bu[2]);   \
-  XS_MFMA(accS[t], A[1], Bt[1]); XS_MFMA(accS[u], A[1], Bu[1]); XS_MFMA(accS[t], A[1], Bt[0]); XS_MFMA(accS[u], A[1], Bu[0]);   \
-  XS_MFMA(accS[t], A[0], Bt[1]); XS_MFMA(accS[u], A[0], Bu[1]); XS_MFMA(accH[t], A[0], Bt[0]); XS_MFMA(accH[u], A[0], Bu[0])
 #define XS_GROUP(ty, A, set) do {                                                  \
-    XS_TAP2(3 * (ty) + 1, bP[set], 3 * (ty) + 2, bQ[set], A);                      \
+    XS_TAP(3 * (ty) + 1, A, bP[set]); XS_TAP(3 * (ty) + 2, A, bQ[set]);            \
     __builtin_amdgcn_sched_barrier(0);                                             \
     b_shift(set);                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                             \
@@ -407,7 +403,6 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
     t_store(v + accH[t] + accS[t], t);
   }
 #undef XS_TAP
-#undef XS_TAP2
 #undef XS_GROUP
 }
 
