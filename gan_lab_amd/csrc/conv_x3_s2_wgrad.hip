@@ -159,11 +159,13 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
   const int l_c = tid >> 3, l_q = tid & 7;                     // low channel, 4-pixel item of the 32 low pixels
   const int l_dst = (l_c * XS_P + (l_q >> 1)) * 16 + (l_q & 1) * 8;                 // + plane * XS_LPL * 16
   const int p_dst = (b_ch * XS_Q + (b_q >> 1)) * 16 + (b_q & 1) * 8;                // + plane * XS_VPL * 16; Q: + (XS_VARR + 1) * 16
-  constexpr int OOB = (int)0x80000000;
+  constexpr int OOB = (int)0x80000000;      // (+ a row pitch stays out of range: pitches are < 2^30)
   // per-thread byte offsets (the workgroup's scalar cursor is added by the load's soffset)
-  const int thrL = (l_c * lplane + 4 * l_q) * 4;
+  // (a 16-pixel-wide low map is ONE strip whose upper 16 pixels do not exist: those items load zeros - half of the k-step's
+  // products are wasted, still 9/16 x 2 of the exact kernel's count at eight times its rate)
+  const int thrL = 4 * l_q < p.Wl ? (l_c * lplane + 4 * l_q) * 4 : OOB;
   const int thrRow = (b_ch * 2 * p.Hl + vq) * W2 * 4;          // row A of this thread's channel (row B: + W2 * 4)
-  const int thrA = thrRow + 32 * b_q, thrB = thrA + W2 * 4;
+  const int thrA = 8 * b_q < W2 ? thrRow + 32 * b_q : OOB, thrB = thrA + W2 * 4;
   float a_s = 1.f, a_t = 0.f;
 
   // load cursor: k-step g of the next issue_loads (they are issued in order g = 0, 1, 2, ...)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
         a_t = p.aff_t[(long long)n * p.CL + l0 + l_c];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = g < F ? fmaf(v[j], a_s, a_t) : 0.f;
+      for (int j = 0; j < 4; ++j) v[j] = (g < F && thrL != OOB) ? fmaf(v[j], a_s, a_t) : 0.f;      // (pixels that do not exist stay zero)
     }
     u32x2 h, m, l;
     xs_split4(v, h, m, l);
@@ -438,7 +440,7 @@ bool xs_geom(const ganlab_conv_geom* g, XSGeom& q) {
   } else {
     q = XSGeom{g->Cin, g->Cout, g->Hin, g->Win};
   }
-  if (q.Hl < 4 || (q.Hl & (q.Hl - 1)) != 0 || q.Wl % 32 != 0) return false;
+  if (q.Hl < 4 || (q.Hl & (q.Hl - 1)) != 0 || (q.Wl % 32 != 0 && q.Wl != 16)) return false;
   if (q.CL % XS_CL != 0 || q.CB % XS_CB != 0) return false;
   const long long hb = (long long)g->N * q.CB * q.Hl * q.Wl * 16, lb = (long long)g->N * q.CL * q.Hl * q.Wl * 4;
   return hb < 0x7fffffffLL && lb < 0x7fffffffLL;
@@ -446,7 +448,7 @@ bool xs_geom(const ganlab_conv_geom* g, XSGeom& q) {
 struct XSPlan { int pairs, splits, sps; };
 XSPlan xs_plan(const ganlab_conv_geom* g, const XSGeom& q) {
   const int pairs = (q.CL / XS_CL) * (q.CB / XS_CB);
-  const int nstrips = g->N * (q.Wl / 32);
+  const int nstrips = g->N * ((q.Wl + 31) / 32);
   int splits = (512 + pairs - 1) / pairs;          // ~ two rounds of workgroups on the 256 CUs
   if (splits > nstrips) splits = nstrips;
   if (splits < 1) splits = 1;
@@ -486,7 +488,7 @@ int ganlab_conv_s2_wgrad_x3(const float* gy, const float* x, const float* aff_s,
   a.N = g->N; a.CL = q.CL; a.CB = q.CB; a.Hl = q.Hl; a.Wl = q.Wl;
   a.hshift = 0;
   while ((1 << a.hshift) < a.Hl) ++a.hshift;
-  a.strips_x = a.Wl / 32; a.nstrips = a.N * a.strips_x;
+  a.strips_x = (a.Wl + 31) / 32; a.nstrips = a.N * a.strips_x;
   a.tiles_b = a.CB / XS_CB; a.pairs = pl.pairs; a.splits = pl.splits; a.sps = pl.sps;
   const long long grid = (long long)pl.pairs * pl.splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return GANLAB_EINVAL;

@@ -229,7 +229,7 @@ int ganlab_conv_wgrad_x3(const float* gy, const float* x, const float* aff_s, co
                          const ganlab_conv_geom* g, float scale, void* workspace, size_t workspace_bytes, void* stream);
 /* weight gradient of a stride-2 3x3 layer (csrc/conv_x3_s2_wgrad.hip; geom.pool = 1: avgpool2(conv3(x)), geom.up = 1:
  * conv3(up2(x))): ganlab_conv_s2_wgrad_f32, or with aff_s / aff_t non-null (up layers) ganlab_conv_s2_wgrad_aff_f32, as split
- * products over the 2x2 box sums of the high-resolution operand; low resolution H a power of two >= 4, W % 32 == 0, channels of
+ * products over the 2x2 box sums of the high-resolution operand; low resolution H a power of two >= 4, W % 32 == 0 or W == 16, channels of
  * the low-resolution operand (pool: Cout, up: Cin) % 64 == 0, of the high-resolution one % 32 == 0.  Deterministic. */
 int ganlab_conv_s2_wgrad_x3_supported(const ganlab_conv_geom* g);
 size_t ganlab_conv_s2_wgrad_x3_workspace(const ganlab_conv_geom* g);

@@ -416,7 +416,8 @@ def test_x3_up_layer_input_gradient(ops, case):
 # ---- stride-2 weight gradient: nine taps over the 2x2 box sums of the high-resolution operand ----------------------------------------
 # N, Cin, Cout, Hl, Wl, kind: several strips per image and per workgroup, odd batch sizes (ragged last split), both channel roles
 SW_CASES = [(2, 32, 64, 8, 32, 'pool'), (3, 64, 128, 16, 64, 'pool'), (5, 96, 64, 4, 32, 'pool'), (2, 32, 192, 32, 96, 'pool'),
-            (2, 64, 32, 8, 32, 'up'), (3, 128, 64, 16, 64, 'up'), (5, 64, 96, 4, 32, 'up'), (7, 192, 32, 8, 64, 'up')]
+            (2, 64, 32, 8, 32, 'up'), (3, 128, 64, 16, 64, 'up'), (5, 64, 96, 4, 32, 'up'), (7, 192, 32, 8, 64, 'up'),
+            (3, 64, 64, 8, 16, 'pool'), (2, 64, 64, 16, 16, 'up')]      # 16-pixel-wide low maps: one half-empty strip
 
 
 @pytest.mark.parametrize('case', SW_CASES)
@@ -439,10 +440,15 @@ def test_x3_stride2_weight_gradient(ops, case, aff):
         (lambda: ops.k_conv_wgrad(gy.cuda(), x.cuda(), geom, scale))
     gw3 = run()
     assert 'x3sw_reduce_kernel' in launched(ops)
+    from gan_lab_amd._lib import GanlabLibraryError
     prev = ops.set_x3(False)
-    try:
-        gw1 = run()
-        assert 'x3sw_reduce_kernel' not in launched(ops)
+    try:      # (the exact-fp32 affine-on-load weight gradient does not take 16-pixel-wide maps; the step never asks it to)
+        try:
+            gw1 = run()
+            assert 'x3sw_reduce_kernel' not in launched(ops)
+        except GanlabLibraryError:
+            assert aff and wl == 16
+            gw1 = gw3
     finally:
         ops.set_x3(prev)
     xin = x.double() * s_.double().view(n, ci, 1, 1) + t_.double().view(n, ci, 1, 1) if aff else x.double()
