@@ -478,3 +478,39 @@ def test_x3_stride2_weight_gradient_is_deterministic_and_closes_long_chains(ops)
     gwd, = torch.autograd.grad(F.avg_pool2d(F.conv2d(x.double(), wd, padding=1), 2), wd, gy.double())
     assert_close(a.cpu(), gwd, TOL, 'x3 stride-2 weight gradient (long chains) vs float64')
     assert rms_rel(a, gwd) <= 2.5e-7, rms_rel(a, gwd)
+
+
+@pytest.mark.parametrize('kind', ['pool', 'up'])
+def test_x3_stride2_weight_gradient_full_size_properties(ops, kind):
+    """Batch 32 at a benchmark layer (64 <-> 128 channels, 256^2 <-> 128^2): agreement with the exact kernel, linearity in the
+    output gradient, and the affine-on-load operand against the materialised one (up)."""
+    up = kind == 'up'
+    n, hl = 32, 128
+    ci, co = (128, 64) if up else (64, 128)
+    hi = hl if up else 2 * hl
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(n, ci, hi, hi, device='cuda', generator=g)
+    gshape = (n, co, 2 * hl, 2 * hl) if up else (n, co, hl, hl)
+    g1, g2 = torch.randn(*gshape, device='cuda', generator=g), torch.randn(*gshape, device='cuda', generator=g)
+    geom = ops.Geom(n, ci, hi, hi, co, 3, 1, up=1) if up else ops.Geom(n, ci, hi, hi, co, 3, 1, pool=1)
+    assert ops.x3_s2_wgrad_ok(geom)
+    w1 = ops.k_conv_wgrad(g1, x, geom, 0.02).clone()
+    assert 'x3sw_reduce_kernel' in launched(ops)
+    w2 = ops.k_conv_wgrad(g2, x, geom, 0.02).clone()
+    w12 = ops.k_conv_wgrad(g1 + g2, x, geom, 0.02).clone()
+    assert_close(w12.cpu(), (w1 + w2).cpu(), 1e-5, 'linearity in the output gradient')
+    prev = ops.set_x3(False)
+    try:
+        e1 = ops.k_conv_wgrad(g1, x, geom, 0.02).clone()
+        assert 'x3sw_reduce_kernel' not in launched(ops)
+    finally:
+        ops.set_x3(prev)
+    assert_close(w1.cpu(), e1.cpu(), 1e-5, 'split-product against exact-fp32 kernel at batch 32')
+    if up:
+        s_ = torch.rand(n, ci, device='cuda', generator=g) + 0.5
+        t_ = torch.randn(n, ci, device='cuda', generator=g)
+        wa = ops.k_conv_wgrad_aff(g1, x, s_, t_, geom, 0.02).clone()
+        assert 'x3sw_reduce_kernel' in launched(ops)
+        wm = ops.k_conv_wgrad(g1, x * s_.view(n, ci, 1, 1) + t_.view(n, ci, 1, 1), geom, 0.02)
+        assert_close(wa.cpu(), wm.cpu(), 1e-5, 'affine on load against the materialised operand')
+    print(f'SUMMARY x3 stride-2 weight gradient {kind} x32: linearity, exact-kernel agreement' + (', affine form' if up else '') + ' ok')
