@@ -147,10 +147,13 @@ __device__ __forceinline__ void gl_x3_pack_position(const float* __restrict__ w9
 // parity px][co 64][8]; tap (ty, tx) of parity (py, px) sums the 3x3 weights of rows R(py, ty) x columns R(px, tx): up forward
 // R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}; the input gradient of the pooled conv takes the flipped sets
 // (k -> 2 - k) and 1/2 per axis.  `up`: 1 = forward of the up layer (GEMM rows = Cin), 0 = input gradient of the pooled layer.
+// An output-channel count that is not a multiple of 64 (32: the 64 -> 32 layers) takes the 32-channel layout: a workgroup covers
+// BOTH row parities of 32 channels and an image's 64 columns are [py][co 32] - [co tile 32][k-step][plane][tap][px][py * 32 + co][8].
 __device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__ w9, int up, float scale, __bf16* __restrict__ out,
-                                                       int CI, int ci, int co) {
+                                                       int CI, int CO, int ci, int co) {
   const int nsteps = CI / 8;
-  const int ct = co >> 6, col = co & 63, j = ci & 7;
+  const bool c32 = (CO & 63) != 0;
+  const int ct = c32 ? co >> 5 : co >> 6, j = ci & 7;
 #pragma unroll
   for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -175,7 +178,8 @@ __device__ __forceinline__ void gl_x3_up_pack_position(const float* __restrict__
           const float r1 = v - (float)h;
           const __bf16 mm = (__bf16)r1;
           const __bf16 l = (__bf16)(r1 - (float)mm);
-          __bf16* base = out + ((((long long)ct * 2 + py) * nsteps + (ci >> 3)) * (3 * 4 * 128)) * 8;
+          __bf16* base = out + (((c32 ? (long long)ct : (long long)ct * 2 + py) * nsteps + (ci >> 3)) * (3 * 4 * 128)) * 8;
+          const int col = c32 ? py * 32 + (co & 31) : co & 63;
           const int kgq = ty * 2 + tx;
           base[((0 * 4 + kgq) * 128 + px * 64 + col) * 8 + j] = h;
           base[((1 * 4 + kgq) * 128 + px * 64 + col) * 8 + j] = mm;

@@ -73,7 +73,11 @@ struct XUArgs {
 };
 struct XUTile { int n, oy0, ox0, co_t, py; };
 
-template <bool AFF>
+// C32: the 32-output-channel form (64 -> 32 up layers, the input gradient of 32 -> 64 pooled layers).  The same 128 GEMM columns
+// mean BOTH row parities x both column parities x 32 channels: wave wn owns row parity py = wn (its operand rows are one patch
+// row further down, its weight columns the image's [py][co 32] half) - the tile index loses the parity, everything else is the
+// 64-channel kernel.
+template <bool AFF, bool C32>
 __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
   constexpr int NLOADS = AFF ? 6 : 4;
   __shared__ __attribute__((aligned(16))) u32x4 lds[XU_LDS];
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
   auto decode = [&](int t) {
     XUTile c;
     c.co_t = t % p.tiles_co; t /= p.tiles_co;
-    c.py = t & 1; t >>= 1;
+    if constexpr (C32) c.py = 0;
+    else { c.py = t & 1; t >>= 1; }
     c.ox0 = (t % p.tiles_x) * 16; t /= p.tiles_x;
     c.oy0 = (t % p.tiles_y) * 8;
     c.n = t / p.tiles_y;
@@ -164,9 +169,9 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
 
   // ---- weights: LDS-DMA, one k-step image per stage ----------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u32x4*>(p.wp), 0, (unsigned)((long long)p.tiles_co * 2 * nsteps * XU_WSTEP * 16), 0x00020000);
+      const_cast<u32x4*>(p.wp), 0, (unsigned)((long long)p.tiles_co * (C32 ? 1 : 2) * nsteps * XU_WSTEP * 16), 0x00020000);
   auto w_dma = [&](const XUTile& c, int step, int buf) {
-    const int soff = ((c.co_t * 2 + c.py) * nsteps + step) * (XU_WSTEP * 16) + wv * 3072;
+    const int soff = ((C32 ? c.co_t : c.co_t * 2 + c.py) * nsteps + step) * (XU_WSTEP * 16) + wv * 3072;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + XU_WOFF + buf * XU_WSTEP + wv * 192 + i * 64),
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
   XU_VALU_SETTLE(accH);
 
   // lane's patch unit for column parity 0: tap (ty, tx) = (kg >> 1, kg & 1); rows 2 wm + m + py + ty, columns l16 + px + tx
-  const int laneA = (2 * wm + (kg >> 1)) * 18 + l16 + (kg & 1);
+  const int laneA = (2 * wm + (kg >> 1) + (C32 ? wn : 0)) * 18 + l16 + (kg & 1);
   const int laneB = XU_WOFF + kg * 128 + wn * 32 + l16;
 
   bf16x8 aF[2][2][3];       // [column parity px][row m][plane]
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
       const long long ib = (long long)cur.n * p.CO * plane * 4;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        const int co = cur.co_t * XU_CO + wn * 32 + cb * 16 + l16;
+        const int co = C32 ? cur.co_t * 32 + cb * 16 + l16 : cur.co_t * XU_CO + wn * 32 + cb * 16 + l16;
         const float bv = bias != nullptr ? bias[co] * bias_scale : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(512) void conv_x3_up_kernel(XUArgs p) {
             if (act == GANLAB_ACT_LRELU) { f0 = gl_lrelu(f0, slope); f1 = gl_lrelu(f1, slope); }
             v0[r] = f0; v1[r] = f1;
           }
-          float* dst = y + ib + (long long)co * plane * 4 + (long long)(2 * (cur.oy0 + 2 * wm + m) + cur.py) * oW + 2 * (cur.ox0 + 4 * kg);
+          float* dst = y + ib + (long long)co * plane * 4 + (long long)(2 * (cur.oy0 + 2 * wm + m) + (C32 ? wn : cur.py)) * oW + 2 * (cur.ox0 + 4 * kg);
           *reinterpret_cast<f32x4*>(dst) = f32x4{v0[0], v1[0], v0[1], v1[1]};
           *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v0[2], v1[2], v0[3], v1[3]};
           accT[m][cb] = f32x4{0.f, 0.f, 0.f, 0.f}; accS[m][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -336,12 +341,18 @@ __global__ void x3_up_pack_kernel(const float* __restrict__ w, __bf16* __restric
   const int CO = up ? Cout : Cin, CI = up ? Cin : Cout;        // GEMM roles: up layer's forward (up = 1), pooled layer's input gradient
   const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (e >= (long long)CO * CI) return;
-  const int col = (int)(e & 63);
-  const long long t = e >> 6;
-  const int ci = (int)(t % CI), ct = (int)(t / CI);
-  const int co = ct * 64 + col;
+  int ci, co;
+  if ((CO & 63) == 0) {
+    const int col = (int)(e & 63);
+    const long long t = e >> 6;
+    ci = (int)(t % CI);
+    co = (int)(t / CI) * 64 + col;
+  } else {
+    co = (int)(e % CO);
+    ci = (int)(e / CO);
+  }
   const float* w9 = up ? w + ((long long)co * Cin + ci) * 9 : w + ((long long)ci * Cin + co) * 9;
-  gl_x3_up_pack_position(w9, up, scale, out, CI, ci, co);
+  gl_x3_up_pack_position(w9, up, scale, out, CI, CO, ci, co);
 }
 
 // the transposed form takes: an up layer's forward (dgrad = 0) or a pooled layer's input gradient (dgrad = 1)
@@ -352,17 +363,24 @@ bool xu_ok(const ganlab_conv_geom* g, int dgrad) {
   if (dgrad && ((g->Hin | g->Win) & 1)) return false;
   const int Hl = dgrad ? g->Hin / 2 : g->Hin, Wl = dgrad ? g->Win / 2 : g->Win;      // the up layer's input; the pooled layer's OUTPUT
   if ((long long)CI * Hl * Wl * 4 > 0x7fffffffLL || (long long)g->N * CI * 4 > 0x7fffffffLL) return false;
-  return CI % 64 == 0 && CO % XU_CO == 0 && Hl % 8 == 0 && Wl % 16 == 0;
+  return CI % 64 == 0 && CO % 32 == 0 && Hl % 8 == 0 && Wl % 16 == 0;
 }
 
 int xu_launch(bool aff, XUArgs a, hipStream_t st) {
-  a.tiles_x = a.Wl / 16; a.tiles_y = a.Hl / 8; a.tiles_co = a.CO / XU_CO;
-  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y * a.tiles_co * 2;
-  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)a.tiles_co * 2 * (a.CI / 8) * XU_WSTEP * 16 > 0xffffffffLL) return GANLAB_EINVAL;
+  const bool c32 = a.CO % XU_CO != 0;      // the 32-channel form (gl_x3_up_pack_position packs by the same rule)
+  a.tiles_x = a.Wl / 16; a.tiles_y = a.Hl / 8; a.tiles_co = c32 ? a.CO / 32 : a.CO / XU_CO;
+  const int images = a.tiles_co * (c32 ? 1 : 2);
+  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y * images;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL || (long long)images * (a.CI / 8) * XU_WSTEP * 16 > 0xffffffffLL) return GANLAB_EINVAL;
   a.ntiles = (int)ntiles;
   const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-  if (aff) GL_LAUNCH(conv_x3_up_kernel<true>, dim3(grid), dim3(512), 0, st, a);
-  else GL_LAUNCH(conv_x3_up_kernel<false>, dim3(grid), dim3(512), 0, st, a);
+  if (c32) {
+    if (aff) GL_LAUNCH((conv_x3_up_kernel<true, true>), dim3(grid), dim3(512), 0, st, a);
+    else GL_LAUNCH((conv_x3_up_kernel<false, true>), dim3(grid), dim3(512), 0, st, a);
+  } else {
+    if (aff) GL_LAUNCH((conv_x3_up_kernel<true, false>), dim3(grid), dim3(512), 0, st, a);
+    else GL_LAUNCH((conv_x3_up_kernel<false, false>), dim3(grid), dim3(512), 0, st, a);
+  }
   return GL_CHECK_LAUNCH();
 }
 
@@ -384,7 +402,8 @@ int ganlab_conv_s2_x3_supported(const ganlab_conv_geom* g, int dgrad) { return x
 
 /* `up`: 1 = an up layer's forward weights, 0 = a pooled layer's input-gradient weights; 48*Cout*Cin bf16 elements */
 long long ganlab_conv_s2_x3_pack(const float* w, void* out, int Cout, int Cin, int up, float scale, void* stream) {
-  if (Cout <= 0 || Cin <= 0 || (up != 0 && up != 1) || Cout % 64 != 0 || Cin % 64 != 0) return GANLAB_EINVAL;
+  if (Cout <= 0 || Cin <= 0 || (up != 0 && up != 1)) return GANLAB_EINVAL;
+  if ((up ? Cin : Cout) % 64 != 0 || (up ? Cout : Cin) % 32 != 0) return GANLAB_EINVAL;      // contraction channels, GEMM columns
   const long long n = 48LL * Cout * Cin;       // 16 taps x 3 planes
   if (out == nullptr) return n;
   if (w == nullptr) return GANLAB_EINVAL;

@@ -75,12 +75,18 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const ganlab_pack_desc* 
     const int up = d.up;                                         // forward weights, 0 = pooled layer's input-gradient weights)
     const int CO = up ? d.Cout : d.Cin, CI = up ? d.Cin : d.Cout;
     if (e >= (long long)CO * CI) return;
-    const int col = (int)(e & 63);
-    const long long t = e >> 6;
-    const int ci = (int)(t % CI), ct = (int)(t / CI);
-    const int co = ct * 64 + col;
+    int ci, co;
+    if ((CO & 63) == 0) {
+      const int col = (int)(e & 63);
+      const long long t = e >> 6;
+      ci = (int)(t % CI);
+      co = (int)(t / CI) * 64 + col;
+    } else {
+      co = (int)(e % CO);
+      ci = (int)(e / CO);
+    }
     const float* w9 = up ? w + ((long long)co * d.Cin + ci) * 9 : w + ((long long)ci * d.Cin + co) * 9;
-    gl_x3_up_pack_position(w9, up, d.scale, reinterpret_cast<__bf16*>(d.dst), CI, ci, co);
+    gl_x3_up_pack_position(w9, up, d.scale, reinterpret_cast<__bf16*>(d.dst), CI, CO, ci, co);
   } else if (d.kind == GANLAB_PACKKIND_X3 && d.ks == 5) {      // conv_x3_down.hip, strided stride-2 form (d.up: 0 = pooled layer's
     const int up = d.up;                                         // forward weights, 1 = up layer's input-gradient weights)
     const int CO = up ? d.Cin : d.Cout, CI = up ? d.Cout : d.Cin;

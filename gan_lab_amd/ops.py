@@ -386,7 +386,7 @@ def x3_s2_ok(g, dgrad=False):
         return False
     co = g.Cin if dgrad else g.Cout
     hl, wl = (g.Hin // 2, g.Win // 2) if dgrad else (g.Hin, g.Win)
-    if g.N * (hl // 8) * (wl // 16) * (co // 64) * 2 < _X3_MIN_TILES:
+    if g.N * (hl // 8) * (wl // 16) * (co // 32) < _X3_MIN_TILES:       # (32 output channels: both row parities in one workgroup)
         return False
     return bool(_lib.lib().ganlab_conv_s2_x3_supported(g.ref(), 1 if dgrad else 0))
 

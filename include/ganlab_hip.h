@@ -201,7 +201,8 @@ int ganlab_conv_fwd_aff_x3(const float* x, const void* wp, const float* aff_s, c
 int ganlab_conv_fwd_aff_tail_x3_chunks(const ganlab_conv_geom* g);
 /* the stride-2 fused layers' transposed form (the exact-fp32 T kernel of csrc/conv_s2.hip): ganlab_conv_s2_fwd_f32 /
  * ganlab_conv_s2_fwd_aff_f32 of an up layer (geom.up = 1; dgrad = 0) and ganlab_conv_s2_dgrad_f32 of a pooled layer
- * (geom.pool = 1; dgrad = 1), low resolution H % 16 == 0, W % 16 == 0, channels % 64 == 0.  pack: `up` = 1 packs an up
+ * (geom.pool = 1; dgrad = 1), low resolution H % 8 == 0, W % 16 == 0, contraction channels % 64 == 0, output channels
+ * % 32 == 0 (not a multiple of 64: the 32-channel form - both row parities per workgroup, its own packed layout).  pack: `up` = 1 packs an up
  * layer's forward weights, 0 a pooled layer's input-gradient weights (48*Cout*Cin bf16 elements; in a ganlab_pack_desc:
  * kind GANLAB_PACKKIND_X3 with ks = 4 and the same `up`). */
 int ganlab_conv_s2_x3_supported(const ganlab_conv_geom* g, int dgrad);

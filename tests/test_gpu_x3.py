@@ -210,7 +210,9 @@ def test_x3_switch_restores_exact_path(ops):
 
 
 # ---- the transposed stride-2 form: an up layer's forward (+ affine on load), a pooled layer's input gradient -------------------
-S2_CASES = [(2, 64, 64, 16, 16), (3, 128, 64, 32, 16), (2, 256, 128, 16, 32), (5, 64, 128, 32, 32)]     # N, Cin, Cout, Hl, Wl
+# N, Cin, Cout, Hl, Wl; the last two: output channels not a multiple of 64 - the 32-channel form (both row parities per workgroup)
+S2_CASES = [(2, 64, 64, 16, 16), (3, 128, 64, 32, 16), (2, 256, 128, 16, 32), (5, 64, 128, 32, 32), (2, 64, 32, 16, 16),
+            (3, 128, 96, 8, 32)]
 
 
 @pytest.mark.parametrize('case', S2_CASES)
@@ -284,26 +286,29 @@ def test_x3_s2_batched_repack_equals_single_pack(ops):
     from gan_lab_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(4)
-    wt = torch.randn(128, 64, 3, 3, generator=g).cuda()
-    arr = (_lib.PackDesc * 2)()
-    singles, outs, blocks = [], [], 0
-    for i, up in enumerate((1, 0)):
-        n = L.ganlab_conv_s2_x3_pack(None, None, 128, 64, up, 0.41, None)
-        assert n == 48 * 128 * 64
+    jobs = [(128, 64, 1), (128, 64, 0), (32, 64, 1), (64, 32, 0)]       # Cout, Cin, up (the last two: the 32-channel layout)
+    arr = (_lib.PackDesc * len(jobs))()
+    singles, outs, keep, blocks = [], [], [], 0
+    for i, (co, ci, up) in enumerate(jobs):
+        wt = torch.randn(co, ci, 3, 3, generator=g).cuda()
+        keep.append(wt)
+        n = L.ganlab_conv_s2_x3_pack(None, None, co, ci, up, 0.41, None)
+        assert n == 48 * co * ci
         one = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
-        assert L.ganlab_conv_s2_x3_pack(wt.data_ptr(), one.data_ptr(), 128, 64, up, 0.41, None) == n
+        assert L.ganlab_conv_s2_x3_pack(wt.data_ptr(), one.data_ptr(), co, ci, up, 0.41, None) == n
         out = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
         singles.append(one)
         outs.append(out)
         d = arr[i]
         d.src, d.dst, d.kind, d.Cout, d.Cin, d.ks, d.mode, d.up, d.scale, d.total, d.block0 = \
-            wt.data_ptr(), out.data_ptr(), 3, 128, 64, 4, 0, up, 0.41, n, blocks
-        blocks += (128 * 64 + 255) // 256
+            wt.data_ptr(), out.data_ptr(), 3, co, ci, 4, 0, up, 0.41, n, blocks
+        blocks += (co * ci + 255) // 256
     tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
-    _lib.check(L.ganlab_pack_many(tab.data_ptr(), 2, blocks, None), 'pack_many')
+    _lib.check(L.ganlab_pack_many(tab.data_ptr(), len(jobs), blocks, None), 'pack_many')
     torch.cuda.synchronize()
     for one, out in zip(singles, outs):
         assert torch.equal(one.view(torch.int16), out.view(torch.int16))
+        assert int((one.view(torch.int16) != 0).sum()) > one.numel() // 2       # (every position written)
 
 
 # ---- weight gradient -------------------------------------------------------------------------------------------------------------
