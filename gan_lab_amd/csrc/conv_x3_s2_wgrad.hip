@@ -151,9 +151,7 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
   };
 
   // ---- staging items ---------------------------------------------------------------------------------------------------------
-  // waves 0..3 (vq = 0) build the VP rows (high rows 2y, 2y+1) and run [stage, matrix work] in a k-step, waves 4..7 (vq = 1)
-  // the VQ rows (2y+1, 2y+2) and run [matrix work, stage]: the two waves of a SIMD are half a k-step out of phase, one's
-  // splitting runs under the other's MFMAs
+  // waves 0..3 (vq = 0) build the VP rows (high rows 2y, 2y+1), waves 4..7 (vq = 1) the VQ rows (2y+1, 2y+2)
   const int vq = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int b_ch = (tid & 255) >> 3, b_q = tid & 7;            // box channel, 8-pixel item of the 64 high pixels
   const int l_c = tid >> 3, l_q = tid & 7;                     // low channel, 4-pixel item of the 32 low pixels
@@ -319,11 +317,12 @@ __global__ __launch_bounds__(512) void conv_x3_s2_wgrad_kernel(XSArgs p) {
 
   // One k-step f (u = f & 3; c = f & 1: the L fragments aL[c] and VP[f] in fragment set c were read behind the barrier of the
   // k-step before, under its last 18 MFMAs):
-  //   waves 0..3:  [stage f+1]  VP[f] x L  ->  VQ[f] x L                 | barrier |  read L[f+1], VP[f+1];  VQ[f-1] x L
-  //   waves 4..7:               VP[f] x L  ->  VQ[f] x L  [stage f+1]    | barrier |  ...
-  // (the matrix work stands ONCE in the k-step, outside any branch: accumulators that two paths write get copied.)  The two
-  // waves of a SIMD are out of phase: one splits and stores while the other's 36 MFMAs run; the LDS reads of a group are
-  // issued a group ahead, the first group's across the barrier, so no wave starts a k-step waiting for the LDS.
+  //   [stage f+1]  VP[f] x L  ->  VQ[f] x L   | barrier |  read L[f+1], VP[f+1];  VQ[f-1] x L
+  // (the matrix work stands ONCE in the k-step, outside any branch: accumulators that two paths write get copied.)  The LDS
+  // reads of a group are issued a group ahead, the first group's across the barrier, so no wave starts a k-step waiting for
+  // the LDS.  XS_STAG (A/B builds): 1 = waves 4..7 stage BEHIND their first two groups instead - the two waves of a SIMD half
+  // a k-step out of phase, one's splitting under the other's MFMAs: 10 % slower (0.483 against 0.435 ms, 256 -> 512 low 32^2);
+  // 2 = odd waves late: 0.450.
 #ifndef XS_STAG
 #define XS_STAG 0
 #endif
