@@ -519,3 +519,40 @@ def test_x3_stride2_weight_gradient_full_size_properties(ops, kind):
         wm = ops.k_conv_wgrad(g1, x * s_.view(n, ci, 1, 1) + t_.view(n, ci, 1, 1), geom, 0.02)
         assert_close(wa.cpu(), wm.cpu(), 1e-5, 'affine on load against the materialised operand')
     print(f'SUMMARY x3 stride-2 weight gradient {kind} x32: linearity, exact-kernel agreement' + (', affine form' if up else '') + ' ok')
+
+
+def test_x3_stride2_weight_gradient_several_strips_per_workgroup(ops):
+    """128 channel-tile pairs leave 4 k-splits for 5 strips: workgroups walk 2, 2 and 1 strips (= images here) - the load cursor's
+    strip change, the affine's reload per image and the ragged last split."""
+    n, ci, co, hl, wl = 5, 512, 512, 4, 32
+    g = torch.Generator(device='cuda').manual_seed(23)
+    x = torch.randn(n, ci, hl, wl, device='cuda', generator=g)
+    gy = torch.randn(n, co, 2 * hl, 2 * wl, device='cuda', generator=g)
+    s_ = torch.rand(n, ci, device='cuda', generator=g) + 0.5
+    t_ = torch.randn(n, ci, device='cuda', generator=g)
+    geom = ops.Geom(n, ci, hl, wl, co, 3, 1, up=1)
+    assert ops.x3_s2_wgrad_ok(geom)
+    wa = ops.k_conv_wgrad_aff(gy, x, s_, t_, geom, 0.03).clone()
+    assert 'x3sw_reduce_kernel' in launched(ops)
+    xm = x * s_.view(n, ci, 1, 1) + t_.view(n, ci, 1, 1)
+    wm = ops.k_conv_wgrad(gy, xm, geom, 0.03).clone()
+    prev = ops.set_x3(False)
+    try:
+        we = ops.k_conv_wgrad(gy, xm, geom, 0.03).clone()
+        assert 'x3sw_reduce_kernel' not in launched(ops)
+    finally:
+        ops.set_x3(prev)
+    assert_close(wa.cpu(), wm.cpu(), 1e-5, 'affine on load against the materialised operand')
+    assert_close(wm.cpu(), we.cpu(), 1e-5, 'split-product against exact-fp32 kernel')
+    # and the pooled form with the same tiling
+    xp = torch.randn(n, ci, 2 * hl, 2 * wl, device='cuda', generator=g)
+    gp = torch.randn(n, co, hl, wl, device='cuda', generator=g)
+    geom_p = ops.Geom(n, ci, 2 * hl, 2 * wl, co, 3, 1, pool=1)
+    w3 = ops.k_conv_wgrad(gp, xp, geom_p, 0.03).clone()
+    assert 'x3sw_reduce_kernel' in launched(ops)
+    prev = ops.set_x3(False)
+    try:
+        w1 = ops.k_conv_wgrad(gp, xp, geom_p, 0.03).clone()
+    finally:
+        ops.set_x3(prev)
+    assert_close(w3.cpu(), w1.cpu(), 1e-5, 'pooled form, several strips per workgroup')
