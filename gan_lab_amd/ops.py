@@ -210,6 +210,9 @@ def pack_generation():
     return _PACK_GEN[0]
 
 
+_ALL_ADDRESSES = (0, 1 << 62)
+
+
 def mark_packs_stale():
     """Every cached packed weight is re-packed at its next use, but the cache entries, their buffers and the descriptor
     tables of the batched re-pack stay (``bump_weight_epoch()`` without arguments drops them).  graphs.GraphedStep: a step
@@ -217,8 +220,10 @@ def mark_packs_stale():
     already on the device - and a replay rewrites the parameters behind the host's back."""
     if _PACK_RANGES:
         bump_weight_epoch(list(_PACK_RANGES.keys()))
-    else:
-        bump_weight_epoch()
+    elif _PACK_CACHE:
+        # no range recorded yet (no optimiser step since the last flush): one catch-all range - nothing is dropped, so the
+        # generation, which is part of a step graph's signature, stays: a capture or replay must not invalidate its own graphs
+        bump_weight_epoch([_ALL_ADDRESSES])
 
 
 def _pack_one(e):

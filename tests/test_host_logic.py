@@ -511,3 +511,26 @@ def test_custom_layers_define_tanh_once():
     from gan_lab_amd.utils import custom_layers
     src = inspect.getsource(custom_layers)
     assert src.count('class Tanh(') == 1
+
+
+def test_mark_packs_stale_keeps_the_pack_generation():
+    """With no rewritten range on record the whole cache goes stale through one catch-all range; nothing is dropped and the
+    generation (part of a step graph's signature) does not move - and an empty cache has nothing to go stale."""
+    from gan_lab_amd import ops
+    saved = (dict(ops._PACK_CACHE), dict(ops._PACK_TABLES), dict(ops._PACK_RANGES))
+    try:
+        ops._PACK_CACHE.clear(); ops._PACK_TABLES.clear(); ops._PACK_RANGES.clear()
+        gen = ops.pack_generation()
+        ops.mark_packs_stale()
+        assert ops.pack_generation() == gen and not ops._PACK_RANGES
+        e = ops._PackEntry()
+        e.w, e.out, e.serial, e.ptr, e.desc = None, None, ops._PACK_SERIAL[0], 4096, None
+        ops._PACK_CACHE['k'] = e
+        ops.mark_packs_stale()
+        assert ops.pack_generation() == gen and 'k' in ops._PACK_CACHE
+        assert ops._stale_range(e) == ops._ALL_ADDRESSES
+        ops.mark_packs_stale()          # with a range on record: the same range again, newer serial
+        assert ops.pack_generation() == gen and list(ops._PACK_RANGES) == [ops._ALL_ADDRESSES]
+    finally:
+        ops._PACK_CACHE.clear(); ops._PACK_TABLES.clear(); ops._PACK_RANGES.clear()
+        ops._PACK_CACHE.update(saved[0]); ops._PACK_TABLES.update(saved[1]); ops._PACK_RANGES.update(saved[2])
