@@ -196,7 +196,8 @@ def bump_weight_epoch(ranges=None):
     address ranges), or without arguments to drop every packed weight."""
     _PACK_SERIAL[0] += 1
     if ranges is None:
-        _PACK_GEN[0] += 1
+        if _PACK_CACHE or _PACK_TABLES:      # (a flush that drops nothing leaves the generation - a step graph's signature - alone)
+            _PACK_GEN[0] += 1
         _PACK_CACHE.clear()
         _PACK_TABLES.clear()
         _PACK_RANGES.clear()
