@@ -73,12 +73,14 @@ def ref_resamplers(up, down, align):
     return upsampler, pooler
 
 
-def make_nets(kind, res, blur='binomial', mbstd=4, resample=None, **gkw):
+def make_nets(kind, res, blur='binomial', mbstd=4, resample=None, nl=None, **gkw):
     """Build reference G and D the way the learners do (stylegan/learner.py:114-163,
     progan/learner.py:120-160) and grow them to `res` (fade_in_phase left True)."""
     dkw = {}
     if resample is not None:
         gkw['upsampler'], dkw['pooler'] = ref_resamplers(*resample)
+    if nl == 'tanh':                       # --nonlinearity tanh (config.py:208; the learners hand nn.Tanh() to both networks)
+        gkw['nl'], dkw['nl'] = nn.Tanh(), nn.Tanh()
     if kind == 'stylegan':
         ns.sb.FMAP_BASE, ns.sb.FMAP_MAX = FMAP_BASE, FMAP_MAX
         Base = type('StyleGAN', (nn.Module, ABC,), dict(ns.sb.StyleGAN.__dict__))
@@ -305,6 +307,8 @@ def golden_nets(kind, res, fade_in, alpha, tag, b=4, loss='nonsaturating', gp='r
     if gkw.get('resample') is not None:
         up, down, align = gkw['resample']
         out['resample'] = np.array([up, down, str(int(bool(align)))], dtype='U16')
+    if gkw.get('nl') is not None:
+        out['nl'] = np.array([gkw['nl']], dtype='U16')
     save(f'{tag}.npz', **out)
 
 
@@ -814,6 +818,9 @@ if __name__ == '__main__':
                                             seed=8, resample=('bilinear', 'nearest', False)),
         'sg_bilinear8': lambda: golden_nets('stylegan', 8, False, 1.0, 'stylegan_bilinear8', seed=9,
                                             resample=('bilinear', 'bilinear', False)),
+        # --nonlinearity tanh in the progressive networks (config.py:208, stylegan/learner.py, progan/learner.py: nl=nn.Tanh())
+        'sg_tanh8': lambda: golden_nets('stylegan', 8, False, 1.0, 'stylegan_tanh8', seed=10, nl='tanh'),
+        'pg_tanh8': lambda: golden_nets('progan', 8, True, 0.7, 'progan_tanh8', loss='wgan', gp='wgan-gp', seed=11, nl='tanh'),
         'mixing': golden_mixing,
         'step_sg': lambda: golden_step('stylegan', 16, 'step_stylegan16', 'nonsaturating', 'r1'),
         'step_sg_fade': lambda: golden_step('stylegan', 8, 'step_stylegan8_fade', 'nonsaturating', 'r1',

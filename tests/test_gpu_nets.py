@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def build_pair(kind, res, sd_g, sd_d, resample=None):
+def build_pair(kind, res, sd_g, sd_d, resample=None, nl=None):
     from gan_lab_amd import progressive as P
     from gan_lab_amd.progan.architectures import ProDiscriminator, ProGenerator, StyleDiscriminator
     from gan_lab_amd.stylegan.architectures import StyleGenerator
@@ -22,6 +22,9 @@ def build_pair(kind, res, sd_g, sd_d, resample=None):
     if resample is not None:               # (model_upsample_type, model_downsample_type, align_corners)
         gkw['upsampler'] = make_upsampler(resample[0], resample[2])
         dkw['pooler'] = make_downsampler(resample[1], resample[2])
+    if nl == 'tanh':                       # --nonlinearity tanh: the learners hand one Tanh() to both networks
+        from gan_lab_amd.utils.custom_layers import Tanh
+        gkw['nl'], dkw['nl'] = Tanh(), Tanh()
     if kind == 'stylegan':
         P.StyleGAN.reset_state()
         g = StyleGenerator(final_res=64, len_latent=16, len_dlatent=16, mapping_num_fcs=2, blur_type='binomial', **gkw)
@@ -47,7 +50,8 @@ def _restore_widths():
 
 
 NETS = ['stylegan_stab16', 'stylegan_fade16', 'stylegan_stab32', 'stylegan_stab4', 'stylegan_r2_8', 'progan_stab16', 'progan_fade8',
-        'stylegan_bilinear16', 'progan_nearest16', 'stylegan_bilinear8']    # last three: the other resamplers
+        'stylegan_bilinear16', 'progan_nearest16', 'stylegan_bilinear8',    # these three: the other resamplers
+        'stylegan_tanh8', 'progan_tanh8']                                   # --nonlinearity tanh
 
 
 @pytest.mark.parametrize('name', NETS)
@@ -61,7 +65,8 @@ def test_nets_match_reference_golden(name):
     if 'resample' in G:
         up, down, align = [str(s) for s in G['resample']]
         resample = (up, down, bool(int(align)))
-    g, d = build_pair(kind, res, sub(G, 'g.'), sub(G, 'd.'), resample)
+    nl = str(G['nl'][0]) if 'nl' in G else None
+    g, d = build_pair(kind, res, sub(G, 'g.'), sub(G, 'd.'), resample, nl)
     g.fade_in_phase = fade
     g.alpha = alpha if fade else 1
     g.eval()
