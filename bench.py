@@ -25,7 +25,8 @@ Prints ONE JSON line on rank 0.
 is timed with device events on the launch stream INSIDE the timed steps and priced with its algorithmic FLOPs
 (2*9*Cin*Cout*H*W*B); ``kernel`` / ``grid`` are read back from the library (the symbol that was dispatched).
 ``executed_tflops_step`` / ``frac_of_mfma_peak_step``: convolution FLOPs the step actually EXECUTES (counted in the
-launchers) per second, over the MFMA peak of the compute dtype; ``algorithmic_tflops_step`` prices the same step at
+launchers) per second, over the MFMA peak of the compute dtype (with the split-product kernels on the fraction is reported as
+``fp32_equivalent_over_fp32_mfma_peak_step`` instead: a speed label, the thick layers' products run on the bf16 cores); ``algorithmic_tflops_step`` prices the same step at
 the reference's pass count and is a label, not a roofline fraction.
 ``cpu_baseline``: the CPU oracle's (oracle/, kind "port") G+D step of the same network on the host cores at a reduced
 batch, 1 warm-up + 3 timed steps, median - a reported baseline, not a target.
@@ -702,6 +703,7 @@ def main():
             # NOT the G+D-step definition of the other configurations: every critic iteration's real batch is counted
             metric = (f'real images consumed/sec incl. {wl.nd} critic iters (main iteration = 1 G-iter + {wl.nd} '
                       f'critic iters), {name} {a.res}^2 bs{a.batch}/GPU')
+        x3_on = a.dtype == 'f32' and _ops.x3_enabled()
         out = {
             'metric': metric,
             'value': round(ips, 4), 'unit': 'images/sec', 'n_gpus': world,
@@ -720,7 +722,10 @@ def main():
                        'per_gpu_batch': a.batch, 'parallelism': f'dp{world}' if world > 1 else 'single'},
             # executed: what the launchers ran (per GPU) over the MFMA peak of one GPU - a roofline fraction of the step
             'executed_tflops_step': round(exec_tflops, 2),
-            'frac_of_mfma_peak_step': round(exec_tflops / peak, 4),
+            # with the split-product kernels on, the thick layers' FLOPs run on the bf16 matrix cores (six bf16 products per fp32
+            # product): fp32-equivalent FLOPs over the fp32 peak is then a speed label, not a fraction of one pipe's roofline
+            'frac_of_mfma_peak_step': None if x3_on else round(exec_tflops / peak, 4),
+            'fp32_equivalent_over_fp32_mfma_peak_step': round(exec_tflops / peak, 4) if x3_on else None,
             'executed_conv_tflop_per_step': round(flops.total / 1e12, 3),
             'executed_conv_tflop_by_pass': {k: round(v / 1e12, 3) for k, v in flops.by_kind.items()},
             'conv_launches_per_step': flops.launches,
